@@ -1,0 +1,450 @@
+"""ctypes bindings for the CPU oracle (oracle/dab_oracle.c) and, where it was
+built, for the reference's own stage classes (oracle/_ref/libdabref.so).
+
+TEST INFRASTRUCTURE.  Only tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg may import this package; the product (odr-dabmod_amd) never
+does and fails loudly when its HIP library is missing.
+"""
+import ctypes as C
+import os
+import subprocess
+import tempfile
+
+import numpy as np
+
+_DIR = os.path.dirname(os.path.abspath(__file__))
+REFERENCE_ROOT = "/root/reference"
+
+STAGE_GAIN, STAGE_FIR, STAGE_RESAMPLE, STAGE_POLY = 1, 2, 4, 8
+GAIN_FIX, GAIN_MAX, GAIN_VAR = 0, 1, 2
+
+
+def build(with_ref=None):
+    """(Re)build liboracle.so / liboracle_fast.so, and _ref when the reference
+    checkout is present (this container only)."""
+    subprocess.check_call(["make", "-s", "-C", _DIR, "all"])
+    if with_ref is None:
+        with_ref = os.path.isdir(os.path.join(REFERENCE_ROOT, "src"))
+    if with_ref:
+        subprocess.check_call(["make", "-s", "-C", _DIR, "-j4", "ref"])
+
+
+class _Mode(C.Structure):
+    _fields_ = [(n, C.c_int) for n in ("mode", "nb_symbols", "carriers", "spacing", "null_size",
+                                       "sym_size", "fic_bytes", "frames_per_tf")]
+
+
+class _ChainCfg(C.Structure):
+    _fields_ = [("mode", C.c_int), ("stages", C.c_uint), ("gain_mode", C.c_int),
+                ("dig_gain", C.c_float), ("normalise", C.c_float), ("var_variance", C.c_float),
+                ("window_overlap", C.c_int), ("taps", C.POINTER(C.c_float)), ("ntaps", C.c_int),
+                ("in_rate", C.c_size_t), ("out_rate", C.c_size_t),
+                ("am", C.c_float * 5), ("pm", C.c_float * 5)]
+
+
+_FP = C.POINTER(C.c_float)
+_U8P = C.POINTER(C.c_uint8)
+
+
+def _fp(a):
+    return a.ctypes.data_as(_FP)
+
+
+def _c64(a):
+    return np.ascontiguousarray(a, dtype=np.complex64)
+
+
+def _u8(a):
+    return np.ascontiguousarray(a, dtype=np.uint8)
+
+
+def _load(name):
+    path = os.path.join(_DIR, name)
+    if not os.path.exists(path):
+        build(with_ref=False)
+    lib = C.CDLL(path)
+    lib.dabo_mode_params.argtypes = [C.c_int, C.POINTER(_Mode)]
+    lib.dabo_qpsk_map.argtypes = [_U8P, C.c_size_t, C.c_int, _FP]
+    lib.dabo_freq_interleave_table.argtypes = [C.c_int, C.POINTER(C.c_uint16)]
+    lib.dabo_freq_interleave.argtypes = [_FP, C.c_size_t, C.c_int, _FP]
+    lib.dabo_phase_reference.argtypes = [C.c_int, _FP, _U8P]
+    lib.dabo_diff_mod.argtypes = [_FP, _FP, C.c_size_t, C.c_int, _FP]
+    lib.dabo_signal_mux.argtypes = [_FP, C.c_size_t, _FP, C.c_size_t, _FP]
+    lib.dabo_signal_mux.restype = None
+    lib.dabo_ofdm_generate.argtypes = [_FP, C.c_int, C.c_int, C.c_int, _FP]
+    lib.dabo_gain_control.argtypes = [_FP, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float,
+                                      C.c_float, _FP, _FP]
+    lib.dabo_guard_interval.argtypes = [_FP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _FP]
+    lib.dabo_fir_filter.argtypes = [_FP, C.c_size_t, _FP, C.c_int, _FP]
+    lib.dabo_fir_filter.restype = None
+    lib.dabo_fir_default_taps.argtypes = [C.POINTER(C.c_int)]
+    lib.dabo_fir_default_taps.restype = _FP
+    lib.dabo_resampler_create.argtypes = [C.c_size_t, C.c_size_t, C.c_size_t]
+    lib.dabo_resampler_create.restype = C.c_void_p
+    lib.dabo_resampler_destroy.argtypes = [C.c_void_p]
+    lib.dabo_resampler_destroy.restype = None
+    lib.dabo_resampler_geometry.argtypes = [C.c_void_p] + [C.POINTER(C.c_size_t)] * 4 + [_FP]
+    lib.dabo_resampler_geometry.restype = None
+    lib.dabo_resampler_process.argtypes = [C.c_void_p, _FP, C.c_size_t, _FP]
+    lib.dabo_memless_poly.argtypes = [_FP, C.c_size_t, _FP, _FP, _FP]
+    lib.dabo_memless_poly.restype = None
+    lib.dabo_memless_lut.argtypes = [_FP, C.c_size_t, C.c_float, _FP, _FP]
+    lib.dabo_memless_lut.restype = None
+    lib.dabo_chain_create.argtypes = [C.POINTER(_ChainCfg)]
+    lib.dabo_chain_create.restype = C.c_void_p
+    lib.dabo_chain_destroy.argtypes = [C.c_void_p]
+    lib.dabo_chain_destroy.restype = None
+    lib.dabo_chain_out_samples_per_tf.argtypes = [C.c_void_p]
+    lib.dabo_chain_out_samples_per_tf.restype = C.c_size_t
+    lib.dabo_chain_process.argtypes = [C.c_void_p, _U8P, C.c_size_t, _FP]
+    lib.dabo_dft_f64.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int]
+    lib.dabo_dft_f64.restype = None
+    return lib
+
+
+_lib = None
+_fast = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        _lib = _load("liboracle.so")
+    return _lib
+
+
+def fast_lib():
+    """-O3 -march=native build of the same source, for the timed CPU baseline."""
+    global _fast
+    if _fast is None:
+        _fast = _load("liboracle_fast.so")
+    return _fast
+
+
+def _chk(rc, what):
+    if rc != 0:
+        raise ValueError("oracle: %s rejected its input (rc=%d)" % (what, rc))
+
+
+def mode_params(mode):
+    m = _Mode()
+    _chk(lib().dabo_mode_params(mode, C.byref(m)), "mode_params")
+    return {n: getattr(m, n) for n, _ in _Mode._fields_}
+
+
+def tf_input_bytes(mode):
+    m = mode_params(mode)
+    return (m["nb_symbols"] - 1) * (m["carriers"] // 4)
+
+
+def tf_samples(mode):
+    m = mode_params(mode)
+    return m["null_size"] + m["nb_symbols"] * m["sym_size"]
+
+
+def qpsk_map(bits, carriers):
+    bits = _u8(bits)
+    out = np.empty(bits.size * 4, np.complex64)
+    _chk(lib().dabo_qpsk_map(bits.ctypes.data_as(_U8P), bits.size, carriers, _fp(out)), "qpsk_map")
+    return out
+
+
+def freq_interleave_table(mode):
+    k = mode_params(mode)["carriers"]
+    idx = np.empty(k, np.uint16)
+    _chk(lib().dabo_freq_interleave_table(mode, idx.ctypes.data_as(C.POINTER(C.c_uint16))),
+         "freq_interleave_table")
+    return idx
+
+
+def freq_interleave(x, mode):
+    x = _c64(x)
+    out = np.empty_like(x)
+    _chk(lib().dabo_freq_interleave(_fp(x), x.size, mode, _fp(out)), "freq_interleave")
+    return out
+
+
+def phase_reference(mode):
+    k = mode_params(mode)["carriers"]
+    out = np.empty(k, np.complex64)
+    q = np.empty(k, np.uint8)
+    _chk(lib().dabo_phase_reference(mode, _fp(out), q.ctypes.data_as(_U8P)), "phase_reference")
+    return out, q
+
+
+def diff_mod(phase, data, carriers):
+    phase, data = _c64(phase), _c64(data)
+    if phase.size != carriers:
+        raise ValueError("oracle: diff_mod phase size not valid")
+    out = np.empty(carriers + data.size, np.complex64)
+    _chk(lib().dabo_diff_mod(_fp(phase), _fp(data), data.size, carriers, _fp(out)), "diff_mod")
+    return out
+
+
+def signal_mux(first, rest):
+    first, rest = _c64(first), _c64(rest)
+    out = np.empty(first.size + rest.size, np.complex64)
+    lib().dabo_signal_mux(_fp(first), first.size, _fp(rest), rest.size, _fp(out))
+    return out
+
+
+def ofdm_generate(x, nsym, carriers, spacing):
+    x = _c64(x)
+    if x.size != nsym * carriers:
+        raise ValueError("oracle: ofdm_generate input size not valid")
+    out = np.empty(nsym * spacing, np.complex64)
+    _chk(lib().dabo_ofdm_generate(_fp(x), nsym, carriers, spacing, _fp(out)), "ofdm_generate")
+    return out
+
+
+def gain_control(x, framesize, gain_mode, dig_gain=1.0, normalise=1.0, var_variance=4.0,
+                 return_gains=False):
+    x = _c64(x)
+    out = np.empty_like(x)
+    gains = np.empty(max(1, x.size // framesize), np.float32)
+    _chk(lib().dabo_gain_control(_fp(x), x.size, framesize, gain_mode, dig_gain, normalise,
+                                 var_variance, _fp(out), _fp(gains)), "gain_control")
+    return (out, gains) if return_gains else out
+
+
+def guard_interval(x, nb_symbols, spacing, null_size, sym_size, overlap=0):
+    x = _c64(x)
+    if x.size != (nb_symbols + 1) * spacing:
+        raise ValueError("oracle: guard_interval input size not valid")
+    out = np.zeros(null_size + nb_symbols * sym_size, np.complex64)
+    _chk(lib().dabo_guard_interval(_fp(x), nb_symbols, spacing, null_size, sym_size, overlap,
+                                   _fp(out)), "guard_interval")
+    return out
+
+
+def fir_default_taps():
+    n = C.c_int()
+    p = lib().dabo_fir_default_taps(C.byref(n))
+    return np.ctypeslib.as_array(p, shape=(n.value,)).copy()
+
+
+def fir_filter(x, taps):
+    x = _c64(x)
+    taps = np.ascontiguousarray(taps, np.float32)
+    out = np.empty_like(x)
+    lib().dabo_fir_filter(_fp(x), x.size, _fp(taps), taps.size, _fp(out))
+    return out
+
+
+class Resampler:
+    def __init__(self, in_rate, out_rate, resolution):
+        self._l = lib()
+        self._h = self._l.dabo_resampler_create(in_rate, out_rate, resolution)
+        if not self._h:
+            raise ValueError("oracle: resampler rates not valid")
+        v = [C.c_size_t() for _ in range(4)]
+        f = C.c_float()
+        self._l.dabo_resampler_geometry(self._h, *[C.byref(a) for a in v], C.byref(f))
+        self.L, self.M, self.fft_in, self.fft_out = [a.value for a in v]
+        self.factor = f.value
+
+    def process(self, x):
+        x = _c64(x)
+        out = np.empty(x.size * self.L // self.M, np.complex64)
+        _chk(self._l.dabo_resampler_process(self._h, _fp(x), x.size, _fp(out)), "resampler")
+        return out
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.dabo_resampler_destroy(self._h)
+            self._h = None
+
+
+def memless_poly(x, am, pm):
+    x = _c64(x)
+    am = np.ascontiguousarray(am, np.float32)
+    pm = np.ascontiguousarray(pm, np.float32)
+    assert am.size == 5 and pm.size == 5
+    out = np.empty_like(x)
+    lib().dabo_memless_poly(_fp(x), x.size, _fp(am), _fp(pm), _fp(out))
+    return out
+
+
+def memless_lut(x, scalefactor, lut):
+    x = _c64(x)
+    lut = np.ascontiguousarray(lut, np.float32)
+    assert lut.size == 32
+    out = np.empty_like(x)
+    lib().dabo_memless_lut(_fp(x), x.size, scalefactor, _fp(lut), _fp(out))
+    return out
+
+
+def dft_f64(x, sign):
+    x = np.ascontiguousarray(x, np.complex128)
+    out = np.empty_like(x)
+    lib().dabo_dft_f64(x.ctypes.data_as(C.POINTER(C.c_double)),
+                       out.ctypes.data_as(C.POINTER(C.c_double)), x.size, sign)
+    return out
+
+
+class Chain:
+    """The whole hot path, stage order of src/DabModulator.cpp:385-419."""
+
+    def __init__(self, mode=1, stages=0, gain_mode=GAIN_VAR, dig_gain=1.0, normalise=1.0,
+                 var_variance=4.0, window_overlap=0, taps=None, in_rate=2048000,
+                 out_rate=2048000, am=(1, 0, 0, 0, 0), pm=(0, 0, 0, 0, 0), fast=False):
+        self._l = fast_lib() if fast else lib()
+        cfg = _ChainCfg()
+        cfg.mode, cfg.stages, cfg.gain_mode = mode, stages, gain_mode
+        cfg.dig_gain, cfg.normalise, cfg.var_variance = dig_gain, normalise, var_variance
+        cfg.window_overlap = window_overlap
+        self._taps = np.ascontiguousarray(fir_default_taps() if taps is None else taps, np.float32)
+        cfg.taps, cfg.ntaps = _fp(self._taps), self._taps.size
+        cfg.in_rate, cfg.out_rate = in_rate, out_rate
+        cfg.am = (C.c_float * 5)(*am)
+        cfg.pm = (C.c_float * 5)(*pm)
+        self.mode = mode
+        self._h = self._l.dabo_chain_create(C.byref(cfg))
+        if not self._h:
+            raise ValueError("oracle: chain configuration not valid")
+        self.out_samples_per_tf = self._l.dabo_chain_out_samples_per_tf(self._h)
+        self.in_bytes_per_tf = tf_input_bytes(mode)
+
+    def process(self, bits):
+        bits = _u8(bits).reshape(-1)
+        if bits.size % self.in_bytes_per_tf:
+            raise ValueError("oracle: chain input size not valid")
+        n = bits.size // self.in_bytes_per_tf
+        out = np.empty(n * self.out_samples_per_tf, np.complex64)
+        _chk(self._l.dabo_chain_process(self._h, bits.ctypes.data_as(_U8P), n, _fp(out)), "chain")
+        return out.reshape(n, self.out_samples_per_tf)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._l.dabo_chain_destroy(self._h)
+            self._h = None
+
+
+# --------------------------------------------------------------------------
+# The reference's own stage classes (oracle/_ref/libdabref.so).  Exists only
+# where /root/reference was available at build time (never on the GPU box).
+
+_ref = None
+
+
+def have_ref():
+    return os.path.exists(os.path.join(_DIR, "_ref", "libdabref.so"))
+
+
+def ref():
+    global _ref
+    if _ref is None:
+        r = C.CDLL(os.path.join(_DIR, "_ref", "libdabref.so"))
+        r.ref_qpsk.argtypes = [_U8P, C.c_size_t, C.c_int, _FP]
+        r.ref_freq_interleave.argtypes = [_FP, C.c_size_t, C.c_int, _FP]
+        r.ref_phase_reference.argtypes = [C.c_int, C.c_int, _FP]
+        r.ref_diff_mod.argtypes = [_FP, _FP, C.c_size_t, C.c_int, _FP]
+        r.ref_null_mux.argtypes = [_FP, C.c_size_t, C.c_int, _FP]
+        r.ref_gain_control.argtypes = [_FP, C.c_size_t, C.c_int, C.c_int, C.c_float, C.c_float,
+                                       C.c_float, _FP]
+        r.ref_guard_interval.argtypes = [_FP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _FP]
+        r.ref_fir_filter.argtypes = [_FP, C.c_size_t, C.c_char_p, _FP]
+        r.ref_memless_poly.argtypes = [_FP, C.c_size_t, C.c_char_p, C.c_uint, _FP]
+        _ref = r
+    return _ref
+
+
+def _rchk(rc, what):
+    if rc != 0:
+        raise ValueError("reference: %s failed (rc=%d)" % (what, rc))
+
+
+def ref_qpsk(bits, carriers):
+    bits = _u8(bits)
+    out = np.empty(bits.size * 4, np.complex64)
+    _rchk(ref().ref_qpsk(bits.ctypes.data_as(_U8P), bits.size, carriers, _fp(out)), "qpsk")
+    return out
+
+
+def ref_freq_interleave(x, mode):
+    x = _c64(x)
+    out = np.empty_like(x)
+    _rchk(ref().ref_freq_interleave(_fp(x), x.size, mode, _fp(out)), "freq_interleave")
+    return out
+
+
+def ref_phase_reference(mode):
+    k = mode_params(mode)["carriers"]
+    out = np.empty(k, np.complex64)
+    _rchk(ref().ref_phase_reference(mode, k, _fp(out)), "phase_reference")
+    return out
+
+
+def ref_diff_mod(phase, data, carriers):
+    phase, data = _c64(phase), _c64(data)
+    out = np.empty(carriers + data.size, np.complex64)
+    _rchk(ref().ref_diff_mod(_fp(phase), _fp(data), data.size, carriers, _fp(out)), "diff_mod")
+    return out
+
+
+def ref_null_mux(rest, carriers):
+    rest = _c64(rest)
+    out = np.empty(carriers + rest.size, np.complex64)
+    _rchk(ref().ref_null_mux(_fp(rest), rest.size, carriers, _fp(out)), "null_mux")
+    return out
+
+
+def ref_gain_control(x, framesize, gain_mode, dig_gain=1.0, normalise=1.0, var_variance=4.0):
+    x = _c64(x)
+    out = np.empty_like(x)
+    _rchk(ref().ref_gain_control(_fp(x), x.size, framesize, gain_mode, dig_gain, normalise,
+                                 var_variance, _fp(out)), "gain_control")
+    return out
+
+
+def ref_guard_interval(x, nb_symbols, spacing, null_size, sym_size, overlap=0):
+    x = _c64(x)
+    out = np.zeros(null_size + nb_symbols * sym_size, np.complex64)
+    _rchk(ref().ref_guard_interval(_fp(x), nb_symbols, spacing, null_size, sym_size, overlap,
+                                   _fp(out)), "guard_interval")
+    return out
+
+
+def write_taps_file(path, taps):
+    """Taps file format of src/FIRFilter.cpp:103-133: count, then one tap per line."""
+    with open(path, "w") as f:
+        f.write("%d\n" % len(taps))
+        for t in taps:
+            f.write("%s\n" % t)
+
+
+def ref_fir_filter(x, taps_file="default"):
+    x = _c64(x)
+    out = np.empty_like(x)
+    _rchk(ref().ref_fir_filter(_fp(x), x.size, taps_file.encode(), _fp(out)), "fir_filter")
+    return out
+
+
+def write_poly_file(path, am, pm):
+    """Coefficient file format 1 of src/MemlessPoly.cpp:145-202."""
+    with open(path, "w") as f:
+        f.write("1\n5\n")
+        for v in list(am) + list(pm):
+            f.write("%s\n" % v)
+
+
+def write_lut_file(path, scalefactor, lut):
+    """Coefficient file format 2 of src/MemlessPoly.cpp:203-226."""
+    with open(path, "w") as f:
+        f.write("2\n%s\n" % scalefactor)
+        for v in lut:
+            f.write("%s\n" % v)
+
+
+def ref_memless_poly(x, coef_file, num_threads=1):
+    x = _c64(x)
+    out = np.empty_like(x)
+    _rchk(ref().ref_memless_poly(_fp(x), x.size, coef_file.encode(), num_threads, _fp(out)),
+          "memless_poly")
+    return out
+
+
+def tmp_path(suffix):
+    fd, p = tempfile.mkstemp(suffix=suffix)
+    os.close(fd)
+    return p

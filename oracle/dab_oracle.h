@@ -1,0 +1,152 @@
+/*
+ * dab_oracle.h -- CPU oracle for the DAB per-transmission-frame DSP hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT CODE.  Only tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg may link or call this library; the product
+ * path (odr-dabmod_amd/csrc, the dabgpu_* C-ABI) never does.
+ *
+ * Plain-C, scalar, single-threaded restatement of what ODR-DabMod v3.0.1
+ * computes for each stage; every function cites the reference file:line it
+ * restates (paths relative to the reference checkout).  Sample type is
+ * interleaved (re,im) float32 == std::complex<float> (src/Buffer.h:40).
+ *
+ * Pinning status (details in DESIGN.md section "Oracle"):
+ *   - qpsk, freq-interleave, phase-ref, diff-mod, signal-mux, gain (fix/max/
+ *     var), guard interval (overlap 0 and >0), FIR, MemlessPoly (poly + LUT):
+ *     PINNED bit-for-bit against the reference's own stage classes compiled
+ *     from /root/reference (oracle/Makefile target `ref`, output oracle/_ref/)
+ *     and against the golden fixtures in tests/golden/ generated from them.
+ *   - OfdmGenerator and Resampler call FFTW3f (third-party, not vendored,
+ *     version unpinned: configure.ac:80) and cannot be compiled in this image
+ *     (no fftw3.h, no stand-ins allowed): for these two the FFT arithmetic is
+ *     PARITY UNPINNED against a reference run; it is pinned by definition
+ *     instead (FFTW computes the exact unnormalised DFT; the oracle evaluates
+ *     that DFT in float64 and rounds once to float32).  The code around the
+ *     FFT (bin mapping, window, zero-stuffing, scaling, overlap-add) restates
+ *     the reference lines cited at each function.
+ *
+ * Build: -O2 -ffp-contract=off (no FMA contraction, like the reference's
+ * default x86-64 build) so the float stages reproduce the reference bit for bit.
+ */
+#ifndef DAB_ORACLE_H
+#define DAB_ORACLE_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Transmission-mode geometry (src/DabModulator.cpp:84-122). */
+typedef struct {
+    int mode;          /* 1..4 */
+    int nb_symbols;    /* data symbols incl. phase reference (76 / 153) */
+    int carriers;      /* K */
+    int spacing;       /* N, FFT size */
+    int null_size;     /* samples of the NULL symbol incl. guard */
+    int sym_size;      /* samples of a data symbol incl. guard */
+    int fic_bytes;     /* punctured FIC bytes per ETI frame */
+    int frames_per_tf; /* ETI frames per transmission frame (src/BlockPartitioner.cpp:44-73) */
+} dabo_mode_t;
+
+int dabo_mode_params(int mode, dabo_mode_t *p); /* 0 ok, -1 invalid mode */
+
+/* bytes of hot-path input per TF = (nb_symbols-1) * carriers/4 */
+size_t dabo_tf_input_bytes(const dabo_mode_t *p);
+/* complex samples per TF = null_size + nb_symbols*sym_size */
+size_t dabo_tf_samples(const dabo_mode_t *p);
+
+/* a1  src/QpskSymbolMapper.cpp:39-213.  nbytes must be a multiple of
+ * carriers/4 (returns -1 otherwise, where the reference throws). out holds
+ * nbytes*4 complex samples. */
+int dabo_qpsk_map(const uint8_t *in, size_t nbytes, int carriers, float *out);
+
+/* a2  src/FrequencyInterleaver.cpp:31-93: permutation table (K entries). */
+int dabo_freq_interleave_table(int mode, uint16_t *idx);
+/* a2  src/FrequencyInterleaver.cpp:103-126. nsamples % K must be 0 (-1). */
+int dabo_freq_interleave(const float *in, size_t nsamples, int mode, float *out);
+
+/* a3  src/PhaseReference.cpp:35-44,91-124,152-171. Also returns the quarter-turn
+ * index (0..3) per carrier in qidx when non-NULL. */
+int dabo_phase_reference(int mode, float *out, uint8_t *qidx);
+
+/* a4  src/DifferentialModulator.cpp:45-76. out holds K + ndata samples. */
+int dabo_diff_mod(const float *phase, const float *data, size_t ndata, int carriers, float *out);
+
+/* a5  src/NullSymbol.cpp:49-57 + src/SignalMultiplexer.cpp:45-71: out = first ++ rest. */
+void dabo_signal_mux(const float *first, size_t nfirst, const float *rest, size_t nrest, float *out);
+
+/* a6  src/OfdmGenerator.cpp:77-94,157-308 (CFR off).  in: nsym*K, out: nsym*N.
+ * DFT evaluated in float64, rounded once to float32. */
+int dabo_ofdm_generate(const float *in, int nsym, int carriers, int spacing, float *out);
+
+/* a7  src/GainControl.cpp:82-192 with the SSE statistics of :196-340.
+ * gain_mode: 0 fix, 1 max, 2 var (src/GainControl.h:45). nsamples % framesize == 0.
+ * If gains != NULL it receives the per-symbol gain actually applied
+ * (mode gain * normalise * digital). */
+int dabo_gain_control(const float *in, size_t nsamples, int framesize, int gain_mode,
+                      float dig_gain, float normalise, float var_variance,
+                      float *out, float *gains);
+
+/* a8  src/GuardIntervalInserter.cpp:96-113 (window), :115-323 (copy / overlap).
+ * in: (nb_symbols+1)*spacing, out: null_size + nb_symbols*sym_size. */
+int dabo_guard_interval(const float *in, int nb_symbols, int spacing, int null_size,
+                        int sym_size, int overlap, float *out);
+
+/* a9  src/FIRFilter.cpp:144-192 (SSE path): look-ahead FIR on interleaved
+ * floats, truncated at the end of the buffer, mul-then-add in tap order. */
+void dabo_fir_filter(const float *in, size_t nsamples, const float *taps, int ntaps, float *out);
+/* src/FIRFilter.cpp:59-71 (== doc/fir-filter/filtertaps.txt). */
+const float *dabo_fir_default_taps(int *ntaps);
+
+/* a10 src/Resampler.cpp:51-112 (setup), :131-195 (process). Stateful. */
+typedef struct dabo_resampler dabo_resampler;
+dabo_resampler *dabo_resampler_create(size_t in_rate, size_t out_rate, size_t resolution);
+void dabo_resampler_destroy(dabo_resampler *r);
+void dabo_resampler_geometry(const dabo_resampler *r, size_t *L, size_t *M,
+                             size_t *fft_in, size_t *fft_out, float *factor);
+/* nsamples must be a multiple of fft_in/2. out holds nsamples*L/M samples. */
+int dabo_resampler_process(dabo_resampler *r, const float *in, size_t nsamples, float *out);
+
+/* a11 src/MemlessPoly.cpp:237-276 (polynomial), :278-309 (LUT). */
+void dabo_memless_poly(const float *in, size_t nsamples, const float am[5], const float pm[5], float *out);
+void dabo_memless_lut(const float *in, size_t nsamples, float scalefactor,
+                      const float lut_re[32], float *out);
+
+/* ---- the chain, stage order of src/DabModulator.cpp:385-419 ------------- */
+enum {
+    DABO_STAGE_GAIN     = 1 << 0,
+    DABO_STAGE_FIR      = 1 << 1,
+    DABO_STAGE_RESAMPLE = 1 << 2,
+    DABO_STAGE_POLY     = 1 << 3
+};
+
+typedef struct {
+    int mode;
+    unsigned stages;      /* DABO_STAGE_* mask; qpsk..ofdm and guard always run */
+    int gain_mode;        /* 0 fix 1 max 2 var */
+    float dig_gain, normalise, var_variance;
+    int window_overlap;
+    const float *taps; int ntaps;
+    size_t in_rate, out_rate;      /* resampler */
+    float am[5], pm[5];
+} dabo_chain_cfg;
+
+typedef struct dabo_chain dabo_chain;
+dabo_chain *dabo_chain_create(const dabo_chain_cfg *cfg);
+void dabo_chain_destroy(dabo_chain *c);
+size_t dabo_chain_out_samples_per_tf(const dabo_chain *c);
+/* bits: nframes * dabo_tf_input_bytes; out: nframes * out_samples_per_tf complex.
+ * Frames are fed in order through ONE stream (resampler state carries over).
+ * Pipeline latency of PipelinedModCodec (src/ModPlugin.cpp:90-115) is NOT
+ * modelled: frame i's output is the fully processed frame i. */
+int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float *out);
+
+/* float64 unnormalised DFT used by a6/a10, exposed for tests: sign=+1 backward. */
+void dabo_dft_f64(const double *in_ri, double *out_ri, size_t n, int sign);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
