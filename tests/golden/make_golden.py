@@ -1,0 +1,101 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/golden.json from the REFERENCE's own stage classes.
+
+Runs only where /root/reference exists (the build container): it drives
+oracle/_ref/libdabref.so, which oracle/Makefile compiles from the reference's
+sources where they lie (never copied).  What is committed is data only:
+
+  * the hot-path input bits per transmission mode (bits_mode<m>.bin), produced
+    by the pure-integer generator below (no libm, no RNG library), and
+  * golden.json: SHA-256 of the byte image of each reference stage's output,
+    plus a few head samples as hex for human inspection.
+
+Integer stages (QpskSymbolMapper .. SignalMultiplexer) are fed from the bits.
+Float stages (GainControl, GuardIntervalInserter, FIRFilter, MemlessPoly) are
+fed from `synth_signal`, an exactly representable pseudo-random complex signal
+with the RMS of an OFDM symbol, so that the fixture does not depend on any FFT
+or libm implementation.  OfdmGenerator and Resampler are absent: they need
+FFTW3f, which is not installed, so no reference run of them exists (see
+oracle/dab_oracle.h "Pinning status").
+"""
+import hashlib
+import json
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
+from tests.golden.synth import synth_bits, synth_signal, POLY_AM, POLY_PM, LUT_SCALE, lut_table  # noqa: E402
+import oracle as O  # noqa: E402
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def head(a, n=4):
+    return np.ascontiguousarray(a).view(np.uint32)[: 2 * n].tolist()
+
+
+def main():
+    if not O.have_ref():
+        O.build(with_ref=True)
+    gold = {"_about": "SHA-256 of reference-stage outputs; see make_golden.py", "modes": {}}
+    for mode in (1, 2, 3, 4):
+        m = O.mode_params(mode)
+        K, N = m["carriers"], m["spacing"]
+        bits = synth_bits(O.tf_input_bytes(mode), seed=mode)
+        bits.tofile(os.path.join(HERE, "bits_mode%d.bin" % mode))
+        g = {}
+        q = O.ref_qpsk(bits, K)
+        g["qpsk"] = {"sha256": sha(q), "head": head(q)}
+        fi = O.ref_freq_interleave(q, mode)
+        g["freq_interleave"] = {"sha256": sha(fi), "head": head(fi)}
+        pr = O.ref_phase_reference(mode)
+        g["phase_reference"] = {"sha256": sha(pr), "head": head(pr)}
+        dm = O.ref_diff_mod(pr, fi, K)
+        g["diff_mod"] = {"sha256": sha(dm), "head": head(dm[K:])}
+        mx = O.ref_null_mux(dm, K)
+        g["signal_mux"] = {"sha256": sha(mx)}
+
+        nsym = m["nb_symbols"] + 1
+        x = synth_signal(nsym * N, seed=100 + mode)
+        g["synth_signal"] = {"sha256": sha(x), "head": head(x)}
+        for gm, name in ((0, "fix"), (1, "max"), (2, "var")):
+            for norm, nn in ((1.0, "n1"), (1.0 / 50000.0, "n50000")):
+                y = O.ref_gain_control(x, N, gm, 1.0, norm, 4.0)
+                g["gain_%s_%s" % (name, nn)] = {"sha256": sha(y), "head": head(y[N:])}
+        y = O.ref_gain_control(x, N, 2, 0.8, 1.0 / 50000.0, 3.5)
+        g["gain_var_dig0.8_var3.5"] = {"sha256": sha(y)}
+        xg = O.ref_gain_control(x, N, 2, 1.0, 1.0 / 50000.0, 4.0)
+        for ov in (0, 10):
+            y = O.ref_guard_interval(xg, m["nb_symbols"], N, m["null_size"], m["sym_size"], ov)
+            g["guard_ov%d" % ov] = {"sha256": sha(y), "head": head(y)}
+        gi = O.ref_guard_interval(xg, m["nb_symbols"], N, m["null_size"], m["sym_size"], 0)
+        f = O.ref_fir_filter(gi, "default")
+        g["fir_default"] = {"sha256": sha(f), "head": head(f)}
+        # taps through the taps-file parser, using the reference's data file
+        f2 = O.ref_fir_filter(gi, os.path.join(O.REFERENCE_ROOT, "doc/fir-filter/filtertaps.txt"))
+        g["fir_tapsfile"] = {"sha256": sha(f2)}
+        pf = O.tmp_path(".coef")
+        O.write_poly_file(pf, POLY_AM, POLY_PM)
+        p = O.ref_memless_poly(f, pf, 1)
+        g["poly"] = {"sha256": sha(p), "head": head(p)}
+        p_id = O.ref_memless_poly(f, os.path.join(O.REFERENCE_ROOT, "python/poly.coef"), 2)
+        g["poly_identity_file"] = {"sha256": sha(p_id)}
+        lf = O.tmp_path(".lut")
+        O.write_lut_file(lf, repr(float(LUT_SCALE)), [repr(float(v)) for v in lut_table()])
+        pl = O.ref_memless_poly(f, lf, 1)
+        g["lut"] = {"sha256": sha(pl)}
+        os.unlink(pf)
+        os.unlink(lf)
+        gold["modes"][str(mode)] = g
+    with open(os.path.join(HERE, "golden.json"), "w") as fo:
+        json.dump(gold, fo, indent=1, sort_keys=True)
+    print("wrote", os.path.join(HERE, "golden.json"))
+
+
+if __name__ == "__main__":
+    main()

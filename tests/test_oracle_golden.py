@@ -1,0 +1,205 @@
+"""The oracle against the golden fixtures generated from the reference's own
+stage classes (tests/golden/make_golden.py), and against independent float64
+math for the two FFTW-backed stages.  CPU only."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import pytest
+
+import oracle as O
+from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, lut_table, synth_bits, synth_signal)
+
+GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
+GOLD = json.load(open(os.path.join(GOLD_DIR, "golden.json")))["modes"]
+
+
+def sha(a):
+    return hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+
+
+def bits_for(mode):
+    b = np.fromfile(os.path.join(GOLD_DIR, "bits_mode%d.bin" % mode), dtype=np.uint8)
+    assert b.size == O.tf_input_bytes(mode)
+    return b
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_synth_generators_reproduce_committed_inputs(mode):
+    assert np.array_equal(synth_bits(O.tf_input_bytes(mode), seed=mode), bits_for(mode))
+    m = O.mode_params(mode)
+    x = synth_signal((m["nb_symbols"] + 1) * m["spacing"], seed=100 + mode)
+    assert sha(x) == GOLD[str(mode)]["synth_signal"]["sha256"]
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_integer_stages_bit_exact_vs_reference(mode):
+    g = GOLD[str(mode)]
+    m = O.mode_params(mode)
+    K = m["carriers"]
+    q = O.qpsk_map(bits_for(mode), K)
+    assert sha(q) == g["qpsk"]["sha256"]
+    fi = O.freq_interleave(q, mode)
+    assert sha(fi) == g["freq_interleave"]["sha256"]
+    pr, _ = O.phase_reference(mode)
+    assert sha(pr) == g["phase_reference"]["sha256"]
+    dm = O.diff_mod(pr, fi, K)
+    assert sha(dm) == g["diff_mod"]["sha256"]
+    mx = O.signal_mux(np.zeros(K, np.complex64), dm)
+    assert sha(mx) == g["signal_mux"]["sha256"]
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_float_stages_bit_exact_vs_reference(mode):
+    g = GOLD[str(mode)]
+    m = O.mode_params(mode)
+    N = m["spacing"]
+    x = synth_signal((m["nb_symbols"] + 1) * N, seed=100 + mode)
+    for gm, name in ((0, "fix"), (1, "max"), (2, "var")):
+        for norm, nn in ((1.0, "n1"), (1.0 / 50000.0, "n50000")):
+            y = O.gain_control(x, N, gm, 1.0, norm, 4.0)
+            assert sha(y) == g["gain_%s_%s" % (name, nn)]["sha256"], (name, nn)
+    assert sha(O.gain_control(x, N, 2, 0.8, 1.0 / 50000.0, 3.5)) == g["gain_var_dig0.8_var3.5"]["sha256"]
+    xg = O.gain_control(x, N, 2, 1.0, 1.0 / 50000.0, 4.0)
+    for ov in (0, 10):
+        y = O.guard_interval(xg, m["nb_symbols"], N, m["null_size"], m["sym_size"], ov)
+        assert sha(y) == g["guard_ov%d" % ov]["sha256"], ov
+    gi = O.guard_interval(xg, m["nb_symbols"], N, m["null_size"], m["sym_size"], 0)
+    f = O.fir_filter(gi, O.fir_default_taps())
+    assert sha(f) == g["fir_default"]["sha256"]
+    assert g["fir_default"]["sha256"] == g["fir_tapsfile"]["sha256"]
+    assert sha(O.memless_poly(f, POLY_AM, POLY_PM)) == g["poly"]["sha256"]
+    assert sha(O.memless_poly(f, [1, 0, 0, 0, 0], [0, 0, 0, 0, 0])) == g["poly_identity_file"]["sha256"]
+    assert sha(O.memless_lut(f, LUT_SCALE, lut_table())) == g["lut"]["sha256"]
+
+
+def test_fir_default_taps_are_symmetric_lowpass():
+    t = O.fir_default_taps()
+    assert t.size == 45 and np.array_equal(t, t[::-1])
+    assert abs(float(t.astype(np.float64).sum()) - 1.0) < 2e-3
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_freq_interleave_table_is_a_permutation(mode):
+    idx = O.freq_interleave_table(mode)
+    K = O.mode_params(mode)["carriers"]
+    assert sorted(idx.tolist()) == list(range(K))
+
+
+def test_input_size_checks_match_reference_throws():
+    with pytest.raises(ValueError):
+        O.qpsk_map(np.zeros(383, np.uint8), 1536)       # src/QpskSymbolMapper.cpp:109-115
+    with pytest.raises(ValueError):
+        O.freq_interleave(np.zeros(1535, np.complex64), 1)  # src/FrequencyInterleaver.cpp:110-113
+    with pytest.raises(ValueError):
+        O.diff_mod(np.zeros(1536, np.complex64), np.zeros(100, np.complex64), 1536)
+    with pytest.raises(ValueError):
+        O.ofdm_generate(np.zeros(10, np.complex64), 77, 1536, 2048)  # src/OfdmGenerator.cpp:170-177
+    with pytest.raises(ValueError):
+        O.gain_control(np.zeros(2047, np.complex64), 2048, 2)        # src/GainControl.cpp:127-130
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_ofdm_matches_float64_dft_definition(mode):
+    """a6: FFTW is absent; the oracle is pinned by definition to the exact
+    unnormalised backward DFT (numpy pocketfft float64 as the independent check)."""
+    m = O.mode_params(mode)
+    K, N, nsym = m["carriers"], m["spacing"], m["nb_symbols"] + 1
+    pr, _ = O.phase_reference(mode)
+    dm = O.diff_mod(pr, O.freq_interleave(O.qpsk_map(bits_for(mode), K), mode), K)
+    z = O.signal_mux(np.zeros(K, np.complex64), dm)
+    t = O.ofdm_generate(z, nsym, K, N).reshape(nsym, N)
+    X = np.zeros((nsym, N), np.complex128)
+    zz = z.reshape(nsym, K)
+    X[:, 1:K // 2 + 1] = zz[:, :K // 2]          # src/OfdmGenerator.cpp:211-221
+    X[:, N - K // 2:] = zz[:, K // 2:]
+    ref = np.fft.ifft(X, axis=1) * N
+    assert np.all(t[0] == 0)
+    rel = np.linalg.norm(t - ref) / np.linalg.norm(ref)
+    assert rel < 1e-7
+    # unnormalised: data-symbol RMS is sqrt(K)
+    assert abs(np.sqrt(np.mean(np.abs(t[1:]) ** 2)) - np.sqrt(K)) < 1e-3 * np.sqrt(K)
+
+
+def _resampler_model(x, nin, nout, factor):
+    w = (0.5 * (1 - np.cos(2 * np.pi * np.arange(nin) / (nin - 1)))).astype(np.float32)
+    hin, hout = nin // 2, nout // 2
+    prev = np.zeros(hin, np.complex128)
+    tail = np.zeros(hout, np.complex128)
+    out = []
+    for h in range(x.size // hin):
+        cur = x[h * hin:(h + 1) * hin].astype(np.complex128)
+        F = np.fft.fft(np.concatenate([prev, cur]) * w)
+        B = np.zeros(nout, np.complex128)
+        if nout > nin:
+            B[:hin] = F[:hin]
+            B[nout - hin:] = F[hin:]
+            B[hin] = F[hin]
+        else:
+            B[:hout] = F[:hout]
+            B[hout:] = F[nin - hout:]
+            B[hout] = 0.5 * (F[nin - hout] + F[hout])
+        y = np.fft.ifft(B * factor) * nout
+        out.append(tail + y[:hout])
+        tail = y[hout:]
+        prev = cur
+    return np.concatenate(out)
+
+
+@pytest.mark.parametrize("out_rate", [8192000, 4096000, 1024000])
+def test_resampler_matches_float64_model_across_two_frames(out_rate):
+    """a10: state carries across frames (src/Resampler.cpp:142-192): feed two TFs."""
+    r = O.Resampler(2048000, out_rate, 2048)
+    assert r.fft_in == 4096
+    x = synth_signal(2 * 49152, seed=5) * np.float32(1 / 64)
+    y = np.concatenate([r.process(x[:49152]), r.process(x[49152:])])
+    ref = _resampler_model(x, r.fft_in, r.fft_out, np.float64(r.factor))
+    assert y.size == x.size * r.L // r.M
+    assert np.linalg.norm(y - ref) / np.linalg.norm(ref) < 2e-7
+
+
+def test_resampler_geometry_x4():
+    r = O.Resampler(2048000, 8192000, 2048)       # src/DabModulator.cpp:265-268
+    assert (r.L, r.M, r.fft_in, r.fft_out) == (4, 1, 4096, 16384)
+    assert r.factor == 2.0 ** -12
+
+
+def test_chain_equals_stage_by_stage():
+    mode = 2
+    m = O.mode_params(mode)
+    K, N = m["carriers"], m["spacing"]
+    bits = np.concatenate([bits_for(mode), synth_bits(O.tf_input_bytes(mode), seed=77)])
+    ch = O.Chain(mode=mode, stages=O.STAGE_GAIN | O.STAGE_FIR, normalise=1 / 50000.0)
+    out = ch.process(bits)
+    assert out.shape == (2, O.tf_samples(mode))
+    pr, _ = O.phase_reference(mode)
+    for f in range(2):
+        b = bits[f * ch.in_bytes_per_tf:(f + 1) * ch.in_bytes_per_tf]
+        z = O.signal_mux(np.zeros(K, np.complex64),
+                         O.diff_mod(pr, O.freq_interleave(O.qpsk_map(b, K), mode), K))
+        t = O.ofdm_generate(z, m["nb_symbols"] + 1, K, N)
+        t = O.gain_control(t, N, O.GAIN_VAR, 1.0, 1 / 50000.0, 4.0)
+        t = O.guard_interval(t, m["nb_symbols"], N, m["null_size"], m["sym_size"], 0)
+        t = O.fir_filter(t, O.fir_default_taps())
+        assert np.array_equal(t.view(np.uint32), out[f].view(np.uint32))
+
+
+@pytest.mark.skipif(not O.have_ref(), reason="reference build (oracle/_ref) not present")
+def test_oracle_vs_live_reference_on_fresh_random_input():
+    rng = np.random.default_rng(2024)
+    mode = 4
+    m = O.mode_params(mode)
+    K, N = m["carriers"], m["spacing"]
+    bits = rng.integers(0, 256, O.tf_input_bytes(mode), dtype=np.uint8)
+    q = O.qpsk_map(bits, K)
+    assert np.array_equal(q.view(np.uint32), O.ref_qpsk(bits, K).view(np.uint32))
+    fi = O.freq_interleave(q, mode)
+    assert np.array_equal(fi.view(np.uint32), O.ref_freq_interleave(q, mode).view(np.uint32))
+    pr, _ = O.phase_reference(mode)
+    dm = O.diff_mod(pr, fi, K)
+    assert np.array_equal(dm.view(np.uint32), O.ref_diff_mod(pr, fi, K).view(np.uint32))
+    t = O.ofdm_generate(O.signal_mux(np.zeros(K, np.complex64), dm), m["nb_symbols"] + 1, K, N)
+    for gm in (0, 1, 2):
+        a = O.gain_control(t, N, gm, 1.0, 1.0, 4.0)
+        assert np.array_equal(a.view(np.uint32), O.ref_gain_control(t, N, gm, 1.0, 1.0, 4.0).view(np.uint32))
