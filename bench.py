@@ -1,0 +1,236 @@
+#!/usr/bin/env python3
+"""bench.py -- Mode-I TX frames/s of the MI355X-native DAB hot path.
+
+    python bench.py --gpus N --steps K --warmup W [--workload cfg3] [--frames B]
+
+A "step" is one pass of the hot path over one batch of B synthetic transmission
+frames (inputs resident in HBM before the timed region).  For N > 1 the driver
+launches one rank per GPU through torch.distributed.run; frames are independent
+units, so every rank runs its own stream of batches (weak scaling, no data-path
+collective); the only collectives are the barrier around the timed region and
+the MAX-reduce of the elapsed time.
+
+Workloads (BASELINE.json configs):
+  cfg3 (default)  coded bits -> QPSK/interleave/diff-mod -> 77x IFFT -> GainControl(var)
+                  -> guard interval -> FIRFilter(45 default taps), native 2.048 Msps
+  cfg2            SignalMultiplexer output (cf32) -> OfdmGenerator + GuardIntervalInserter
+  cfg4            cfg3 + Resampler 2.048->8.192 Msps + MemlessPoly
+
+One JSON line on stdout (rank 0).
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+
+# ALGORITHMIC (compulsory) bytes per transmission frame, SURVEY 8(d) / BASELINE.md section 3
+ALGO_BYTES = {
+    "cfg2": 946176 + 1572864,        # 77x1536 cf32 read + 196608 cf32 written
+    "cfg3": 28800 + 1572864,         # coded bits read + native-rate IQ written
+    "cfg4": 28800 + 6291456,         # coded bits read + 8.192 Msps IQ written
+}
+
+
+def pkg():
+    mod = importlib.import_module("odr-dabmod_amd")
+    sys.modules["odr_dabmod_amd"] = mod
+    return mod
+
+
+def cpu_baseline(workload, seconds_budget=12.0):
+    """The oracle's chain (kind "port": -O3 -march=native build of oracle/dab_oracle.c,
+    one thread) timed on a bounded sample of the same workload."""
+    import numpy as np
+    import oracle as O
+    from tests.golden.synth import synth_bits
+    kw = dict(mode=1, fast=True)
+    if workload == "cfg2":
+        kw.update(stages=0)
+    elif workload == "cfg3":
+        kw.update(stages=3, gain_mode=2, normalise=1.0 / 50000.0)
+    else:
+        kw.update(stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000,
+                  am=(1.0, 0.05, -0.01, 0.002, 0.0), pm=(0.0, 0.02, 0.003, 0.0, 0.0))
+    ch = O.Chain(**kw)
+    bits = np.stack([synth_bits(28800, seed=500 + i) for i in range(8)])
+    t0 = time.perf_counter()
+    ch.process(bits[:2])
+    per = (time.perf_counter() - t0) / 2
+    n = int(max(8, min(4096, seconds_budget / max(per, 1e-6))))
+    n -= n % 8
+    t0 = time.perf_counter()
+    for i in range(n // 8):
+        ch.process(bits)
+    dt = time.perf_counter() - t0
+    return {"value": round(n / dt, 3), "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d Mode-I frames, %s chain, oracle/dab_oracle.c -O3 -march=native, "
+                      "1 thread, %.1f s" % (n, workload, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", default="cfg3", choices=sorted(ALGO_BYTES))
+    ap.add_argument("--frames", type=int, default=2048, help="transmission frames per step per GPU")
+    ap.add_argument("--chunks", type=int, default=0, help="workgroups per frame (0 = auto)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    P = pkg()
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+
+    def run_workload(workload, B, steps, warmup):
+        md = P.Modulator(mode=1, device=local_rank, max_frames=B, chunks_per_frame=args.chunks)
+        md.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        if workload == "cfg2":
+            stages, from_bits = 0, False
+        elif workload == "cfg3":
+            stages, from_bits = P.STAGE_GAIN | P.STAGE_FIR, True
+        else:
+            stages, from_bits = P.STAGE_GAIN | P.STAGE_FIR | P.STAGE_RESAMPLE | P.STAGE_POLY, True
+            md.set_resampler(2048000, 8192000)
+            md.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0])
+        ns = md.out_samples_per_frame(stages)
+        stream = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(stream):
+            # synthetic hot-path input: uniform random bytes, resident in HBM
+            rs = np.random.RandomState(42 + rank)
+            bits = np.frombuffer(rs.bytes(B * 28800), dtype=np.uint8).reshape(B, 28800)
+            d_bits = torch.from_numpy(bits.copy()).to(dev)
+            if from_bits:
+                d_in = d_bits
+            else:
+                # cfg2 input = SignalMultiplexer output: produce it on the device once
+                # (QPSK constellation points of the same bits, unit modulus, blank NULL symbol)
+                d_in = torch.zeros((B, 77 * 1536), dtype=torch.complex64, device=dev)
+                q = torch.randint(0, 4, (B, 76 * 1536), device=dev)
+                ang = (q.float() * 2 + 1) * (np.pi / 4)
+                d_in[:, 1536:] = torch.polar(torch.ones_like(ang), ang)
+            d_out = torch.empty((B, ns), dtype=torch.complex64, device=dev)
+            h = stream.cuda_stream
+
+            def step():
+                if from_bits:
+                    md.chain_dev(d_in, B, stages, d_out, stream=h)
+                else:
+                    md.symbols_dev(d_in, B, stages, d_out, stream=h)
+
+            for _ in range(warmup):
+                step()
+            stream.synchronize()
+            barrier()
+            torch.cuda.synchronize()
+            e0 = torch.cuda.Event(enable_timing=True)
+            e1 = torch.cuda.Event(enable_timing=True)
+            t0 = time.perf_counter()
+            e0.record(stream)
+            for _ in range(steps):
+                step()
+            e1.record(stream)
+            torch.cuda.synchronize()
+            barrier()
+            wall = time.perf_counter() - t0
+            ev_ms = e0.elapsed_time(e1)
+        if world > 1:
+            tt = torch.tensor([wall], dtype=torch.float64, device=dev)
+            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+            wall = float(tt.item())
+        md.close()
+        del d_out, d_in, d_bits
+        torch.cuda.empty_cache()
+        return wall, ev_ms / steps
+
+    B = args.frames
+    wall, kern_ms = run_workload(args.workload, B, args.steps, args.warmup)
+    frames = world * B * args.steps
+    value = frames / wall
+    algo = ALGO_BYTES[args.workload]
+    achieved = algo * B / (kern_ms * 1e-3) / 1e9  # GB/s per GPU, per-launch HIP-event time
+
+    traffic = None
+    tp = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tp):
+        try:
+            t = json.load(open(tp)).get(args.workload)
+            if t and t.get("frames") == B:
+                traffic = t.get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    line = {
+        "metric": "Mode-I TX frames/sec (196608 IQ/frame)",
+        "value": round(value, 2),
+        "unit": "frames/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": round(wall / args.steps * 1e3, 4),
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": "f32",
+        "data": "synthetic",
+        "config": {"workload": {"cfg2": "Mode I OfdmGenerator+GuardIntervalInserter (BASELINE config 2)",
+                                "cfg3": "Mode I full chain from coded bits + GainControl(var) + "
+                                        "FIRFilter(45 default taps), native 2.048 Msps (BASELINE config 3)",
+                                "cfg4": "Mode I cfg3 + Resampler 2.048->8.192 Msps + MemlessPoly "
+                                        "(BASELINE config 4)"}[args.workload],
+                   "frames_per_step_per_gpu": B, "mode": 1, "parallelism": "%d independent streams" % world,
+                   "realtime_multiple": round(value / 10.4167, 1)},
+        "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
+                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                     "kernel": "tf_kernel" if args.workload != "cfg4" else "tf_kernel+resampler_kernel+poly_kernel",
+                     "algorithmic_bytes_per_frame": algo, "kernel_ms_per_launch": round(kern_ms, 4)},
+    }
+
+    if rank == 0 and world == 1:
+        if not args.no_extra:
+            extra = {}
+            for wl, b2 in (("cfg2", B), ("cfg4", max(64, B // 4))):
+                if wl == args.workload:
+                    continue
+                try:
+                    w2, k2 = run_workload(wl, b2, max(3, args.steps // 4), 1)
+                    extra[wl] = {"frames_per_s": round(b2 * max(3, args.steps // 4) / w2, 2),
+                                 "frames_per_step": b2,
+                                 "achieved_GBps": round(ALGO_BYTES[wl] * b2 / (k2 * 1e-3) / 1e9, 2)}
+                except Exception as ex:  # secondary numbers must never break the contract line
+                    extra[wl] = {"error": str(ex)[:200]}
+            line["other_workloads"] = extra
+        if not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(args.workload)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

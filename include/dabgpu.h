@@ -1,0 +1,181 @@
+/*
+ * dabgpu.h -- C-ABI of the MI355X-native DAB COFDM hot path (libdabgpu.so).
+ *
+ * This is the drop-in boundary: plain C, no exceptions, no C++/torch types.
+ * Every stage entry point replaces the `process()` of one ODR-DabMod flowgraph
+ * plugin (reference file:line cited at each declaration); the C++ adapters in
+ * odr-dabmod_amd/host/ keep the reference's ModPlugin class names and
+ * constructor signatures and call these functions (INTEGRATION.md shows the
+ * binding a maintainer adds to src/DabModulator.cpp).
+ *
+ * Conventions
+ *   - return 0 on success, <0 on error (DABGPU_E_*); dabgpu_last_error(ctx)
+ *     gives the message the adapter throws as std::runtime_error, mirroring
+ *     the reference's own size-check throws.
+ *   - samples are interleaved (re,im) float32 == std::complex<float>
+ *     (reference src/Buffer.h:40).
+ *   - `*_process` take HOST pointers (what a ModPlugin's Buffer holds) and
+ *     stage through pinned memory; `*_dev` take DEVICE pointers plus a HIP
+ *     stream handle (hipStream_t cast to void*, NULL = the context's stream)
+ *     and are asynchronous on that stream.
+ *   - out_cap is the capacity of the output buffer in bytes; *out_bytes
+ *     receives the produced length (the producer sizes its output, like
+ *     Buffer::setLength at the top of every reference process()).
+ *   - setters may be called from another thread (remote-control thread in the
+ *     reference); they take effect at the next *_process call.
+ *   - There is NO CPU fallback: every entry point fails with
+ *     DABGPU_E_DEVICE when no gfx950 device/kernel is available.
+ */
+#ifndef DABGPU_H
+#define DABGPU_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DABGPU_API __attribute__((visibility("default")))
+
+enum {
+    DABGPU_OK = 0,
+    DABGPU_E_INVALID = -1, /* bad argument / size check failed (reference throws std::runtime_error) */
+    DABGPU_E_DEVICE = -2,  /* HIP error, no device, kernel image missing */
+    DABGPU_E_NOMEM = -3,
+    DABGPU_E_CAPACITY = -4 /* out_cap too small / n_frames > max_frames */
+};
+
+/* GainMode, reference src/GainControl.h:45 */
+enum { DABGPU_GAIN_FIX = 0, DABGPU_GAIN_MAX = 1, DABGPU_GAIN_VAR = 2 };
+
+/* stage mask for the fused chain (order of src/DabModulator.cpp:385-419).
+ * QPSK map, frequency interleave, differential modulation, signal mux, OFDM
+ * IFFT and guard-interval insertion always run. */
+enum {
+    DABGPU_STAGE_GAIN = 1u << 0,     /* GainControl   */
+    DABGPU_STAGE_FIR = 1u << 1,      /* FIRFilter     */
+    DABGPU_STAGE_RESAMPLE = 1u << 2, /* Resampler     */
+    DABGPU_STAGE_POLY = 1u << 3,     /* MemlessPoly   */
+    DABGPU_STAGE_NOGUARD = 1u << 8   /* stop after OfdmGenerator(+GainControl): no guard interval */
+};
+
+typedef struct dabgpu_ctx dabgpu_ctx;
+
+typedef struct {
+    int mode;          /* transmission mode 1..4 (src/DabModulator.cpp:84-122) */
+    int device;        /* HIP device ordinal */
+    int max_frames;    /* largest n_frames of a *_process call (scratch sizing); 0 -> 1 */
+    int chunks_per_frame; /* workgroups per transmission frame for the fused kernel; 0 = auto */
+} dabgpu_config;
+
+DABGPU_API int dabgpu_create(const dabgpu_config *cfg, dabgpu_ctx **out);
+DABGPU_API void dabgpu_destroy(dabgpu_ctx *ctx);
+DABGPU_API const char *dabgpu_last_error(const dabgpu_ctx *ctx); /* ctx may be NULL: last create error */
+DABGPU_API const char *dabgpu_version(void);
+
+/* geometry of the configured mode (src/DabModulator.cpp:84-122) */
+typedef struct {
+    int mode, nb_symbols, carriers, spacing, null_size, sym_size;
+    size_t tf_input_bytes; /* hot-path input per transmission frame (BlockPartitioner output) */
+    size_t tf_samples;     /* complex samples per transmission frame at the native rate */
+} dabgpu_geometry;
+DABGPU_API int dabgpu_get_geometry(const dabgpu_ctx *ctx, dabgpu_geometry *g);
+
+/* ---- runtime parameters (remote-control setters of the reference) -------- */
+
+/* GainControl::set_parameter digital/mode/var, src/GainControl.cpp:505-554; normalise is the
+ * constructor argument derived from the sink, src/DabMod.cpp:259-347 */
+DABGPU_API int dabgpu_set_gain(dabgpu_ctx *ctx, int gain_mode, float digital, float normalise,
+                               float var_variance);
+/* FIRFilter::load_filter_taps, src/FIRFilter.cpp:95-141 (n <= 128) */
+DABGPU_API int dabgpu_set_fir_taps(dabgpu_ctx *ctx, const float *taps, size_t n);
+/* FIRFilter("default"): the built-in 45 taps, src/FIRFilter.cpp:59-71 */
+DABGPU_API int dabgpu_set_fir_default_taps(dabgpu_ctx *ctx);
+/* GuardIntervalInserter::update_window, src/GuardIntervalInserter.cpp:96-113 */
+DABGPU_API int dabgpu_set_window_overlap(dabgpu_ctx *ctx, size_t overlap);
+/* Resampler(inputRate, outputRate, resolution = spacing), src/Resampler.cpp:51-112;
+ * resets the stream state (prev-input halo and overlap tail) */
+DABGPU_API int dabgpu_set_resampler(dabgpu_ctx *ctx, size_t in_rate, size_t out_rate);
+/* MemlessPoly::load_coefficients format 1, src/MemlessPoly.cpp:154-202 */
+DABGPU_API int dabgpu_set_poly(dabgpu_ctx *ctx, const float am[5], const float pm[5]);
+/* MemlessPoly::load_coefficients format 2, src/MemlessPoly.cpp:203-226 */
+DABGPU_API int dabgpu_set_lut(dabgpu_ctx *ctx, float scalefactor, const float lut[32]);
+
+/* ---- per-stage entry points (HOST buffers; one per reference plugin) ----- */
+
+/* QpskSymbolMapper::process, src/QpskSymbolMapper.cpp:39-213 */
+DABGPU_API int dabgpu_qpsk_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
+                                   size_t out_cap, size_t *out_bytes);
+/* FrequencyInterleaver::process, src/FrequencyInterleaver.cpp:128-145 */
+DABGPU_API int dabgpu_freq_interleave_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes,
+                                              void *out, size_t out_cap, size_t *out_bytes);
+/* PhaseReference::process, src/PhaseReference.cpp:174-190 */
+DABGPU_API int dabgpu_phase_reference_process(dabgpu_ctx *ctx, void *out, size_t out_cap,
+                                              size_t *out_bytes);
+/* DifferentialModulator::process, src/DifferentialModulator.cpp:80-108 (in0 phase ref, in1 data) */
+DABGPU_API int dabgpu_diff_mod_process(dabgpu_ctx *ctx, const void *phase, size_t phase_bytes,
+                                       const void *data, size_t data_bytes, void *out,
+                                       size_t out_cap, size_t *out_bytes);
+/* NullSymbol::process src/NullSymbol.cpp:49-57 */
+DABGPU_API int dabgpu_null_symbol_process(dabgpu_ctx *ctx, void *out, size_t out_cap,
+                                          size_t *out_bytes);
+/* SignalMultiplexer::process, src/SignalMultiplexer.cpp:45-71: out = first ++ rest */
+DABGPU_API int dabgpu_signal_mux_process(dabgpu_ctx *ctx, const void *first, size_t first_bytes,
+                                         const void *rest, size_t rest_bytes, void *out,
+                                         size_t out_cap, size_t *out_bytes);
+/* OfdmGeneratorCF32::process, src/OfdmGenerator.cpp:157-308 (CFR off) */
+DABGPU_API int dabgpu_ofdm_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
+                                   size_t out_cap, size_t *out_bytes);
+/* GainControl::internal_process, src/GainControl.cpp:82-192 */
+DABGPU_API int dabgpu_gain_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
+                                   size_t out_cap, size_t *out_bytes);
+/* GuardIntervalInserter::process, src/GuardIntervalInserter.cpp:325-336 */
+DABGPU_API int dabgpu_guard_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
+                                    size_t out_cap, size_t *out_bytes);
+/* FIRFilter::internal_process, src/FIRFilter.cpp:144-309 (any length, one frame per call) */
+DABGPU_API int dabgpu_fir_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
+                                  size_t out_cap, size_t *out_bytes);
+/* Resampler::process, src/Resampler.cpp:131-195 (stateful across calls) */
+DABGPU_API int dabgpu_resampler_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes,
+                                        void *out, size_t out_cap, size_t *out_bytes);
+/* MemlessPoly::internal_process, src/MemlessPoly.cpp:342-411 */
+DABGPU_API int dabgpu_poly_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
+                                   size_t out_cap, size_t *out_bytes);
+
+/* ---- the fused chain ----------------------------------------------------- */
+
+/* bytes of IQ produced per transmission frame for a stage mask */
+DABGPU_API size_t dabgpu_chain_out_bytes_per_frame(const dabgpu_ctx *ctx, unsigned stage_mask);
+
+/* cifPart output (n_frames x tf_input_bytes) -> IQ.  Replaces the sub-graph
+ * cifMap .. cifGuard/cifFilter/cifRes/cifPoly of src/DabModulator.cpp:385-419
+ * with ONE plugin.  Frames are consecutive frames of one stream (the resampler
+ * state carries from frame to frame and from call to call). */
+DABGPU_API int dabgpu_chain_process(dabgpu_ctx *ctx, const uint8_t *bits, size_t n_frames,
+                                    unsigned stage_mask, void *iq_out, size_t out_cap,
+                                    size_t *out_bytes);
+/* same, device-resident input and output, asynchronous on `stream` */
+DABGPU_API int dabgpu_chain_process_dev(dabgpu_ctx *ctx, const void *d_bits, size_t n_frames,
+                                        unsigned stage_mask, void *d_iq, size_t out_cap,
+                                        size_t *out_bytes, void *stream);
+/* SignalMultiplexer output ((nb_symbols+1) x carriers cf32 per frame) -> IQ:
+ * the OfdmGenerator[+GainControl][+Guard][+FIR..] part of the chain. */
+DABGPU_API int dabgpu_symbols_process_dev(dabgpu_ctx *ctx, const void *d_carriers,
+                                          size_t n_frames, unsigned stage_mask, void *d_iq,
+                                          size_t out_cap, size_t *out_bytes, void *stream);
+
+/* wait for everything queued on the context's own stream */
+DABGPU_API int dabgpu_synchronize(dabgpu_ctx *ctx);
+
+/* timing aid for bench.py: average duration (ms) of the dominant kernel of the
+ * most recent *_dev call repeated `iters` times on the context's stream,
+ * bracketed by HIP events on that stream. */
+DABGPU_API int dabgpu_time_chain_dev(dabgpu_ctx *ctx, const void *d_bits, size_t n_frames,
+                                     unsigned stage_mask, void *d_iq, size_t out_cap, int iters,
+                                     float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

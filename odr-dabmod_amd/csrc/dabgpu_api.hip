@@ -1,0 +1,943 @@
+// dabgpu_api.hip -- the C-ABI of include/dabgpu.h: context, device tables,
+// host staging, and the mapping from reference plugins to kernel launches.
+
+#include "../../include/dabgpu.h"
+#include "dabgpu_internal.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+using namespace dabgpu;
+
+namespace {
+
+thread_local std::string g_create_error;
+
+// src/FIRFilter.cpp:59-71 == doc/fir-filter/filtertaps.txt (configuration data)
+const float kDefaultTaps[45] = {
+    -0.00110450468492f, 0.00120703084394f, -0.000840645749122f, -0.000187368263141f,
+    0.00184351124335f, -0.00355578539893f, 0.00419321097434f, -0.00254214904271f,
+    -0.00183473504148f, 0.00781436730176f, -0.0125957569107f, 0.0126200336963f,
+    -0.00537294941023f, -0.00866683479398f, 0.0249746385962f, -0.0356550291181f,
+    0.0319730602205f, -0.00795613788068f, -0.0363943465054f, 0.0938014090061f,
+    -0.151176810265f, 0.193567320704f, 0.791776955128f, 0.193567320704f,
+    -0.151176810265f, 0.0938014090061f, -0.0363943465054f, -0.00795613788068f,
+    0.0319730602205f, -0.0356550291181f, 0.0249746385962f, -0.00866683479398f,
+    -0.00537294941023f, 0.0126200336963f, -0.0125957569107f, 0.00781436730176f,
+    -0.00183473504148f, -0.00254214904271f, 0.00419321097434f, -0.00355578539893f,
+    0.00184351124335f, -0.000187368263141f, -0.000840645749122f, 0.00120703084394f,
+    -0.00110450468492f};
+
+// ETSI EN 300 401 table 43 (h_{i,j}) and tables 44-47 ((i, n) per 32-carrier
+// block, positive carriers first) -- the data of src/PhaseReference.cpp:35-124.
+const char *const kH[4] = {"0200001120002211", "0323013021232330", "0002021322022013",
+                           "0121033223212132"};
+const char *const kPrBlocks[4] = {
+    "033121110232211002322313003221130333231003302111"
+    "011220310312223302112233011223330212223101132132",
+    "201202312013021322320112",
+    "322212021320",
+    "003120120031221202312310001121320212203303112332",
+};
+
+struct DevBuf {
+    void *p = nullptr;
+    size_t cap = 0;
+    hipError_t reserve(size_t n)
+    {
+        if (n <= cap) return hipSuccess;
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+        hipError_t e = hipMalloc(&p, n);
+        if (e == hipSuccess) cap = n;
+        return e;
+    }
+    void release()
+    {
+        if (p) (void)hipFree(p);
+        p = nullptr;
+        cap = 0;
+    }
+};
+
+struct Settings {
+    int gain_mode = DABGPU_GAIN_VAR;      // src/ConfigParser.h:60-91 defaults
+    float digital = 1.0f, normalise = 1.0f, var_variance = 4.0f;
+    std::vector<float> taps;
+    size_t overlap = 0;
+    size_t rs_in = 2048000, rs_out = 2048000;
+    bool poly_is_lut = false;
+    float am[5] = {1, 0, 0, 0, 0}, pm[5] = {0, 0, 0, 0, 0};
+    float lut_scale = 0.f, lut[32] = {0};
+    unsigned long long epoch = 1;  // bumped by every setter
+    bool resampler_reset = true;
+};
+
+}  // namespace
+
+struct dabgpu_ctx {
+    Geometry g{};
+    int device = 0;
+    int max_frames = 1;
+    int chunks_cfg = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+
+    // constant tables
+    DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_window, d_coef;
+    // resampler
+    DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo, d_rs_spec;
+    int rs_nin = 0, rs_nout = 0;
+    size_t rs_L = 1, rs_M = 1;
+    float rs_factor = 1.f;
+    // scratch
+    DevBuf d_a, d_b, d_c, d_in, d_out;
+
+    std::mutex mu;
+    Settings set;                    // guarded by mu
+    Settings cur;                    // snapshot used by the processing thread
+    unsigned long long applied_epoch = 0;
+
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+};
+
+namespace {
+
+int fail(dabgpu_ctx *c, int code, const std::string &msg)
+{
+    if (c) c->err = msg; else g_create_error = msg;
+    return code;
+}
+
+int hip_fail(dabgpu_ctx *c, hipError_t e, const char *what)
+{
+    return fail(c, e == hipErrorOutOfMemory ? DABGPU_E_NOMEM : DABGPU_E_DEVICE,
+                std::string(what) + ": " + hipGetErrorString(e));
+}
+
+#define HIPCHK(ctx, expr)                                                                      \
+    do {                                                                                       \
+        hipError_t e_ = (expr);                                                                \
+        if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr);                                 \
+    } while (0)
+
+bool mode_geometry(int mode, Geometry *g)
+{
+    // src/DabModulator.cpp:84-122
+    static const Geometry tab[4] = {
+        {1, 76, 1536, 2048, 11, 2656, 2552},
+        {2, 76, 384, 512, 9, 664, 638},
+        {3, 153, 192, 256, 8, 345, 319},
+        {4, 76, 768, 1024, 10, 1328, 1276},
+    };
+    if (mode == 0) mode = 4;
+    if (mode < 1 || mode > 4) return false;
+    *g = tab[mode - 1];
+    return true;
+}
+
+size_t tf_in_bytes(const Geometry &g) { return (size_t)(g.nb_symbols - 1) * (size_t)(g.K / 4); }
+size_t tf_samples(const Geometry &g)
+{
+    return (size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size;
+}
+
+template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v, hipStream_t s)
+{
+    hipError_t e = b.reserve(std::max<size_t>(v.size() * sizeof(T), 16));
+    if (e != hipSuccess) return e;
+    e = hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
+    if (e != hipSuccess) return e;
+    return hipStreamSynchronize(s);  // v may be a temporary
+}
+
+int build_tables(dabgpu_ctx *c)
+{
+    const Geometry &g = c->g;
+    const int N = g.N, K = g.K;
+    std::vector<float2> tw(N);
+    for (int m = 0; m < N; ++m) {
+        const double a = 2.0 * M_PI * (double)m / (double)N;
+        tw[m] = make_float2((float)std::cos(a), (float)std::sin(a));
+    }
+    // frequency interleaver permutation, src/FrequencyInterleaver.cpp:73-92
+    std::vector<uint16_t> dst(K), src(K);
+    {
+        const unsigned lo = (unsigned)(N - K) / 2, hi = (unsigned)N - lo, beta = (unsigned)N / 4 - 1;
+        unsigned p = 0, n = 0;
+        for (unsigned j = 1; j < (unsigned)N; ++j) {
+            p = (13u * p + beta) & (unsigned)(N - 1);
+            if (p >= lo && p <= hi && p != (unsigned)N / 2) {
+                if (n >= (unsigned)K) return fail(c, DABGPU_E_INVALID, "interleaver table overflow");
+                dst[n++] = (uint16_t)(p > (unsigned)N / 2 ? p - ((unsigned)N / 2 + 1)
+                                                          : p + (unsigned)(K - N / 2));
+            }
+        }
+        if (n != (unsigned)K) return fail(c, DABGPU_E_INVALID, "interleaver table short");
+        for (int i = 0; i < K; ++i) src[dst[i]] = (uint16_t)i;
+    }
+    // phase reference quarter-turn index, src/PhaseReference.cpp:152-171
+    std::vector<uint8_t> phq(K);
+    {
+        const char *blk = kPrBlocks[g.mode - 1];
+        for (int o = 0; o < K / 32; ++o) {
+            const int i = blk[2 * o] - '0', n = blk[2 * o + 1] - '0';
+            for (int k = 0; k < 32; ++k) phq[32 * o + k] = (uint8_t)(((kH[i][k & 15] - '0') + n) & 3);
+        }
+    }
+    // |y_s| of the fp32 differential recurrence y_{s+1} = y_s * x_s with
+    // x = (+-c +-jc), c = (float)sqrt(1/2) (src/DifferentialModulator.cpp:65-76):
+    // an axis state (m, 0) goes to (fl(m c), fl(m c)), a diagonal state (a, a) to
+    // (fl(a c) + fl(a c), 0) -- independent of the data, so it is a table.
+    std::vector<float> mag(g.nb_symbols);
+    {
+        const volatile float c45 = (float)0.70710678118654752440;
+        volatile float m = 1.0f;
+        mag[0] = 1.0f;
+        for (int s = 1; s < g.nb_symbols; ++s) {
+            volatile float p = m * c45;
+            m = (s & 1) ? p : (float)(p + p);
+            mag[s] = m;
+        }
+    }
+    hipStream_t s = c->stream;
+    HIPCHK(c, upload(c->d_twiddle, tw, s));
+    HIPCHK(c, upload(c->d_src, src, s));
+    HIPCHK(c, upload(c->d_dst, dst, s));
+    HIPCHK(c, upload(c->d_phq, phq, s));
+    HIPCHK(c, upload(c->d_mag, mag, s));
+    return DABGPU_OK;
+}
+
+// take the settings snapshot and (re)upload what changed
+int apply_settings(dabgpu_ctx *c)
+{
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        if (c->set.epoch == c->applied_epoch) return DABGPU_OK;
+        c->cur = c->set;
+        c->set.resampler_reset = false;
+        c->applied_epoch = c->set.epoch;
+    }
+    hipStream_t s = c->stream;
+    std::vector<float> taps(kMaxTaps, 0.0f);
+    std::copy(c->cur.taps.begin(), c->cur.taps.end(), taps.begin());
+    HIPCHK(c, upload(c->d_taps, taps, s));
+    if (c->cur.overlap) {
+        // src/GuardIntervalInserter.cpp:106-111
+        const size_t W = c->cur.overlap;
+        std::vector<float> w(2 * W);
+        for (size_t i = 0; i < 2 * W; ++i)
+            w[i] = (float)(0.5 * (1.0 - std::cos(M_PI * (double)i / (double)(2 * W - 1))));
+        HIPCHK(c, upload(c->d_window, w, s));
+    }
+    std::vector<float> coef(48, 0.f);
+    std::copy(c->cur.am, c->cur.am + 5, coef.begin());
+    std::copy(c->cur.pm, c->cur.pm + 5, coef.begin() + 8);
+    std::copy(c->cur.lut, c->cur.lut + 32, coef.begin() + 16);
+    HIPCHK(c, upload(c->d_coef, coef, s));
+
+    // resampler geometry, src/Resampler.cpp:65-112
+    {
+        size_t a = c->cur.rs_in, b = c->cur.rs_out;
+        while (b) { size_t t = a % b; a = b; b = t; }
+        const size_t L = c->cur.rs_out / a, M = c->cur.rs_in / a;
+        size_t f = (size_t)c->g.N * 2 / M;
+        if (f & 1) ++f;
+        const size_t nin = f * M, nout = f * L;
+        c->rs_L = L; c->rs_M = M;
+        const bool changed = (int)nin != c->rs_nin || (int)nout != c->rs_nout;
+        c->rs_nin = (int)nin; c->rs_nout = (int)nout;
+        const size_t big = std::max(nin, nout);
+        c->rs_factor = 1.0f / (float)big * (float)c->cur.rs_out / (float)c->cur.rs_in;
+        if (c->cur.rs_in != c->cur.rs_out && (changed || c->cur.resampler_reset)) {
+            std::vector<float> w(nin);
+            for (size_t i = 0; i < nin; ++i)
+                w[i] = (float)(0.5 * (1.0 - std::cos(2.0 * M_PI * (double)i / (double)(nin - 1))));
+            HIPCHK(c, upload(c->d_rs_window, w, s));
+            std::vector<float2> ti(nin), to(nout);
+            for (size_t m = 0; m < nin; ++m) {
+                const double x = 2.0 * M_PI * (double)m / (double)nin;
+                ti[m] = make_float2((float)std::cos(x), (float)std::sin(x));
+            }
+            for (size_t m = 0; m < nout; ++m) {
+                const double x = 2.0 * M_PI * (double)m / (double)nout;
+                to[m] = make_float2((float)std::cos(x), (float)std::sin(x));
+            }
+            HIPCHK(c, upload(c->d_rs_tw_in, ti, s));
+            HIPCHK(c, upload(c->d_rs_tw_out, to, s));
+            HIPCHK(c, c->d_rs_halo.reserve(nin * sizeof(float2)));
+            HIPCHK(c, hipMemsetAsync(c->d_rs_halo.p, 0, nin * sizeof(float2), s));
+        }
+    }
+    return DABGPU_OK;
+}
+
+Tables tables_of(dabgpu_ctx *c)
+{
+    Tables t;
+    t.twiddle = (const float2 *)c->d_twiddle.p;
+    t.src_carrier = (const uint16_t *)c->d_src.p;
+    t.dst_pos = (const uint16_t *)c->d_dst.p;
+    t.phase_q = (const uint8_t *)c->d_phq.p;
+    t.mag = (const float *)c->d_mag.p;
+    t.taps = (const float *)c->d_taps.p;
+    t.window = (const float *)c->d_window.p;
+    return t;
+}
+
+GainParams gain_of(const dabgpu_ctx *c)
+{
+    GainParams gp;
+    gp.mode = c->cur.gain_mode;
+    gp.constant = c->cur.normalise * c->cur.digital;  // src/GainControl.cpp:118
+    gp.var_variance = c->cur.var_variance;
+    return gp;
+}
+
+int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
+{
+    if (c->chunks_cfg > 0) return c->chunks_cfg;
+    // one workgroup per frame once the batch alone fills the chip (256 CUs x 4
+    // workgroups); below that split frames into runs of symbols.
+    const int nsym = c->g.nb_symbols + 1;
+    if (n_frames >= 1024) return 1;
+    int want = (int)((1024 + n_frames - 1) / n_frames);
+    want = std::min(want, (nsym + 6) / 7);  // at least 7 symbols per workgroup
+    return std::max(1, want);
+}
+
+bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
+
+int check_resampler(dabgpu_ctx *c)
+{
+    if (!is_pow2((size_t)c->rs_nin) || !is_pow2((size_t)c->rs_nout) || c->rs_nin < 512 ||
+        c->rs_nout < 512 || c->rs_nin > 16384 || c->rs_nout > 16384)
+        return fail(c, DABGPU_E_INVALID,
+                    "Resampler: only power-of-two rate ratios (FFT sizes 512..16384) are supported");
+    return DABGPU_OK;
+}
+
+// stream of `total` samples at d_in -> resampled at d_out (stateful)
+int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out, hipStream_t s)
+{
+    int rc = check_resampler(c);
+    if (rc) return rc;
+    const size_t hin = (size_t)c->rs_nin / 2;
+    if (total % hin) return fail(c, DABGPU_E_INVALID, "Resampler::process input size not valid!");
+    const size_t nhops = total / hin;
+    ResamplerArgs a;
+    a.nin = c->rs_nin; a.nout = c->rs_nout; a.factor = c->rs_factor;
+    a.window = (const float *)c->d_rs_window.p;
+    a.tw_in = (const float2 *)c->d_rs_tw_in.p;
+    a.tw_out = (const float2 *)c->d_rs_tw_out.p;
+    a.in = d_in; a.halo = (const float2 *)c->d_rs_halo.p;
+    a.out = d_out; a.nhops = nhops;
+    HIPCHK(c, launch_resampler(a, s));
+    // new halo = last two hops of the concatenation [halo | in]
+    float2 *halo = (float2 *)c->d_rs_halo.p;
+    if (nhops >= 2) {
+        HIPCHK(c, hipMemcpyAsync(halo, d_in + (nhops - 2) * hin, 2 * hin * sizeof(float2),
+                                 hipMemcpyDeviceToDevice, s));
+    } else {
+        HIPCHK(c, hipMemcpyAsync(halo, halo + hin, hin * sizeof(float2), hipMemcpyDeviceToDevice, s));
+        HIPCHK(c, hipMemcpyAsync(halo + hin, d_in, hin * sizeof(float2), hipMemcpyDeviceToDevice, s));
+    }
+    return DABGPU_OK;
+}
+
+int run_poly(dabgpu_ctx *c, const float2 *d_in, size_t n, float2 *d_out, hipStream_t s)
+{
+    const float *coef = (const float *)c->d_coef.p;
+    if (c->cur.poly_is_lut)
+        HIPCHK(c, launch_lut(d_in, n, c->cur.lut_scale, coef + 16, d_out, s));
+    else
+        HIPCHK(c, launch_poly(d_in, n, coef, coef + 8, d_out, s));
+    return DABGPU_OK;
+}
+
+size_t out_samples_per_frame(const dabgpu_ctx *c, unsigned mask, size_t L, size_t M)
+{
+    size_t n = (mask & DABGPU_STAGE_NOGUARD) ? (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.N
+                                             : tf_samples(c->g);
+    if (mask & DABGPU_STAGE_RESAMPLE) n = n * L / M;
+    return n;
+}
+
+// The chain on device pointers.  from_bits: d_in is coded bits, else carriers.
+int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask,
+              float2 *d_out, size_t out_cap, size_t *out_bytes, hipStream_t s)
+{
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    if ((mask & DABGPU_STAGE_NOGUARD) && (mask & (DABGPU_STAGE_FIR | DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY)))
+        return fail(c, DABGPU_E_INVALID, "NOGUARD cannot be combined with FIR/RESAMPLE/POLY");
+    if ((mask & DABGPU_STAGE_FIR) && c->cur.taps.empty())
+        return fail(c, DABGPU_E_INVALID, "FIRFilter: no taps loaded");
+    if ((mask & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) mask &= ~DABGPU_STAGE_RESAMPLE;
+    const size_t per = out_samples_per_frame(c, mask, c->rs_L, c->rs_M);
+    const size_t need = n_frames * per * sizeof(float2);
+    if (out_bytes) *out_bytes = need;
+    if (need > out_cap) return fail(c, DABGPU_E_CAPACITY, "output buffer too small");
+    if (n_frames == 0) return DABGPU_OK;
+
+    const size_t native = (mask & DABGPU_STAGE_NOGUARD) ? per : tf_samples(c->g);
+    const bool post = mask & (DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY);
+    const bool windowed = c->cur.overlap > 0 && !(mask & DABGPU_STAGE_NOGUARD);
+    if (windowed) {
+        const size_t W = c->cur.overlap;
+        if (W > (size_t)(c->g.sym_size - c->g.N))
+            return fail(c, DABGPU_E_INVALID, "window overlap larger than the guard interval");
+    }
+
+    // where the native-rate stream goes
+    float2 *native_out = d_out;
+    if (post) {
+        HIPCHK(c, c->d_a.reserve(n_frames * native * sizeof(float2)));
+        native_out = (float2 *)c->d_a.p;
+    }
+
+    TfArgs a;
+    a.g = c->g;
+    a.t = tables_of(c);
+    a.gain = gain_of(c);
+    a.ntaps = (int)c->cur.taps.size();
+    a.n_frames = (int)n_frames;
+    a.bits = from_bits ? (const uint8_t *)d_in : nullptr;
+    a.carriers = from_bits ? nullptr : (const float2 *)d_in;
+    unsigned flags = from_bits ? TF_FROM_BITS : 0;
+    if (mask & DABGPU_STAGE_GAIN) flags |= TF_GAIN;
+
+    if (!windowed) {
+        if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
+        if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
+        a.chunks_per_frame = auto_chunks(c, n_frames);
+        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.out = native_out;
+        a.out_stride = native;
+        HIPCHK(c, launch_tf(a, flags, s));
+    } else {
+        // OFDM windowing: IFFT(+gain) -> windowed guard -> FIR as separate kernels
+        const size_t nsymN = (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.N;
+        HIPCHK(c, c->d_b.reserve(n_frames * nsymN * sizeof(float2)));
+        a.chunks_per_frame = auto_chunks(c, n_frames);
+        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.out = (float2 *)c->d_b.p;
+        a.out_stride = nsymN;
+        HIPCHK(c, launch_tf(a, flags, s));
+        float2 *gout = native_out;
+        if (mask & DABGPU_STAGE_FIR) {
+            HIPCHK(c, c->d_c.reserve(n_frames * native * sizeof(float2)));
+            gout = (float2 *)c->d_c.p;
+        }
+        HIPCHK(c, launch_guard_window((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
+                                      (const float *)c->d_window.p, gout, s));
+        if (mask & DABGPU_STAGE_FIR)
+            HIPCHK(c, launch_fir(gout, native, n_frames, (const float *)c->d_taps.p,
+                                 (int)c->cur.taps.size(), native_out, s));
+    }
+
+    if (post) {
+        const float2 *cur = native_out;
+        size_t n = n_frames * native;
+        if (mask & DABGPU_STAGE_RESAMPLE) {
+            float2 *dst = d_out;
+            if (mask & DABGPU_STAGE_POLY) {
+                HIPCHK(c, c->d_b.reserve(n_frames * per * sizeof(float2)));
+                dst = (float2 *)c->d_b.p;
+            }
+            rc = run_resampler(c, cur, n, dst, s);
+            if (rc) return rc;
+            cur = dst;
+            n = n_frames * per;
+        }
+        if (mask & DABGPU_STAGE_POLY) {
+            rc = run_poly(c, cur, n, d_out, s);
+            if (rc) return rc;
+        }
+    }
+    return DABGPU_OK;
+}
+
+// host-pointer stage wrapper: H2D, launch, D2H on the context stream
+struct HostIO {
+    dabgpu_ctx *c;
+    explicit HostIO(dabgpu_ctx *ctx) : c(ctx) {}
+    int in(DevBuf &b, const void *h, size_t n)
+    {
+        HIPCHK(c, b.reserve(std::max<size_t>(n, 16)));
+        if (n) HIPCHK(c, hipMemcpyAsync(b.p, h, n, hipMemcpyHostToDevice, c->stream));
+        return DABGPU_OK;
+    }
+    int out(void *h, const void *d, size_t n)
+    {
+        if (n) HIPCHK(c, hipMemcpyAsync(h, d, n, hipMemcpyDeviceToHost, c->stream));
+        HIPCHK(c, hipStreamSynchronize(c->stream));
+        return DABGPU_OK;
+    }
+};
+
+int check_out(dabgpu_ctx *c, size_t need, size_t cap, size_t *out_bytes)
+{
+    if (out_bytes) *out_bytes = need;
+    if (need > cap) return fail(c, DABGPU_E_CAPACITY, "output buffer too small");
+    return DABGPU_OK;
+}
+
+#define CTXCHK(c)                                                                              \
+    do {                                                                                       \
+        if (!(c)) return DABGPU_E_INVALID;                                                     \
+        hipError_t e_ = hipSetDevice((c)->device);                                             \
+        if (e_ != hipSuccess) return hip_fail((c), e_, "hipSetDevice");                        \
+    } while (0)
+
+}  // namespace
+
+// ===========================================================================
+extern "C" {
+
+const char *dabgpu_version(void) { return "dabgpu 0.1 (gfx950)"; }
+
+const char *dabgpu_last_error(const dabgpu_ctx *ctx)
+{
+    return ctx ? ctx->err.c_str() : g_create_error.c_str();
+}
+
+int dabgpu_create(const dabgpu_config *cfg, dabgpu_ctx **out)
+{
+    if (!cfg || !out) return fail(nullptr, DABGPU_E_INVALID, "null argument");
+    *out = nullptr;
+    Geometry g;
+    if (!mode_geometry(cfg->mode, &g))
+        return fail(nullptr, DABGPU_E_INVALID, "invalid DAB transmission mode");
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev == 0)
+        return fail(nullptr, DABGPU_E_DEVICE,
+                    std::string("no HIP device available (there is no CPU fallback): ") +
+                        hipGetErrorString(e));
+    if (cfg->device < 0 || cfg->device >= ndev)
+        return fail(nullptr, DABGPU_E_INVALID, "device ordinal out of range");
+    e = hipSetDevice(cfg->device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipSetDevice");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, cfg->device);
+    if (e != hipSuccess) return hip_fail(nullptr, e, "hipGetDeviceProperties");
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        return fail(nullptr, DABGPU_E_DEVICE,
+                    std::string("device is ") + prop.gcnArchName + ", kernels are built for gfx950 only");
+
+    dabgpu_ctx *c = new dabgpu_ctx();
+    c->g = g;
+    c->device = cfg->device;
+    c->max_frames = std::max(1, cfg->max_frames);
+    c->chunks_cfg = cfg->chunks_per_frame;
+    auto bail = [&](int rc) {
+        g_create_error = c->err;
+        dabgpu_destroy(c);
+        return rc;
+    };
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) return bail(hip_fail(c, e, "hipStreamCreate"));
+    (void)hipEventCreate(&c->ev0);
+    (void)hipEventCreate(&c->ev1);
+    // the fused kernel uses up to ~40 KiB of dynamic LDS; nothing to opt in on gfx950 (<= 64 KiB)
+    int rc = build_tables(c);
+    if (rc) return bail(rc);
+    c->set.taps.assign(kDefaultTaps, kDefaultTaps + 45);
+    rc = apply_settings(c);
+    if (rc) return bail(rc);
+    *out = c;
+    return DABGPU_OK;
+}
+
+void dabgpu_destroy(dabgpu_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps,
+                      &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
+                      &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out})
+        b->release();
+    if (c->ev0) (void)hipEventDestroy(c->ev0);
+    if (c->ev1) (void)hipEventDestroy(c->ev1);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int dabgpu_get_geometry(const dabgpu_ctx *c, dabgpu_geometry *g)
+{
+    if (!c || !g) return DABGPU_E_INVALID;
+    g->mode = c->g.mode; g->nb_symbols = c->g.nb_symbols; g->carriers = c->g.K;
+    g->spacing = c->g.N; g->null_size = c->g.null_size; g->sym_size = c->g.sym_size;
+    g->tf_input_bytes = tf_in_bytes(c->g);
+    g->tf_samples = tf_samples(c->g);
+    return DABGPU_OK;
+}
+
+// ---- setters ---------------------------------------------------------------
+
+int dabgpu_set_gain(dabgpu_ctx *c, int gain_mode, float digital, float normalise, float var_variance)
+{
+    if (!c) return DABGPU_E_INVALID;
+    if (gain_mode < 0 || gain_mode > 2) return fail(c, DABGPU_E_INVALID, "invalid gainmode");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->set.gain_mode = gain_mode; c->set.digital = digital; c->set.normalise = normalise;
+    c->set.var_variance = var_variance;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_fir_taps(dabgpu_ctx *c, const float *taps, size_t n)
+{
+    if (!c) return DABGPU_E_INVALID;
+    if (!taps || n == 0) return fail(c, DABGPU_E_INVALID, "FIRFilter: taps file has invalid format.");
+    if (n > (size_t)kMaxTaps) return fail(c, DABGPU_E_INVALID, "FIRFilter: more than 128 taps not supported");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->set.taps.assign(taps, taps + n);
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_fir_default_taps(dabgpu_ctx *c) { return dabgpu_set_fir_taps(c, kDefaultTaps, 45); }
+
+int dabgpu_set_window_overlap(dabgpu_ctx *c, size_t overlap)
+{
+    if (!c) return DABGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->set.overlap = overlap;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_resampler(dabgpu_ctx *c, size_t in_rate, size_t out_rate)
+{
+    if (!c) return DABGPU_E_INVALID;
+    if (!in_rate || !out_rate) return fail(c, DABGPU_E_INVALID, "Resampler: invalid rate");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->set.rs_in = in_rate; c->set.rs_out = out_rate; c->set.resampler_reset = true;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_poly(dabgpu_ctx *c, const float am[5], const float pm[5])
+{
+    if (!c || !am || !pm) return DABGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    std::copy(am, am + 5, c->set.am);
+    std::copy(pm, pm + 5, c->set.pm);
+    c->set.poly_is_lut = false;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_lut(dabgpu_ctx *c, float scalefactor, const float lut[32])
+{
+    if (!c || !lut) return DABGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->set.lut_scale = scalefactor;
+    std::copy(lut, lut + 32, c->set.lut);
+    c->set.poly_is_lut = true;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+// ---- per-stage, host buffers ------------------------------------------------
+
+int dabgpu_qpsk_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                        size_t *out_bytes)
+{
+    CTXCHK(c);
+    if (in_bytes % (size_t)(c->g.K / 4) != 0)
+        return fail(c, DABGPU_E_INVALID, "QpskSymbolMapper::process input size not valid!");
+    const size_t need = in_bytes * 4 * sizeof(float2);
+    int rc = check_out(c, need, out_cap, out_bytes);
+    if (rc) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(need, 16)));
+    HIPCHK(c, launch_qpsk((const uint8_t *)c->d_a.p, in_bytes, c->g.K, (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_freq_interleave_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out,
+                                   size_t out_cap, size_t *out_bytes)
+{
+    CTXCHK(c);
+    const size_t ns = in_bytes / sizeof(float2);
+    if (in_bytes % sizeof(float2) || ns % (size_t)c->g.K != 0)
+        return fail(c, DABGPU_E_INVALID, "FrequencyInterleaver::process input size not valid!");
+    int rc = check_out(c, in_bytes, out_cap, out_bytes);
+    if (rc) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(in_bytes, 16)));
+    HIPCHK(c, launch_freq_interleave((const float2 *)c->d_a.p, ns, c->g.K,
+                                     (const uint16_t *)c->d_src.p, (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, in_bytes);
+}
+
+int dabgpu_phase_reference_process(dabgpu_ctx *c, void *out, size_t out_cap, size_t *out_bytes)
+{
+    CTXCHK(c);
+    const size_t need = (size_t)c->g.K * sizeof(float2);
+    int rc = check_out(c, need, out_cap, out_bytes);
+    if (rc) return rc;
+    HostIO io(c);
+    HIPCHK(c, c->d_b.reserve(need));
+    HIPCHK(c, launch_phase_reference((const uint8_t *)c->d_phq.p, c->g.K, (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_diff_mod_process(dabgpu_ctx *c, const void *phase, size_t phase_bytes, const void *data,
+                            size_t data_bytes, void *out, size_t out_cap, size_t *out_bytes)
+{
+    CTXCHK(c);
+    const size_t K = (size_t)c->g.K;
+    if (phase_bytes != K * sizeof(float2))
+        return fail(c, DABGPU_E_INVALID, "DifferentialModulator::process input phase size not valid!");
+    if (data_bytes % (K * sizeof(float2)) != 0)
+        return fail(c, DABGPU_E_INVALID, "DifferentialModulator::process input data size not valid!");
+    const size_t need = phase_bytes + data_bytes;
+    int rc = check_out(c, need, out_cap, out_bytes);
+    if (rc) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, phase, phase_bytes))) return rc;
+    if ((rc = io.in(c->d_c, data, data_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(need));
+    HIPCHK(c, launch_diff_mod((const float2 *)c->d_a.p, (const float2 *)c->d_c.p,
+                              data_bytes / (K * sizeof(float2)), c->g.K, (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_null_symbol_process(dabgpu_ctx *c, void *out, size_t out_cap, size_t *out_bytes)
+{
+    CTXCHK(c);
+    const size_t need = (size_t)c->g.K * sizeof(float2);
+    int rc = check_out(c, need, out_cap, out_bytes);
+    if (rc) return rc;
+    HostIO io(c);
+    HIPCHK(c, c->d_b.reserve(need));
+    HIPCHK(c, hipMemsetAsync(c->d_b.p, 0, need, c->stream));
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_signal_mux_process(dabgpu_ctx *c, const void *first, size_t first_bytes, const void *rest,
+                              size_t rest_bytes, void *out, size_t out_cap, size_t *out_bytes)
+{
+    CTXCHK(c);
+    const size_t need = first_bytes + rest_bytes;
+    int rc = check_out(c, need, out_cap, out_bytes);
+    if (rc) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(need, 16)));
+    if (first_bytes) HIPCHK(c, hipMemcpyAsync(c->d_b.p, first, first_bytes, hipMemcpyHostToDevice, c->stream));
+    if (rest_bytes)
+        HIPCHK(c, hipMemcpyAsync((char *)c->d_b.p + first_bytes, rest, rest_bytes, hipMemcpyHostToDevice, c->stream));
+    HostIO io(c);
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_ofdm_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                        size_t *out_bytes)
+{
+    CTXCHK(c);
+    const size_t per_in = (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.K * sizeof(float2);
+    if (in_bytes != per_in)
+        return fail(c, DABGPU_E_INVALID, "OfdmGenerator::process input size not valid!");
+    HostIO io(c);
+    int rc = io.in(c->d_c, in, in_bytes);
+    if (rc) return rc;
+    const size_t need = (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.N * sizeof(float2);
+    if ((rc = check_out(c, need, out_cap, out_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(need));
+    size_t ob = 0;
+    rc = run_chain(c, c->d_c.p, false, 1, DABGPU_STAGE_NOGUARD, (float2 *)c->d_b.p, need, &ob, c->stream);
+    if (rc) return rc;
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_gain_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                        size_t *out_bytes)
+{
+    CTXCHK(c);
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    const size_t ns = in_bytes / sizeof(float2);
+    if (in_bytes % sizeof(float2) || ns % (size_t)c->g.N != 0)
+        return fail(c, DABGPU_E_INVALID, "GainControl::process input size not valid!");
+    if ((rc = check_out(c, in_bytes, out_cap, out_bytes))) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(in_bytes, 16)));
+    HIPCHK(c, launch_gain((const float2 *)c->d_a.p, ns / (size_t)c->g.N, c->g.N, gain_of(c),
+                          (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, in_bytes);
+}
+
+int dabgpu_guard_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                         size_t *out_bytes)
+{
+    CTXCHK(c);
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    const size_t per_in = (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.N * sizeof(float2);
+    if (in_bytes != per_in)
+        return fail(c, DABGPU_E_INVALID, "GuardIntervalInserter::process input size not valid!");
+    const size_t need = tf_samples(c->g) * sizeof(float2);
+    if ((rc = check_out(c, need, out_cap, out_bytes))) return rc;
+    if (c->cur.overlap > (size_t)(c->g.sym_size - c->g.N))
+        return fail(c, DABGPU_E_INVALID, "window overlap larger than the guard interval");
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(need));
+    if (c->cur.overlap == 0)
+        HIPCHK(c, launch_guard_copy((const float2 *)c->d_a.p, 1, c->g, (float2 *)c->d_b.p, c->stream));
+    else
+        HIPCHK(c, launch_guard_window((const float2 *)c->d_a.p, 1, c->g, (int)c->cur.overlap,
+                                      (const float *)c->d_window.p, (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_fir_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                       size_t *out_bytes)
+{
+    CTXCHK(c);
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    if (in_bytes % sizeof(float2)) return fail(c, DABGPU_E_INVALID, "FIRFilter: input size not valid");
+    if ((rc = check_out(c, in_bytes, out_cap, out_bytes))) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(in_bytes, 16)));
+    HIPCHK(c, launch_fir((const float2 *)c->d_a.p, in_bytes / sizeof(float2), 1,
+                         (const float *)c->d_taps.p, (int)c->cur.taps.size(), (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, in_bytes);
+}
+
+int dabgpu_resampler_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                             size_t *out_bytes)
+{
+    CTXCHK(c);
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    if (in_bytes % sizeof(float2)) return fail(c, DABGPU_E_INVALID, "Resampler: input size not valid");
+    const size_t ns = in_bytes / sizeof(float2);
+    const size_t need = ns * c->rs_L / c->rs_M * sizeof(float2);
+    if ((rc = check_out(c, need, out_cap, out_bytes))) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(need, 16)));
+    if (c->cur.rs_in == c->cur.rs_out) {
+        HIPCHK(c, hipMemcpyAsync(c->d_b.p, c->d_a.p, in_bytes, hipMemcpyDeviceToDevice, c->stream));
+    } else {
+        if ((rc = run_resampler(c, (const float2 *)c->d_a.p, ns, (float2 *)c->d_b.p, c->stream))) return rc;
+    }
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_poly_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                        size_t *out_bytes)
+{
+    CTXCHK(c);
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    if (in_bytes % (2 * sizeof(float2)))
+        return fail(c, DABGPU_E_INVALID, "MemlessPoly: input size not valid");
+    if ((rc = check_out(c, in_bytes, out_cap, out_bytes))) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(in_bytes, 16)));
+    if ((rc = run_poly(c, (const float2 *)c->d_a.p, in_bytes / sizeof(float2), (float2 *)c->d_b.p, c->stream)))
+        return rc;
+    return io.out(out, c->d_b.p, in_bytes);
+}
+
+// ---- chain -------------------------------------------------------------------
+
+size_t dabgpu_chain_out_bytes_per_frame(const dabgpu_ctx *c, unsigned mask)
+{
+    if (!c) return 0;
+    size_t L = 1, M = 1;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<dabgpu_ctx *>(c)->mu);
+        size_t a = c->set.rs_in, b = c->set.rs_out;
+        while (b) { size_t t = a % b; a = b; b = t; }
+        L = c->set.rs_out / a; M = c->set.rs_in / a;
+    }
+    return out_samples_per_frame(c, mask, L, M) * sizeof(float2);
+}
+
+int dabgpu_chain_process_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames, unsigned mask,
+                             void *d_iq, size_t out_cap, size_t *out_bytes, void *stream)
+{
+    CTXCHK(c);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
+}
+
+int dabgpu_symbols_process_dev(dabgpu_ctx *c, const void *d_car, size_t n_frames, unsigned mask,
+                               void *d_iq, size_t out_cap, size_t *out_bytes, void *stream)
+{
+    CTXCHK(c);
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    return run_chain(c, d_car, false, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
+}
+
+int dabgpu_chain_process(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, unsigned mask,
+                         void *iq_out, size_t out_cap, size_t *out_bytes)
+{
+    CTXCHK(c);
+    if (n_frames > (size_t)c->max_frames)
+        return fail(c, DABGPU_E_CAPACITY, "n_frames exceeds max_frames of the context");
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    unsigned m2 = mask;
+    if ((m2 & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) m2 &= ~DABGPU_STAGE_RESAMPLE;
+    const size_t need = n_frames * out_samples_per_frame(c, m2, c->rs_L, c->rs_M) * sizeof(float2);
+    if ((rc = check_out(c, need, out_cap, out_bytes))) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_in, bits, n_frames * tf_in_bytes(c->g)))) return rc;
+    // final output lives in its own buffer: d_a / d_b / d_c are the chain's scratch
+    HIPCHK(c, c->d_out.reserve(std::max<size_t>(need, 16)));
+    size_t ob = 0;
+    rc = run_chain(c, c->d_in.p, true, n_frames, mask, (float2 *)c->d_out.p, need, &ob, c->stream);
+    if (rc) return rc;
+    return io.out(iq_out, c->d_out.p, need);
+}
+
+int dabgpu_synchronize(dabgpu_ctx *c)
+{
+    CTXCHK(c);
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    return DABGPU_OK;
+}
+
+int dabgpu_time_chain_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames, unsigned mask,
+                          void *d_iq, size_t out_cap, int iters, float *avg_ms)
+{
+    CTXCHK(c);
+    if (iters < 1 || !avg_ms) return fail(c, DABGPU_E_INVALID, "iters < 1");
+    size_t ob = 0;
+    int rc = run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, &ob, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
+    for (int i = 0; i < iters; ++i) {
+        rc = run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, &ob, c->stream);
+        if (rc) return rc;
+    }
+    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
+    HIPCHK(c, hipEventSynchronize(c->ev1));
+    float ms = 0.f;
+    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
+    *avg_ms = ms / (float)iters;
+    return DABGPU_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,94 @@
+// dabgpu_internal.h -- shared between the kernel file and the C-ABI file.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stddef.h>
+#include <stdint.h>
+
+namespace dabgpu {
+
+constexpr int kMaxTaps = 128;
+
+// Transmission-mode geometry (reference src/DabModulator.cpp:84-122).
+struct Geometry {
+    int mode;
+    int nb_symbols;  // 76 / 153 (phase reference + data symbols)
+    int K;           // carriers
+    int N;           // FFT size ("spacing")
+    int logN;
+    int null_size;
+    int sym_size;
+};
+
+// Device-resident constant tables, built once per context.
+struct Tables {
+    const float2 *twiddle;        // N entries, exp(+2 pi i m / N)
+    const uint16_t *src_carrier;  // K: interleaved position k -> carrier index n before interleaving
+    const uint16_t *dst_pos;      // K: carrier n -> interleaved position (reference's m_indices)
+    const uint8_t *phase_q;       // K: quarter-turn index (0..3) of the phase reference at position k
+    const float *mag;             // nb_symbols: |y| after s differential multiplications (fp32 recurrence)
+    const float *taps;            // kMaxTaps floats, zero padded
+    const float *window;          // 2*overlap floats (guard-interval raised cosine)
+};
+
+struct GainParams {
+    int mode;            // 0 fix, 1 max, 2 var
+    float constant;      // normalise * digital  (reference src/GainControl.cpp:118)
+    float var_variance;
+};
+
+// Arguments of the fused per-transmission-frame kernel.
+struct TfArgs {
+    Geometry g;
+    Tables t;
+    GainParams gain;
+    int ntaps;
+    int n_frames;
+    int chunks_per_frame;
+    int syms_per_chunk;
+    const uint8_t *bits;      // FROM_BITS: n_frames * (nb_symbols-1)*K/4 bytes
+    const float2 *carriers;   // else: n_frames * (nb_symbols+1)*K samples
+    float2 *out;
+    size_t out_stride;        // samples per frame in `out`
+};
+
+enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8 };
+
+hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
+size_t tf_lds_bytes(int logN, unsigned flags);
+
+// Stand-alone stage kernels (per-stage drop-ins and the non-fused fallbacks).
+hipError_t launch_qpsk(const uint8_t *in, size_t nbytes, int K, float2 *out, hipStream_t s);
+hipError_t launch_freq_interleave(const float2 *in, size_t nsamples, int K,
+                                  const uint16_t *src_carrier, float2 *out, hipStream_t s);
+hipError_t launch_phase_reference(const uint8_t *phase_q, int K, float2 *out, hipStream_t s);
+hipError_t launch_diff_mod(const float2 *phase, const float2 *data, size_t nsym_data, int K,
+                           float2 *out, hipStream_t s);
+hipError_t launch_gain(const float2 *in, size_t nsym, int N, GainParams gp, float2 *out,
+                       hipStream_t s);
+hipError_t launch_guard_copy(const float2 *in, size_t n_frames, Geometry g, float2 *out,
+                             hipStream_t s);
+hipError_t launch_guard_window(const float2 *in, size_t n_frames, Geometry g, int overlap,
+                               const float *window, float2 *out, hipStream_t s);
+hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, const float *taps,
+                      int ntaps, float2 *out, hipStream_t s);
+hipError_t launch_poly(const float2 *in, size_t nsamples, const float *am, const float *pm,
+                       float2 *out, hipStream_t s);
+hipError_t launch_lut(const float2 *in, size_t nsamples, float scale, const float *lut,
+                      float2 *out, hipStream_t s);
+
+// Resampler (reference src/Resampler.cpp:131-195), power-of-two FFT sizes.
+struct ResamplerArgs {
+    int nin, nout;          // FFT sizes (e.g. 4096 -> 16384)
+    float factor;
+    const float *window;    // nin
+    const float2 *tw_in;    // nin entries exp(+2 pi i m / nin)
+    const float2 *tw_out;   // nout entries
+    const float2 *in;       // nhops * nin/2 samples (one stream)
+    const float2 *halo;     // nin samples: the two hops before `in` (zeros at stream start)
+    float2 *out;            // nhops * nout/2
+    size_t nhops;
+};
+hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s);
+
+}  // namespace dabgpu
