@@ -13,7 +13,8 @@ import numpy as np
 
 _DIR = os.path.dirname(os.path.abspath(__file__))
 _CSRC = os.path.join(_DIR, "csrc")
-LIB_PATH = os.path.join(_CSRC, "libdabgpu.so")
+# DABGPU_LIB selects another build of the same library (tuning sweeps); never a fallback
+LIB_PATH = os.environ.get("DABGPU_LIB") or os.path.join(_CSRC, "libdabgpu.so")
 
 STAGE_GAIN, STAGE_FIR, STAGE_RESAMPLE, STAGE_POLY, STAGE_NOGUARD = 1, 2, 4, 8, 1 << 8
 GAIN_FIX, GAIN_MAX, GAIN_VAR = 0, 1, 2

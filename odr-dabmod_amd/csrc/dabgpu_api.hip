@@ -90,7 +90,7 @@ struct dabgpu_ctx {
     std::string err;
 
     // constant tables
-    DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_window, d_coef;
+    DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_firh, d_window, d_coef;
     // resampler
     DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo, d_rs_spec;
     int rs_nin = 0, rs_nout = 0;
@@ -229,6 +229,22 @@ int apply_settings(dabgpu_ctx *c)
     std::vector<float> taps(kMaxTaps, 0.0f);
     std::copy(c->cur.taps.begin(), c->cur.taps.end(), taps.begin());
     HIPCHK(c, upload(c->d_taps, taps, s));
+    {
+        // frequency response seen by the look-ahead FIR on a cyclically extended symbol:
+        // H[k] = sum_j taps[j] exp(+2 pi i j k / N), evaluated in float64
+        const int N = c->g.N;
+        std::vector<float2> h(N);
+        for (int k = 0; k < N; ++k) {
+            double re = 0.0, im = 0.0;
+            for (size_t j = 0; j < c->cur.taps.size(); ++j) {
+                const double a = 2.0 * M_PI * (double)((j * (size_t)k) % (size_t)N) / (double)N;
+                re += (double)c->cur.taps[j] * std::cos(a);
+                im += (double)c->cur.taps[j] * std::sin(a);
+            }
+            h[k] = make_float2((float)re, (float)im);
+        }
+        HIPCHK(c, upload(c->d_firh, h, s));
+    }
     if (c->cur.overlap) {
         // src/GuardIntervalInserter.cpp:106-111
         const size_t W = c->cur.overlap;
@@ -289,6 +305,7 @@ Tables tables_of(dabgpu_ctx *c)
     t.mag = (const float *)c->d_mag.p;
     t.taps = (const float *)c->d_taps.p;
     t.window = (const float *)c->d_window.p;
+    t.fir_h = (const float2 *)c->d_firh.p;
     return t;
 }
 
@@ -389,8 +406,10 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
 
     const size_t native = (mask & DABGPU_STAGE_NOGUARD) ? per : tf_samples(c->g);
     const bool post = mask & (DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY);
-    const bool windowed = c->cur.overlap > 0 && !(mask & DABGPU_STAGE_NOGUARD);
-    if (windowed) {
+    const bool fir_fits = (int)c->cur.taps.size() - 1 <= c->g.sym_size - c->g.N;
+    const bool windowed = (c->cur.overlap > 0 || ((mask & DABGPU_STAGE_FIR) && !fir_fits)) &&
+                          !(mask & DABGPU_STAGE_NOGUARD);
+    if (windowed && c->cur.overlap > 0) {
         const size_t W = c->cur.overlap;
         if (W > (size_t)(c->g.sym_size - c->g.N))
             return fail(c, DABGPU_E_INVALID, "window overlap larger than the guard interval");
@@ -436,8 +455,11 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             HIPCHK(c, c->d_c.reserve(n_frames * native * sizeof(float2)));
             gout = (float2 *)c->d_c.p;
         }
-        HIPCHK(c, launch_guard_window((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
-                                      (const float *)c->d_window.p, gout, s));
+        if (c->cur.overlap > 0)
+            HIPCHK(c, launch_guard_window((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
+                                          (const float *)c->d_window.p, gout, s));
+        else
+            HIPCHK(c, launch_guard_copy((const float2 *)c->d_b.p, n_frames, c->g, gout, s));
         if (mask & DABGPU_STAGE_FIR)
             HIPCHK(c, launch_fir(gout, native, n_frames, (const float *)c->d_taps.p,
                                  (int)c->cur.taps.size(), native_out, s));
@@ -562,7 +584,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps,
+    for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
                       &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out})
         b->release();

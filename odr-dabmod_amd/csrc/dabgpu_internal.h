@@ -29,6 +29,7 @@ struct Tables {
     const float *mag;             // nb_symbols: |y| after s differential multiplications (fp32 recurrence)
     const float *taps;            // kMaxTaps floats, zero padded
     const float *window;          // 2*overlap floats (guard-interval raised cosine)
+    const float2 *fir_h;          // N: frequency response of the taps, sum_j taps[j] e^{+2 pi i jk/N}
 };
 
 struct GainParams {

@@ -25,6 +25,14 @@
 
 #include <algorithm>
 
+// build-time tuning knobs (tools/variants.sh sweeps them)
+#ifndef DABGPU_TF_WAVES
+#define DABGPU_TF_WAVES 2      // __launch_bounds__ waves per SIMD for tf_kernel (2 -> <=256 VGPRs, no spills)
+#endif
+#ifndef DABGPU_FIR_SCHED
+#define DABGPU_FIR_SCHED 1
+#endif
+
 namespace dabgpu {
 namespace {
 
@@ -192,15 +200,24 @@ DEV float wave_max(float x)
     return x;
 }
 
-template <int T> DEV void block_sum2(float &a, float &b, float *red, int t)
+DEV double wave_sum_d(double x)
 {
-    a = wave_sum(a);
-    b = wave_sum(b);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) x += __shfl_xor(x, o, 64);
+    return x;
+}
+
+// two sums at once, accumulated in float64 (four values per symbol: cheap, and it
+// keeps the variance within 1e-8 of the exact population variance)
+template <int T> DEV void block_sum2(double &a, double &b, double *red, int t)
+{
+    a = wave_sum_d(a);
+    b = wave_sum_d(b);
     constexpr int NW = (T + 63) / 64;
     if (NW > 1) {
         if ((t & 63) == 0) { red[2 * (t >> 6)] = a; red[2 * (t >> 6) + 1] = b; }
         __syncthreads();
-        float sa = 0.f, sb = 0.f;
+        double sa = 0., sb = 0.;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { sa += red[2 * w]; sb += red[2 * w + 1]; }
         a = sa; b = sb;
@@ -208,8 +225,9 @@ template <int T> DEV void block_sum2(float &a, float &b, float *red, int t)
     }
 }
 
-template <int T> DEV float block_max(float a, float *red, int t)
+template <int T> DEV float block_max(float a, double *redd, int t)
 {
+    float *red = reinterpret_cast<float *>(redd);
     a = wave_max(a);
     constexpr int NW = (T + 63) / 64;
     if (NW > 1) {
@@ -227,10 +245,10 @@ template <int T> DEV float block_max(float a, float *red, int t)
 // Gain of one symbol from its N samples held 8 per lane.
 // Reference src/GainControl.cpp:196-340 (a per-SSE-lane running mean / running variance;
 // here: two-pass mean / population variance, parallel reduction).
-template <int T> DEV float symbol_gain(const cf *v, const GainParams &gp, float *red, int t,
+template <int T> DEV float symbol_gain(const cf *v, const GainParams &gp, double *red, int t,
                                         bool on = true)
 {
-    constexpr float invN = 1.0f / (8 * T);
+    constexpr double invN = 1.0 / (8 * T);
     const float live = on ? 1.0f : 0.0f;  // lanes beyond T (N = 256 only) contribute nothing
     if (gp.mode == 0) return 512.0f;
     if (gp.mode == 1) {
@@ -240,22 +258,23 @@ template <int T> DEV float symbol_gain(const cf *v, const GainParams &gp, float 
         m = block_max<T>(m * live, red, t);
         return ((int)m != 0) ? 32767.0f / m : 1.0f;
     }
-    float sr = 0.f, si = 0.f;
+    double sr = 0., si = 0.;
 #pragma unroll
-    for (int i = 0; i < 8; ++i) { sr += v[i].x; si += v[i].y; }
+    for (int i = 0; i < 8; ++i) { sr += (double)v[i].x; si += (double)v[i].y; }
     sr *= live; si *= live;
     block_sum2<T>(sr, si, red, t);
-    const float mr = sr * invN, mi = si * invN;
-    float qr = 0.f, qi = 0.f;
+    const float mr = (float)(sr * invN), mi = (float)(si * invN);
+    double qr = 0., qi = 0.;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const float dr = v[i].x - mr, di = v[i].y - mi;
-        qr = fmaf(dr, dr, qr);
-        qi = fmaf(di, di, qi);
+        qr += (double)dr * (double)dr;
+        qi += (double)di * (double)di;
     }
     qr *= live; qi *= live;
     block_sum2<T>(qr, qi, red, t);
-    const float vr = sqrtf(qr * invN) * gp.var_variance, vi = sqrtf(qi * invN) * gp.var_variance;
+    const float vr = sqrtf((float)(qr * invN)) * gp.var_variance,
+                vi = sqrtf((float)(qi * invN)) * gp.var_variance;
     if ((int)vr == 0) return 1.0f;
     return 32767.0f / fmaxf(vr, vi);
 }
@@ -291,37 +310,44 @@ template <int NTP, int R> DEV void fir_block(const cf *__restrict__ sb, int j0,
 #pragma unroll
             for (int i = R - 1; i < R + G - 1; ++i) w[i] = sb[j0 + (g + 1) * G + i];
         }
+#if DABGPU_FIR_SCHED
+        // keep the scheduler from hoisting every group's LDS loads to the top of the
+        // unrolled block (that is what drove the kernel past 128 VGPRs into scratch)
+        __builtin_amdgcn_sched_barrier(0);
+#endif
     }
 }
 
 // ---------------------------------------------------------------------------
-template <int LOGN, int NTP> struct TfLayout {
-    static constexpr int N = 1 << LOGN;
-    static constexpr int T = N / 8;
-    static constexpr int R = 10;                      // FIR outputs per lane per pass
-    // stream buffer: [carry (ntaps-1) | segment (<= null_size) | NTP zero pad] (+ slack for the
-    // last pass of the FIR reading R+7 beyond)
-    static constexpr int SB = (NTP - 1) + (N + N / 2) + NTP + 2 * T * 0 + 32;
-};
-
 // cos/sin of p*45deg as {-1,0,+1} codes: (CX >> 2p) & 3 = value + 1
 constexpr unsigned kCX = 0x901Au;
+constexpr int kBnd = 128;  // LDS slots per boundary buffer (>= kMaxTaps - 1)
 
-template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NTP>
-__global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8, 4)
+// FIR inside the fused kernel ("spectral FIR").
+// The stream is a chain of cyclically extended symbols, and the FIR looks AHEAD
+// (out[n] = sum_j taps[j] in[n+j]), so every output whose ntaps-1 look-ahead
+// samples stay inside its own segment is a CIRCULAR convolution of the symbol:
+//     out[p] = g_s * IDFT_N( X_s[k] * H[k] )[(p - cp) mod N],  H[k] = sum_j taps[j] e^{+2 pi i jk/N}
+// i.e. a second IFFT of the same carriers under a per-bin factor.  Only the last
+// C = ntaps-1 samples of a segment see the next symbol; those 44 outputs are
+// computed directly from the C-sample tail of this symbol and the C-sample head
+// of the next one (unfiltered, gain applied), kept in LDS.  Cost per symbol:
+// 2 FFTs + C*ntaps MACs instead of 1 FFT + N*ntaps MACs.
+
+template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR>
+__global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8, DABGPU_TF_WAVES)
 void tf_kernel(const TfArgs a)
 {
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
-    constexpr int R = TfLayout<LOGN, NTP>::R;
     const int t = threadIdx.x;
     const bool lane_on = t < T;  // only N=256 (T=32) runs with idle lanes
     const int tt = lane_on ? t : 0;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf *fbuf = reinterpret_cast<cf *>(smem);                 // N + N/8 complex
-    float *red = reinterpret_cast<float *>(fbuf + F::LDS_ELEMS);  // 16 floats
-    cf *sb = reinterpret_cast<cf *>(red + 16);               // stream buffer (FIR only)
+    cf *fbuf = reinterpret_cast<cf *>(smem);                        // N + N/8 complex
+    double *red = reinterpret_cast<double *>(fbuf + F::LDS_ELEMS);  // 16 doubles
+    cf *bnd = reinterpret_cast<cf *>(red + 16);                     // FIR: tail[2][kBnd], head[kBnd]
 
     const int K = a.g.K, nsym = a.g.nb_symbols + 1;
     const int frame = blockIdx.x / a.chunks_per_frame;
@@ -330,7 +356,7 @@ void tf_kernel(const TfArgs a)
     const int s_end = min(nsym, s_begin + a.syms_per_chunk);
     if (frame >= a.n_frames || s_begin >= nsym) return;
 
-    const int C = FIR ? a.ntaps - 1 : 0;  // FIR look-ahead = carry length
+    const int C = FIR ? a.ntaps - 1 : 0;  // FIR look-ahead
     const int cp0 = GUARD ? a.g.null_size - N : 0, cp = GUARD ? a.g.sym_size - N : 0;
     const int len0 = N + cp0, len = N + cp;
 
@@ -340,14 +366,16 @@ void tf_kernel(const TfArgs a)
 
     // the lane's 6 active first-stage inputs: r = {0|3,1,2,5,6,7}; bin = t + T*r
     // interleaved position k: bins 1..K/2 -> k = bin-1 ; bins N-K/2.. -> k = bin-N+K
+    const int r0 = (tt == 0) ? 3 : 0;
     int kpos[6];
+    cf hk[6];
     {
-        const int r0 = (tt == 0) ? 3 : 0;
         const int rr[6] = {r0, 1, 2, 5, 6, 7};
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const int bin = tt + T * rr[c];
             kpos[c] = (bin <= K / 2) ? bin - 1 : bin - N + K;
+            if (FIR) hk[c] = a.t.fir_h[bin];
         }
     }
     int bitpos[6];
@@ -366,7 +394,7 @@ void tf_kernel(const TfArgs a)
     cf *fout = a.out + (size_t)frame * a.out_stride;
 
     // advance the differential state over data block d (symbol s = d + 2)
-    auto advance = [&](int d) {
+    auto advance = [&](int d) __attribute__((always_inline)) {
         const uint8_t *blk = fbits + (size_t)d * (size_t)(K / 4);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
@@ -378,66 +406,85 @@ void tf_kernel(const TfArgs a)
         }
     };
 
-    // frequency-domain symbol s into v[8] (first-stage layout)
-    auto load_symbol = [&](int s, cf *v) {
-#pragma unroll
-        for (int r = 0; r < 8; ++r) v[r] = mk(0.f, 0.f);
-        const int r0 = (tt == 0) ? 3 : 0;
+    // the lane's 6 active carriers of symbol s
+    auto load_active = [&](int s, cf *val) __attribute__((always_inline)) {
         if (FROM_BITS) {
-            if (s >= 1) {
-                const float mg = a.t.mag[s - 1];
-                cf val[6];
+            const float mg = s >= 1 ? a.t.mag[s - 1] : 0.f;
 #pragma unroll
-                for (int c = 0; c < 6; ++c) {
-                    const unsigned p = phase[c];
-                    const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
-                    const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
-                    val[c] = mk(cx * mg, cy * mg);
-                }
-                if (r0 == 0) v[0] = val[0]; else v[3] = val[0];
-                v[1] = val[1]; v[2] = val[2]; v[5] = val[3]; v[6] = val[4]; v[7] = val[5];
+            for (int c = 0; c < 6; ++c) {
+                const unsigned p = phase[c];
+                const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
+                const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
+                val[c] = mk(cx * mg, cy * mg);
             }
         } else {
             const cf *sym = fcar + (size_t)s * (size_t)K;
-            cf val[6];
 #pragma unroll
             for (int c = 0; c < 6; ++c) val[c] = sym[kpos[c]];
-            if (r0 == 0) v[0] = val[0]; else v[3] = val[0];
-            v[1] = val[1]; v[2] = val[2]; v[5] = val[3]; v[6] = val[4]; v[7] = val[5];
         }
     };
+    // scatter them into the first-stage register layout
+    auto place = [&](const cf *val, cf *v) __attribute__((always_inline)) {
+        v[0] = r0 == 0 ? val[0] : mk(0.f, 0.f);
+        v[3] = r0 == 0 ? mk(0.f, 0.f) : val[0];
+        v[4] = mk(0.f, 0.f);
+        v[1] = val[1]; v[2] = val[2]; v[5] = val[3]; v[6] = val[4]; v[7] = val[5];
+    };
 
-    // ---- FIR state ---------------------------------------------------------
-    const float *taps = a.t.taps;
-    if (FIR) {
-        for (int i = t; i < TfLayout<LOGN, NTP>::SB; i += blockDim.x) sb[i] = mk(0.f, 0.f);
-        __syncthreads();
-    }
-
-    // where the chunk starts: with FIR the symbol before s_begin is computed
-    // too (no output) to obtain its last ntaps-1 samples.
-    const int s_first = (FIR && s_begin > 0) ? s_begin - 1 : s_begin;
     if (FROM_BITS) {
         // the loop below applies block s-2 on entering symbol s; bring the state to
-        // "blocks 0 .. s_first-3 applied"
-        for (int d = 0; d + 3 <= s_first; ++d) advance(d);
+        // "blocks 0 .. s_begin-3 applied"
+        for (int d = 0; d + 3 <= s_begin; ++d) advance(d);
     }
 
     // gain of the NULL symbol = gain computed on symbol 1 (reference
     // src/GainControl.cpp:139-144); only matters when symbol 0 is not blank.
     float g_null = 1.0f;
-    if (GAIN && !FROM_BITS && s_first == 0) {
-        cf v[8];
-        load_symbol(1, v);
+    if (GAIN && !FROM_BITS && s_begin == 0) {
+        cf val[6], v[8];
+        load_active(1, val);
+        place(val, v);
         F::template run<+1>(v, fbuf, tw, tt);
         g_null = symbol_gain<T>(v, a.gain, red, tt, lane_on);
     }
 
-    int prev_len = 0;  // samples of the previous segment in sb (after the carry)
-    for (int s = s_first; s < s_end; ++s) {
-        cf v[8];
+    // With FIR the symbol after the chunk is transformed too (first IFFT only) to
+    // obtain the head that the chunk's last boundary outputs look into.
+    const int s_stop = (FIR && s_end < nsym) ? s_end + 1 : s_end;
+    int cur = 0;               // which tail buffer holds the previous symbol's tail
+    size_t prev_pos = 0;       // stream position of the previous segment
+    int prev_seg = 0;
+    bool have_prev = false;
+
+    // boundary outputs of the previous segment: 4 lanes per output, shuffle-reduced
+    auto boundary = [&](const cf *tail, const cf *head, bool head_zero) __attribute__((always_inline)) {
+        const float *taps = a.t.taps;
+        for (int i0 = 0; i0 < C; i0 += (int)blockDim.x / 4) {
+            const int i = i0 + (t >> 2), q = t & 3;
+            cf acc = mk(0.f, 0.f);
+            if (i < C) {
+                for (int j = q; j < a.ntaps; j += 4) {
+                    const int u = i + j;
+                    cf x = mk(0.f, 0.f);
+                    if (u < C) x = tail[u];
+                    else if (!head_zero) x = head[u - C];
+                    const float tp = taps[j];
+                    acc.x = fmaf(x.x, tp, acc.x);
+                    acc.y = fmaf(x.y, tp, acc.y);
+                }
+            }
+            acc.x += __shfl_xor(acc.x, 1, 64); acc.y += __shfl_xor(acc.y, 1, 64);
+            acc.x += __shfl_xor(acc.x, 2, 64); acc.y += __shfl_xor(acc.y, 2, 64);
+            if (i < C && q == 0) fout[prev_pos + (size_t)(prev_seg - C + i)] = acc;
+        }
+    };
+
+    for (int s = s_begin; s < s_stop; ++s) {
+        const bool lookahead = s >= s_end;      // FIR only: no output for this symbol
+        cf val[6], v[8];
         if (FROM_BITS && s >= 2) advance(s - 2);
-        load_symbol(s, v);
+        load_active(s, val);
+        place(val, v);
         const bool blank = FROM_BITS && s == 0;  // NULL symbol without TII: exact zeros
         if (!blank) F::template run<+1>(v, fbuf, tw, tt);
 
@@ -445,8 +492,6 @@ void tf_kernel(const TfArgs a)
         if (GAIN) {
             g = (s == 0) ? g_null : symbol_gain<T>(v, a.gain, red, tt, lane_on);
             g = g * a.gain.constant;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = cscale(v[m], g);
         }
 
         const int cpl = (s == 0) ? cp0 : cp;
@@ -455,67 +500,71 @@ void tf_kernel(const TfArgs a)
         const size_t pos = GUARD ? (s == 0 ? 0 : (size_t)len0 + (size_t)(s - 1) * (size_t)len)
                                  : (size_t)s * (size_t)N;
         if (!FIR) {
-            if (s >= s_begin && lane_on) {
+            if (lane_on) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int n = t + T * m;
-                    fout[pos + cpl + n] = v[m];
-                    if (n >= N - cpl) fout[pos + n - (N - cpl)] = v[m];
+                    const cf y = GAIN ? cscale(v[m], g) : v[m];
+                    fout[pos + cpl + n] = y;
+                    if (n >= N - cpl) fout[pos + n - (N - cpl)] = y;
                 }
             }
             continue;
         }
 
-        // ---- FIR path: [carry | segment | zeros] in LDS ---------------------
-        cf carry = mk(0.f, 0.f);
-        if (t < C && prev_len > 0) carry = sb[prev_len + t];
-        __syncthreads();
-        if (t < C) sb[t] = carry;
+        // ---- FIR: boundary samples of the unfiltered, gain-scaled symbol ------
+        cf *tail_new = bnd + (cur ^ 1) * kBnd, *tail_prev = bnd + cur * kBnd, *head = bnd + 2 * kBnd;
         if (lane_on) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
-                sb[C + cpl + n] = v[m];
-                if (n >= N - cpl) sb[C + n - (N - cpl)] = v[m];
+                const cf y = cscale(v[m], g);
+                if (n >= N - C) tail_new[n - (N - C)] = y;                       // last C samples
+                const int hn = n - (N - cpl);                                   // head of the segment =
+                if (hn >= 0 && hn < C) head[hn] = y;                             // start of the cyclic prefix
             }
         }
-        for (int i = t; i < NTP + R + 8; i += blockDim.x) sb[C + seg + i] = mk(0.f, 0.f);
         __syncthreads();
-        prev_len = seg;
+        if (have_prev) boundary(tail_prev, head, false);
+        cur ^= 1;
+        if (lookahead) break;
 
-        if (s >= s_begin || s + 1 == s_begin) {
-            // outputs j in [0, nout): stream position pos - C + j
-            const bool last = (s == nsym - 1);
-            const int nout = seg + (last ? C : 0);
-            // first valid j: positions before the chunk's own range are skipped
-            // (they belong to the previous chunk, or lie before the frame start)
-            int jmin = 0;
-            if (s == 0) jmin = C;                 // stream position would be negative
-            if (s + 1 == s_begin) jmin = seg;     // warm-up symbol: nothing to emit
-            // the chunk [s_begin, s_end) emits stream [pos(s_begin)-C, pos(s_end)-C)
-            for (int jb = 0; jb < nout; jb += T * R) {
-                const int j0 = jb + t * R;
-                if (!lane_on || j0 >= nout || j0 + R <= jmin) continue;
-                cf acc[R];
-                fir_block<NTP, R>(sb, j0, taps, acc);
+        // ---- second IFFT: carriers times the filter's frequency response ------
+        if (!blank) {
 #pragma unroll
-                for (int i = 0; i < R; ++i) {
-                    const int j = j0 + i;
-                    if (j >= jmin && j < nout) fout[pos + (size_t)j - (size_t)C] = acc[i];
-                }
+            for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
+            place(val, v);
+            F::template run<+1>(v, fbuf, tw, tt);
+        }
+        if (lane_on) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int n = t + T * m;
+                const cf y = cscale(v[m], g);
+                if (n < N - C) fout[pos + cpl + n] = y;                 // the last C belong to `boundary`
+                if (n >= N - cpl) fout[pos + n - (N - cpl)] = y;
             }
         }
+        have_prev = true;
+        prev_pos = pos;
+        prev_seg = seg;
+    }
+    if (FIR && s_end == nsym && have_prev) {
+        // end of the frame: the look-ahead runs off the buffer, missing terms are
+        // dropped (reference src/FIRFilter.cpp:186-191)
+        __syncthreads();
+        boundary(bnd + cur * kBnd, bnd + 2 * kBnd, true);
     }
 }
 
-template <int LOGN, int NTP> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)
+template <int LOGN> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)
 {
     constexpr int T = (1 << LOGN) / 8;
     const dim3 block(T < 64 ? 64 : T);
     const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
-    const size_t lds = tf_lds_bytes(LOGN, flags | (NTP > 48 ? 0x100u : 0u));
+    const size_t lds = tf_lds_bytes(LOGN, flags);
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
-    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, NTP>), grid, block, lds, s, a)
+    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR>), grid, block, lds, s, a)
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
@@ -535,27 +584,23 @@ template <int LOGN, int NTP> hipError_t launch_tf_n(const TfArgs &a, unsigned fl
 size_t tf_lds_bytes(int logN, unsigned flags)
 {
     const size_t N = (size_t)1 << logN;
-    size_t b = (N + N / 8) * sizeof(float2) + 16 * sizeof(float);
-    if (flags & TF_FIR) {
-        const int ntp = (flags & 0x100u) ? 128 : 48;
-        b += ((size_t)(ntp - 1) + N + N / 2 + (size_t)ntp + 32) * sizeof(float2);
-    }
+    size_t b = (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
+    if (flags & TF_FIR) b += 3 * 128 * sizeof(float2);  // tail[2], head
     return b;
 }
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
 {
-    const bool big = (flags & TF_FIR) && a.ntaps > 48;
-    if ((flags & TF_FIR) && (a.ntaps < 1 || a.ntaps > kMaxTaps)) return hipErrorInvalidValue;
+    if (flags & TF_FIR) {
+        // the fused (spectral) FIR needs its look-ahead to fit in a cyclic prefix
+        const int C = a.ntaps - 1;
+        if (a.ntaps < 1 || a.ntaps > kMaxTaps || C > a.g.sym_size - a.g.N) return hipErrorInvalidValue;
+    }
     switch (a.g.logN) {
-#define CASE(L)                                                                                \
-    case L:                                                                                    \
-        return big ? launch_tf_n<L, 128>(a, flags, s) : launch_tf_n<L, 48>(a, flags, s);
-        CASE(8)
-        CASE(9)
-        CASE(10)
-        CASE(11)
-#undef CASE
+        case 8: return launch_tf_n<8>(a, flags, s);
+        case 9: return launch_tf_n<9>(a, flags, s);
+        case 10: return launch_tf_n<10>(a, flags, s);
+        case 11: return launch_tf_n<11>(a, flags, s);
     }
     return hipErrorInvalidValue;
 }
@@ -614,15 +659,16 @@ __global__ void phase_reference_kernel(const uint8_t *__restrict__ q, int K, cf 
 __global__ void diff_mod_kernel(const cf *__restrict__ phase, const cf *__restrict__ data,
                                 size_t nsym, int K, cf *__restrict__ out)
 {
+#pragma clang fp contract(off)  // round products and sums separately (the HIP *_rn helpers are plain operators)
     const int k = blockIdx.x * blockDim.x + threadIdx.x;
     if (k >= K) return;
     cf y = phase[k];
     out[k] = y;
     for (size_t s = 0; s < nsym; ++s) {
         const cf x = data[s * (size_t)K + k];
-        const float rr = __fmul_rn(y.x, x.x), ii = __fmul_rn(y.y, x.y);
-        const float ri = __fmul_rn(y.x, x.y), ir = __fmul_rn(y.y, x.x);
-        y = mk(__fsub_rn(rr, ii), __fadd_rn(ri, ir));
+        const float rr = y.x * x.x, ii = y.y * x.y;
+        const float ri = y.x * x.y, ir = y.y * x.x;
+        y = mk(rr - ii, ri + ir);
         out[(s + 1) * (size_t)K + k] = y;
     }
 }
@@ -633,7 +679,7 @@ template <int LOGN> __global__ void gain_kernel(const cf *__restrict__ in, size_
                                                 GainParams gp, cf *__restrict__ out)
 {
     constexpr int N = 1 << LOGN, T = N / 8;
-    __shared__ float red[16];
+    __shared__ double red[16];
     const size_t s = blockIdx.x;
     const int t = threadIdx.x;
     const bool on = t < T;
@@ -675,6 +721,7 @@ __global__ void guard_copy_kernel(const cf *__restrict__ in, size_t n_frames, Ge
 __global__ void guard_window_kernel(const cf *__restrict__ in, size_t n_frames, Geometry g, int W,
                                     const float *__restrict__ win, cf *__restrict__ out)
 {
+#pragma clang fp contract(off)  // products and sums rounded separately, like the reference
     const size_t tf = (size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_frames * tf) return;
@@ -694,10 +741,10 @@ __global__ void guard_window_kernel(const cf *__restrict__ in, size_t n_frames, 
         // overwritten first by the previous symbol's suffix (1/2 -> 0), then += own rising edge
         const cf *xp = x - N;
         const float fs = win[W - 1 - o];
-        r = mk(__fmul_rn(xp[o].x, fs), __fmul_rn(xp[o].y, fs));
+        r = mk(xp[o].x * fs, xp[o].y * fs);
         const float fr = win[W + o];
         const cf xr = x[N - cpl + o];
-        r = mk(__fadd_rn(r.x, __fmul_rn(xr.x, fr)), __fadd_rn(r.y, __fmul_rn(xr.y, fr)));
+        { const float pr_ = xr.x * fr, pi_ = xr.y * fr; r = mk(r.x + pr_, r.y + pi_); }
         have = true;
     }
     if (!have) {
@@ -706,12 +753,12 @@ __global__ void guard_window_kernel(const cf *__restrict__ in, size_t n_frames, 
             // falling half window 1 -> 1/2, then the next symbol's rising edge is added
             const int i2 = o - (seg - W);
             const float ff = win[2 * W - 1 - i2];
-            r = mk(__fmul_rn(x[n].x, ff), __fmul_rn(x[n].y, ff));
+            r = mk(x[n].x * ff, x[n].y * ff);
             const cf *xn = x + N;
             const int cpn = g.sym_size - N;
             const cf xr = xn[N - cpn - W + i2];
             const float fr = win[i2];
-            r = mk(__fadd_rn(r.x, __fmul_rn(xr.x, fr)), __fadd_rn(r.y, __fmul_rn(xr.y, fr)));
+            { const float pr_ = xr.x * fr, pi_ = xr.y * fr; r = mk(r.x + pr_, r.y + pi_); }
         } else {
             r = x[n];
         }
