@@ -32,6 +32,11 @@
 #ifndef DABGPU_FIR_SCHED
 #define DABGPU_FIR_SCHED 1
 #endif
+#ifndef DABGPU_TW_POWERS
+// twiddles resident in registers per FFT stage: 0 = all seven W^r; 1 = W, W^2, W^4 (the
+// rest are products of two of them); 2 = W only (powers by repeated multiplication)
+#define DABGPU_TW_POWERS 0
+#endif
 
 namespace dabgpu {
 namespace {
@@ -40,6 +45,13 @@ typedef float2 cf;
 #define DEV __device__ __forceinline__
 
 constexpr float kSqrtHalf = 0.70710678118654752440f;
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() carries a
+// workgroup fence over ALL address spaces, which on gfx950 becomes s_waitcnt vmcnt(0):
+// with global stores in flight (every symbol ends with ~10 of them per wave) each
+// barrier would wait for HBM write acknowledgements.  Nothing in these kernels
+// communicates between waves through global memory, so LDS ordering is all we need.
+DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 DEV cf mk(float x, float y) { return make_float2(x, y); }
 DEV cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
@@ -87,7 +99,10 @@ template <int LOGN> struct Fft {
     static constexpr int NR8 = LOGN / 3;          // radix-8 stages
     static constexpr int RF = N >> (3 * NR8);     // final radix 1/2/4
     static constexpr int NB = RF > 1 ? 8 / RF : 0;  // final-stage butterflies per lane
-    static constexpr int NTW = 7 * (NR8 - 1) + NB * (RF > 1 ? RF - 1 : 0);
+    static constexpr int TWM = DABGPU_TW_POWERS;
+    static constexpr int TW_PER_STAGE = TWM == 0 ? 7 : (TWM == 1 ? 3 : 1);
+    static constexpr int TW_FINAL = RF > 1 ? (TWM == 0 ? RF - 1 : 1) : 0;
+    static constexpr int NTW = TW_PER_STAGE * (NR8 - 1) + NB * TW_FINAL;
 
     // LDS image of the exchange buffer: element i lives at i + (i >> 3) for the
     // two scatters with stride 1 and 8 (pad one slot per 8: ds_write_b64 is then
@@ -104,7 +119,7 @@ template <int LOGN> struct Fft {
             cf *wp = lds + (j0 + (j0 >> 3));
 #pragma unroll
             for (int r = 0; r < 8; ++r) wp[r * NS + (r * NS) / 8] = v[r];
-            __syncthreads();
+            lds_barrier();
             const cf *rp = lds + (t + (t >> 3));
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = rp[m * (T + T / 8)];
@@ -113,12 +128,12 @@ template <int LOGN> struct Fft {
             cf *wp = lds + j0;
 #pragma unroll
             for (int r = 0; r < 8; ++r) wp[r * NS] = v[r];
-            __syncthreads();
+            lds_barrier();
             const cf *rp = lds + t;
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = rp[m * T];
         }
-        __syncthreads();
+        lds_barrier();
     }
 
     static DEV void load_twiddles(const cf *__restrict__ wtab, int t, cf *tw)
@@ -127,15 +142,46 @@ template <int LOGN> struct Fft {
         int ns = 8;
 #pragma unroll
         for (int st = 1; st < NR8; ++st) {
+            const int base = (t % ns) * (N / (ns * 8));
 #pragma unroll
-            for (int r = 1; r < 8; ++r) tw[n++] = wtab[(r * (t % ns) * (N / (ns * 8))) & (N - 1)];
+            for (int r = 1; r < 8; ++r) {
+                const bool keep = TWM == 0 || (TWM == 1 && (r == 1 || r == 2 || r == 4)) || (TWM == 2 && r == 1);
+                if (keep) tw[n++] = wtab[(r * base) & (N - 1)];
+            }
             ns *= 8;
         }
         if (RF > 1) {
 #pragma unroll
             for (int b = 0; b < NB; ++b)
 #pragma unroll
-                for (int r = 1; r < RF; ++r) tw[n++] = wtab[(r * (t + T * b)) & (N - 1)];
+                for (int r = 1; r < RF; ++r)
+                    if (TWM == 0 || r == 1) tw[n++] = wtab[(r * (t + T * b)) & (N - 1)];
+        }
+    }
+
+    // the seven twiddles W^1..W^7 of a radix-8 stage from the resident subset
+    template <int S> static DEV void stage_twiddles(const cf *tw, int &n, cf *w)
+    {
+        if (TWM == 0) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw[n + r]);
+            n += 7;
+        } else if (TWM == 1) {
+            w[0] = twid<S>(tw[n]); w[1] = twid<S>(tw[n + 1]); w[3] = twid<S>(tw[n + 2]);
+            n += 3;
+            w[2] = cmul(w[0], w[1]);
+            w[4] = cmul(w[3], w[0]);
+            w[5] = cmul(w[3], w[1]);
+            w[6] = cmul(w[3], w[2]);
+        } else {
+            w[0] = twid<S>(tw[n]);
+            n += 1;
+            w[1] = cmul(w[0], w[0]);
+            w[2] = cmul(w[1], w[0]);
+            w[3] = cmul(w[1], w[1]);
+            w[4] = cmul(w[3], w[0]);
+            w[5] = cmul(w[2], w[2]);
+            w[6] = cmul(w[3], w[2]);
         }
     }
 
@@ -147,30 +193,42 @@ template <int LOGN> struct Fft {
         dft8<S>(v);
         exchange<1>(v, lds, t);
         int n = 0;
+        cf w[7];
         if (NR8 >= 2) {
+            stage_twiddles<S>(tw, n, w);
 #pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twid<S>(tw[n++]));
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
             if (NR8 > 2 || RF > 1) exchange<8>(v, lds, t);
         }
         if (NR8 >= 3) {
+            stage_twiddles<S>(tw, n, w);
 #pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twid<S>(tw[n++]));
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
             if (NR8 > 3 || RF > 1) exchange<64>(v, lds, t);
         }
         if (NR8 >= 4) {
+            stage_twiddles<S>(tw, n, w);
 #pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], twid<S>(tw[n++]));
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
             if (RF > 1) exchange<512>(v, lds, t);
         }
         if (RF == 4) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                cf x0 = v[b], x1 = cmul(v[b + 2], twid<S>(tw[n])), x2 = cmul(v[b + 4], twid<S>(tw[n + 1])),
-                   x3 = cmul(v[b + 6], twid<S>(tw[n + 2]));
-                n += 3;
+                cf w1, w2, w3;
+                if (TWM == 0) {
+                    w1 = twid<S>(tw[n]); w2 = twid<S>(tw[n + 1]); w3 = twid<S>(tw[n + 2]);
+                    n += 3;
+                } else {
+                    w1 = twid<S>(tw[n]);
+                    n += 1;
+                    w2 = cmul(w1, w1);
+                    w3 = cmul(w2, w1);
+                }
+                cf x0 = v[b], x1 = cmul(v[b + 2], w1), x2 = cmul(v[b + 4], w2), x3 = cmul(v[b + 6], w3);
                 dft4<S>(x0, x1, x2, x3);
                 v[b] = x0; v[b + 2] = x1; v[b + 4] = x2; v[b + 6] = x3;
             }
@@ -216,12 +274,12 @@ template <int T> DEV void block_sum2(double &a, double &b, double *red, int t)
     constexpr int NW = (T + 63) / 64;
     if (NW > 1) {
         if ((t & 63) == 0) { red[2 * (t >> 6)] = a; red[2 * (t >> 6) + 1] = b; }
-        __syncthreads();
+        lds_barrier();
         double sa = 0., sb = 0.;
 #pragma unroll
         for (int w = 0; w < NW; ++w) { sa += red[2 * w]; sb += red[2 * w + 1]; }
         a = sa; b = sb;
-        __syncthreads();
+        lds_barrier();
     }
 }
 
@@ -232,12 +290,12 @@ template <int T> DEV float block_max(float a, double *redd, int t)
     constexpr int NW = (T + 63) / 64;
     if (NW > 1) {
         if ((t & 63) == 0) red[t >> 6] = a;
-        __syncthreads();
+        lds_barrier();
         float m = red[0];
 #pragma unroll
         for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
         a = m;
-        __syncthreads();
+        lds_barrier();
     }
     return a;
 }
@@ -348,6 +406,19 @@ void tf_kernel(const TfArgs a)
     cf *fbuf = reinterpret_cast<cf *>(smem);                        // N + N/8 complex
     double *red = reinterpret_cast<double *>(fbuf + F::LDS_ELEMS);  // 16 doubles
     cf *bnd = reinterpret_cast<cf *>(red + 16);                     // FIR: tail[2][kBnd], head[kBnd]
+    // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 3 * kBnd : 0));
+    constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
+    constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
+    // small read-only tables copied to LDS once: read through global memory they compile to
+    // vector loads (the output stores may alias them), and every such load drags an
+    // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
+    float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
+    float *mag_l = taps_l + kMaxTaps;
+    for (int i = t; i < kMaxTaps; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
+    if (FROM_BITS)
+        for (int i = t; i < a.g.nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
+    lds_barrier();
 
     const int K = a.g.K, nsym = a.g.nb_symbols + 1;
     const int frame = blockIdx.x / a.chunks_per_frame;
@@ -393,32 +464,47 @@ void tf_kernel(const TfArgs a)
                                : a.carriers + (size_t)frame * (size_t)nsym * (size_t)K;
     cf *fout = a.out + (size_t)frame * a.out_stride;
 
-    // advance the differential state over data block d (symbol s = d + 2)
-    auto advance = [&](int d) __attribute__((always_inline)) {
-        const uint8_t *blk = fbits + (size_t)d * (size_t)(K / 4);
+    // advance the differential state over one data block (K/4 bytes: I bits, then Q bits)
+    // held in LDS or in global memory; the 12 byte reads are issued together
+    auto advance = [&](const uint8_t *blk) __attribute__((always_inline)) {
+        unsigned ib[6], qb[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const int n = bitpos[c];
-            const unsigned ib = (blk[n >> 3] >> (7 - (n & 7))) & 1u;
-            const unsigned qb = (blk[(K >> 3) + (n >> 3)] >> (7 - (n & 7))) & 1u;
-            const unsigned gcode = ib ^ (qb * 3u);  // 00->0 10->1 11->2 01->3 quarter turns
+            ib[c] = blk[bitpos[c] >> 3];
+            qb[c] = blk[(K >> 3) + (bitpos[c] >> 3)];
+        }
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int sh = 7 - (bitpos[c] & 7);
+            const unsigned i1 = (ib[c] >> sh) & 1u, q1 = (qb[c] >> sh) & 1u;
+            const unsigned gcode = i1 ^ (q1 * 3u);  // 00->0 10->1 11->2 01->3 quarter turns
             phase[c] = (phase[c] + 2u * gcode + 1u) & 7u;
         }
     };
+    // global -> register half of the staging of block d: lanes 0 .. K/16-1 fetch one dword
+    // each.  Kept free of divergent control flow on purpose (the other lanes re-read word 0
+    // and later park it in a dummy LDS slot): a load or its wait inside an exec-masked
+    // branch makes the compiler re-wait vmcnt(0) -- i.e. for the previous symbol's stores --
+    // at the top of the next iteration.
+    auto fetch_block = [&](int d) __attribute__((always_inline)) -> uint32_t {
+        const int dd = min(max(d, 0), a.g.nb_symbols - 2);
+        return reinterpret_cast<const uint32_t *>(fbits + (size_t)dd * (size_t)(K / 4))[t < kBitWords ? t : 0];
+    };
+    const int bit_slot = t < kBitWords ? t : kBitWords;   // kBitWords = dummy slot
 
     // the lane's 6 active carriers of symbol s
     auto load_active = [&](int s, cf *val) __attribute__((always_inline)) {
         if (FROM_BITS) {
-            const float mg = s >= 1 ? a.t.mag[s - 1] : 0.f;
+            const float mg = s >= 1 ? mag_l[s - 1] : 0.f;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const unsigned p = phase[c];
                 const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
                 const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
-                val[c] = mk(cx * mg, cy * mg);
+                val[c] = s >= 1 ? mk(cx * mg, cy * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
             }
         } else {
-            const cf *sym = fcar + (size_t)s * (size_t)K;
+            const cf *sym = fcar + (size_t)min(s, nsym - 1) * (size_t)K;
 #pragma unroll
             for (int c = 0; c < 6; ++c) val[c] = sym[kpos[c]];
         }
@@ -434,7 +520,9 @@ void tf_kernel(const TfArgs a)
     if (FROM_BITS) {
         // the loop below applies block s-2 on entering symbol s; bring the state to
         // "blocks 0 .. s_begin-3 applied"
-        for (int d = 0; d + 3 <= s_begin; ++d) advance(d);
+        for (int d = 0; d + 3 <= s_begin; ++d) advance(fbits + (size_t)d * (size_t)(K / 4));
+        // stage the block of the first symbol (block s_begin-2) into bitbuf[0]
+        bitbuf[bit_slot] = fetch_block(s_begin - 2);
     }
 
     // gain of the NULL symbol = gain computed on symbol 1 (reference
@@ -458,7 +546,7 @@ void tf_kernel(const TfArgs a)
 
     // boundary outputs of the previous segment: 4 lanes per output, shuffle-reduced
     auto boundary = [&](const cf *tail, const cf *head, bool head_zero) __attribute__((always_inline)) {
-        const float *taps = a.t.taps;
+        const float *taps = taps_l;
         for (int i0 = 0; i0 < C; i0 += (int)blockDim.x / 4) {
             const int i = i0 + (t >> 2), q = t & 3;
             cf acc = mk(0.f, 0.f);
@@ -479,11 +567,27 @@ void tf_kernel(const TfArgs a)
         }
     };
 
+    // Input of symbol s+1 is requested while symbol s is being transformed and BEFORE
+    // symbol s is stored: vmcnt retires in order, so a load issued after the stores would
+    // make every symbol wait for the previous symbol's HBM writes.
+    int bb = 0;                 // which bitbuf half holds the block of the current symbol
+    cf nval[6];                 // carriers path: the next symbol's active carriers
+    if (!FROM_BITS) load_active(s_begin, nval);
+
     for (int s = s_begin; s < s_stop; ++s) {
         const bool lookahead = s >= s_end;      // FIR only: no output for this symbol
         cf val[6], v[8];
-        if (FROM_BITS && s >= 2) advance(s - 2);
-        load_active(s, val);
+        uint32_t pf = 0u;
+        if (FROM_BITS) {
+            lds_barrier();                    // bitbuf[bb] written (prologue / previous iteration)
+            if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
+            pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
+            load_active(s, val);
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) val[c] = nval[c];
+            if (s + 1 < s_stop) load_active(s + 1, nval);
+        }
         place(val, v);
         const bool blank = FROM_BITS && s == 0;  // NULL symbol without TII: exact zeros
         if (!blank) F::template run<+1>(v, fbuf, tw, tt);
@@ -499,49 +603,41 @@ void tf_kernel(const TfArgs a)
         // position of this segment in the frame's output stream
         const size_t pos = GUARD ? (s == 0 ? 0 : (size_t)len0 + (size_t)(s - 1) * (size_t)len)
                                  : (size_t)s * (size_t)N;
-        if (!FIR) {
+        if (FIR) {
+            // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
+            cf *tail_new = bnd + (cur ^ 1) * kBnd, *tail_prev = bnd + cur * kBnd, *head = bnd + 2 * kBnd;
             if (lane_on) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int n = t + T * m;
-                    const cf y = GAIN ? cscale(v[m], g) : v[m];
-                    fout[pos + cpl + n] = y;
-                    if (n >= N - cpl) fout[pos + n - (N - cpl)] = y;
+                    const cf y = cscale(v[m], g);
+                    if (n >= N - C) tail_new[n - (N - C)] = y;                   // last C samples
+                    const int hn = n - (N - cpl);                               // head of the segment =
+                    if (hn >= 0 && hn < C) head[hn] = y;                         // start of the cyclic prefix
                 }
             }
-            continue;
-        }
-
-        // ---- FIR: boundary samples of the unfiltered, gain-scaled symbol ------
-        cf *tail_new = bnd + (cur ^ 1) * kBnd, *tail_prev = bnd + cur * kBnd, *head = bnd + 2 * kBnd;
-        if (lane_on) {
+            lds_barrier();
+            if (have_prev) boundary(tail_prev, head, false);
+            cur ^= 1;
+            // ---- second IFFT: carriers times the filter's frequency response ----------
+            if (!lookahead && !blank) {
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int n = t + T * m;
-                const cf y = cscale(v[m], g);
-                if (n >= N - C) tail_new[n - (N - C)] = y;                       // last C samples
-                const int hn = n - (N - cpl);                                   // head of the segment =
-                if (hn >= 0 && hn < C) head[hn] = y;                             // start of the cyclic prefix
+                for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
+                place(val, v);
+                F::template run<+1>(v, fbuf, tw, tt);
             }
         }
-        __syncthreads();
-        if (have_prev) boundary(tail_prev, head, false);
-        cur ^= 1;
-        if (lookahead) break;
-
-        // ---- second IFFT: carriers times the filter's frequency response ------
-        if (!blank) {
-#pragma unroll
-            for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
-            place(val, v);
-            F::template run<+1>(v, fbuf, tw, tt);
+        if (FROM_BITS) {
+            bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;   // waits for the prefetch only
+            bb ^= 1;
         }
+        if (lookahead) break;
         if (lane_on) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
-                const cf y = cscale(v[m], g);
-                if (n < N - C) fout[pos + cpl + n] = y;                 // the last C belong to `boundary`
+                const cf y = (GAIN || FIR) ? cscale(v[m], g) : v[m];
+                if (!FIR || n < N - C) fout[pos + cpl + n] = y;          // FIR: the last C belong to `boundary`
                 if (n >= N - cpl) fout[pos + n - (N - cpl)] = y;
             }
         }
@@ -552,7 +648,7 @@ void tf_kernel(const TfArgs a)
     if (FIR && s_end == nsym && have_prev) {
         // end of the frame: the look-ahead runs off the buffer, missing terms are
         // dropped (reference src/FIRFilter.cpp:186-191)
-        __syncthreads();
+        lds_barrier();
         boundary(bnd + cur * kBnd, bnd + 2 * kBnd, true);
     }
 }
@@ -586,6 +682,8 @@ size_t tf_lds_bytes(int logN, unsigned flags)
     const size_t N = (size_t)1 << logN;
     size_t b = (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
     if (flags & TF_FIR) b += 3 * 128 * sizeof(float2);  // tail[2], head
+    if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
+    b += (kMaxTaps + 160) * sizeof(float);  // taps + |y_s| table
     return b;
 }
 
@@ -781,7 +879,7 @@ void fir_kernel(const cf *__restrict__ in, size_t frame_samples, const float *__
         const size_t p = base + (size_t)i;
         sb[i] = p < frame_samples ? fin[p] : mk(0.f, 0.f);
     }
-    __syncthreads();
+    lds_barrier();
     cf acc[R];
     const int j0 = threadIdx.x * R;
     fir_block<NTP, R>(sb, j0, taps, acc);
