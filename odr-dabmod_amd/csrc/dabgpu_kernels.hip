@@ -338,6 +338,93 @@ template <int T> DEV float symbol_gain(const cf *v, const GainParams &gp, double
 }
 
 // ---------------------------------------------------------------------------
+// Wave-wide reductions on DPP (VALU data paths, no LDS traffic): two quad
+// permutes, two row rotations, then the four row results through SGPRs.
+template <int CTRL> DEV float dpp_mov(float x)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, x), CTRL,
+                                                                 0xF, 0xF, false));
+}
+DEV float lane_bcast(float x, int lane)
+{
+    return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
+}
+DEV float wave_sum_dpp(float x)
+{
+    x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
+    x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
+    x += dpp_mov<0x124>(x);   // row_ror:4
+    x += dpp_mov<0x128>(x);   // row_ror:8  -> every lane holds the sum of its row of 16
+    return (lane_bcast(x, 0) + lane_bcast(x, 16)) + (lane_bcast(x, 32) + lane_bcast(x, 48));
+}
+DEV float wave_max_dpp(float x)
+{
+    x = fmaxf(x, dpp_mov<0xB1>(x));
+    x = fmaxf(x, dpp_mov<0x4E>(x));
+    x = fmaxf(x, dpp_mov<0x124>(x));
+    x = fmaxf(x, dpp_mov<0x128>(x));
+    return fmaxf(fmaxf(lane_bcast(x, 0), lane_bcast(x, 16)), fmaxf(lane_bcast(x, 32), lane_bcast(x, 48)));
+}
+
+// Gain of one OFDM symbol inside the fused kernel.  One pass: the DC bin of every
+// symbol is zero by construction (reference src/OfdmGenerator.cpp:209-210), so the
+// time-domain mean is rounding noise and var = E[x^2] - mean^2 has no cancellation.
+// Per-lane partial sums in float64, wave reduction on DPP, waves combined through LDS.
+template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, double *redd, int t,
+                                              bool on)
+{
+    constexpr double invN = 1.0 / (8 * T);
+    constexpr int NW = (T + 63) / 64;
+    float *red = reinterpret_cast<float *>(redd);
+    if (gp.mode == 0) return 512.0f;
+    if (gp.mode == 1) {
+        float m = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) m = fmaxf(m, fmaxf(fabsf(v[i].x), fabsf(v[i].y)));
+        m = wave_max_dpp(on ? m : 0.f);
+        if (NW > 1) {
+            if ((t & 63) == 0) red[t >> 6] = m;
+            lds_barrier();
+            m = red[0];
+#pragma unroll
+            for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
+            lds_barrier();
+        }
+        return ((int)m != 0) ? 32767.0f / m : 1.0f;
+    }
+    double sr = 0., si = 0., qr = 0., qi = 0.;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const double xr = (double)v[i].x, xi = (double)v[i].y;
+        sr += xr; si += xi;
+        qr += xr * xr; qi += xi * xi;
+    }
+    float f0 = on ? (float)sr : 0.f, f1 = on ? (float)si : 0.f, f2 = on ? (float)qr : 0.f,
+          f3 = on ? (float)qi : 0.f;
+    f0 = wave_sum_dpp(f0); f1 = wave_sum_dpp(f1); f2 = wave_sum_dpp(f2); f3 = wave_sum_dpp(f3);
+    double d0 = f0, d1 = f1, d2 = f2, d3 = f3;
+    if (NW > 1) {
+        if ((t & 63) == 0) {
+            red[4 * (t >> 6)] = f0; red[4 * (t >> 6) + 1] = f1;
+            red[4 * (t >> 6) + 2] = f2; red[4 * (t >> 6) + 3] = f3;
+        }
+        lds_barrier();
+        d0 = d1 = d2 = d3 = 0.;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
+            d0 += (double)red[4 * w]; d1 += (double)red[4 * w + 1];
+            d2 += (double)red[4 * w + 2]; d3 += (double)red[4 * w + 3];
+        }
+        lds_barrier();
+    }
+    const double mr = d0 * invN, mi = d1 * invN;
+    const float vr = sqrtf((float)fmax(d2 * invN - mr * mr, 0.0)) * gp.var_variance,
+                vi = sqrtf((float)fmax(d3 * invN - mi * mi, 0.0)) * gp.var_variance;
+    if ((int)vr == 0) return 1.0f;
+    return 32767.0f / fmaxf(vr, vi);
+}
+
+// ---------------------------------------------------------------------------
 // FIR over the LDS stream buffer: lane computes R consecutive outputs starting
 // at j0; taps are wave-uniform (SGPR operands).  out[j] = sum_k taps[k]*sb[j+k]
 // accumulated in tap order (reference src/FIRFilter.cpp:168-184; fused
@@ -533,7 +620,7 @@ void tf_kernel(const TfArgs a)
         load_active(1, val);
         place(val, v);
         F::template run<+1>(v, fbuf, tw, tt);
-        g_null = symbol_gain<T>(v, a.gain, red, tt, lane_on);
+        g_null = symbol_gain_fused<T>(v, a.gain, red, tt, lane_on);
     }
 
     // With FIR the symbol after the chunk is transformed too (first IFFT only) to
@@ -561,8 +648,8 @@ void tf_kernel(const TfArgs a)
                     acc.y = fmaf(x.y, tp, acc.y);
                 }
             }
-            acc.x += __shfl_xor(acc.x, 1, 64); acc.y += __shfl_xor(acc.y, 1, 64);
-            acc.x += __shfl_xor(acc.x, 2, 64); acc.y += __shfl_xor(acc.y, 2, 64);
+            acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);   // the 4 lanes of an output
+            acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);   // are one DPP quad
             if (i < C && q == 0) fout[prev_pos + (size_t)(prev_seg - C + i)] = acc;
         }
     };
@@ -594,7 +681,7 @@ void tf_kernel(const TfArgs a)
 
         float g = 1.0f;
         if (GAIN) {
-            g = (s == 0) ? g_null : symbol_gain<T>(v, a.gain, red, tt, lane_on);
+            g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red, tt, lane_on);
             g = g * a.gain.constant;
         }
 
