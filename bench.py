@@ -80,7 +80,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(ALGO_BYTES))
-    ap.add_argument("--frames", type=int, default=2048, help="transmission frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=4096, help="transmission frames per step per GPU")
     ap.add_argument("--chunks", type=int, default=0, help="workgroups per frame (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")

@@ -112,6 +112,9 @@ template <int LOGN> struct Fft {
     // exchange need 2 address registers instead of 16.
     static constexpr int LDS_ELEMS = N + N / 8;
 
+    // One barrier per exchange: consecutive exchanges alternate between two LDS
+    // buffers, so the next scatter can never overtake a lane still gathering from
+    // the previous one (that lane is at most one barrier behind).
     template <int NS> static DEV void exchange(cf *v, cf *lds, int t)
     {
         if (NS < 64) {
@@ -133,7 +136,6 @@ template <int LOGN> struct Fft {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = rp[m * T];
         }
-        lds_barrier();
     }
 
     static DEV void load_twiddles(const cf *__restrict__ wtab, int t, cf *tw)
@@ -188,10 +190,11 @@ template <int LOGN> struct Fft {
     // conjugate twiddles when S < 0 (table holds exp(+2 pi i m/N))
     template <int S> static DEV cf twid(cf w) { return S > 0 ? w : mk(w.x, -w.y); }
 
-    template <int S> static DEV void run(cf *v, cf *lds, const cf *tw, int t)
+    template <int S> static DEV void run(cf *v, cf *lds2, int &par, const cf *tw, int t)
     {
+#define DABGPU_NEXT_BUF (lds2 + ((par ^= 1) ? LDS_ELEMS : 0))
         dft8<S>(v);
-        exchange<1>(v, lds, t);
+        exchange<1>(v, DABGPU_NEXT_BUF, t);
         int n = 0;
         cf w[7];
         if (NR8 >= 2) {
@@ -199,21 +202,21 @@ template <int LOGN> struct Fft {
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (NR8 > 2 || RF > 1) exchange<8>(v, lds, t);
+            if (NR8 > 2 || RF > 1) exchange<8>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
             stage_twiddles<S>(tw, n, w);
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (NR8 > 3 || RF > 1) exchange<64>(v, lds, t);
+            if (NR8 > 3 || RF > 1) exchange<64>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 4) {
             stage_twiddles<S>(tw, n, w);
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (RF > 1) exchange<512>(v, lds, t);
+            if (RF > 1) exchange<512>(v, DABGPU_NEXT_BUF, t);
         }
         if (RF == 4) {
 #pragma unroll
@@ -240,6 +243,7 @@ template <int LOGN> struct Fft {
                 v[b + 4] = csub(x0, x1);
             }
         }
+#undef DABGPU_NEXT_BUF
     }
 };
 
@@ -369,7 +373,8 @@ DEV float wave_max_dpp(float x)
 // Gain of one OFDM symbol inside the fused kernel.  One pass: the DC bin of every
 // symbol is zero by construction (reference src/OfdmGenerator.cpp:209-210), so the
 // time-domain mean is rounding noise and var = E[x^2] - mean^2 has no cancellation.
-// Per-lane partial sums in float64, wave reduction on DPP, waves combined through LDS.
+// Per-lane partial sums and the DPP wave reduction in fp32, waves combined in float64.
+// `redd` must alternate between two scratch areas from call to call (one barrier only).
 template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, double *redd, int t,
                                               bool on)
 {
@@ -388,19 +393,19 @@ template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, 
             m = red[0];
 #pragma unroll
             for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
-            lds_barrier();
         }
         return ((int)m != 0) ? 32767.0f / m : 1.0f;
     }
-    double sr = 0., si = 0., qr = 0., qi = 0.;
+    // per-lane partial sums of 8 samples in fp32: their rounding errors are independent
+    // across the 256 lanes and average out (~1e-8 on the total); the cross-lane tree is fp32
+    // too, the cross-wave combine and the variance formula are float64
+    float sr = 0.f, si = 0.f, qr = 0.f, qi = 0.f;
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-        const double xr = (double)v[i].x, xi = (double)v[i].y;
-        sr += xr; si += xi;
-        qr += xr * xr; qi += xi * xi;
+        sr += v[i].x; si += v[i].y;
+        qr = fmaf(v[i].x, v[i].x, qr); qi = fmaf(v[i].y, v[i].y, qi);
     }
-    float f0 = on ? (float)sr : 0.f, f1 = on ? (float)si : 0.f, f2 = on ? (float)qr : 0.f,
-          f3 = on ? (float)qi : 0.f;
+    float f0 = on ? sr : 0.f, f1 = on ? si : 0.f, f2 = on ? qr : 0.f, f3 = on ? qi : 0.f;
     f0 = wave_sum_dpp(f0); f1 = wave_sum_dpp(f1); f2 = wave_sum_dpp(f2); f3 = wave_sum_dpp(f3);
     double d0 = f0, d1 = f1, d2 = f2, d3 = f3;
     if (NW > 1) {
@@ -415,7 +420,6 @@ template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, 
             d0 += (double)red[4 * w]; d1 += (double)red[4 * w + 1];
             d2 += (double)red[4 * w + 2]; d3 += (double)red[4 * w + 3];
         }
-        lds_barrier();
     }
     const double mr = d0 * invN, mi = d1 * invN;
     const float vr = sqrtf((float)fmax(d2 * invN - mr * mr, 0.0)) * gp.var_variance,
@@ -490,8 +494,9 @@ void tf_kernel(const TfArgs a)
     const int tt = lane_on ? t : 0;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf *fbuf = reinterpret_cast<cf *>(smem);                        // N + N/8 complex
-    double *red = reinterpret_cast<double *>(fbuf + F::LDS_ELEMS);  // 16 doubles
+    cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
+    int fpar = 0;                                                       // which half the next exchange uses
+    double *red = reinterpret_cast<double *>(fbuf + 2 * F::LDS_ELEMS);  // 16 doubles
     cf *bnd = reinterpret_cast<cf *>(red + 16);                     // FIR: tail[2][kBnd], head[kBnd]
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 3 * kBnd : 0));
@@ -619,8 +624,8 @@ void tf_kernel(const TfArgs a)
         cf val[6], v[8];
         load_active(1, val);
         place(val, v);
-        F::template run<+1>(v, fbuf, tw, tt);
-        g_null = symbol_gain_fused<T>(v, a.gain, red, tt, lane_on);
+        F::template run<+1>(v, fbuf, fpar, tw, tt);
+        g_null = symbol_gain_fused<T>(v, a.gain, red + 8, tt, lane_on);
     }
 
     // With FIR the symbol after the chunk is transformed too (first IFFT only) to
@@ -677,11 +682,11 @@ void tf_kernel(const TfArgs a)
         }
         place(val, v);
         const bool blank = FROM_BITS && s == 0;  // NULL symbol without TII: exact zeros
-        if (!blank) F::template run<+1>(v, fbuf, tw, tt);
+        if (!blank) F::template run<+1>(v, fbuf, fpar, tw, tt);
 
         float g = 1.0f;
         if (GAIN) {
-            g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red, tt, lane_on);
+            g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
             g = g * a.gain.constant;
         }
 
@@ -711,7 +716,7 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
                 place(val, v);
-                F::template run<+1>(v, fbuf, tw, tt);
+                F::template run<+1>(v, fbuf, fpar, tw, tt);
             }
         }
         if (FROM_BITS) {
@@ -767,7 +772,7 @@ template <int LOGN> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipS
 size_t tf_lds_bytes(int logN, unsigned flags)
 {
     const size_t N = (size_t)1 << logN;
-    size_t b = (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
+    size_t b = 2 * (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
     if (flags & TF_FIR) b += 3 * 128 * sizeof(float2);  // tail[2], head
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float);  // taps + |y_s| table
@@ -1149,6 +1154,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);
+    int fpar = 0;
     const int t = threadIdx.x;
     const long h0 = (long)blockIdx.x * hops_per_run;
     const long h1 = min((long)a.nhops, h0 + hops_per_run);
@@ -1174,7 +1180,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
             const cf x = i < NIN ? a.halo[i] : a.in[i - NIN];
             v[m] = mk(x.x * win[m], x.y * win[m]);
         }
-        F::template run<-1>(v, fbuf, tw, t);
+        F::template run<-1>(v, fbuf, fpar, tw, t);
 #pragma unroll
         for (int m = 0; m < 8; ++m) Fk[m] = cscale(v[m], a.factor);
 
@@ -1198,7 +1204,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
                     v[m] = cmul(Fk[m], w);
                 }
             }
-            F::template run<+1>(v, fbuf, tw, t);
+            F::template run<+1>(v, fbuf, fpar, tw, t);
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
                 const cf o = cadd(tail[m * Q + p], v[m]);
@@ -1217,7 +1223,7 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
     // stream is long enough, never shorter than 12 hops per run.
     int hpr = (int)std::max<size_t>(12, (a.nhops + 2047) / 2048);
     const dim3 grid((unsigned)((a.nhops + hpr - 1) / hpr)), block(NIN / 8);
-    const size_t lds = (size_t)(NIN + NIN / 8) * sizeof(float2);
+    const size_t lds = 2 * (size_t)(NIN + NIN / 8) * sizeof(float2);
     switch (Q) {
         case 2: hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2>), grid, block, lds, s, a, hpr); break;
         case 4: hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4>), grid, block, lds, s, a, hpr); break;
