@@ -88,23 +88,15 @@ def main():
 
     import numpy as np
     import torch
-    import torch.distributed as dist
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    P = pkg()
+    streams = importlib.import_module("odr-dabmod_amd.streams")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
+    grp = streams.StreamGroup(backend="nccl")     # torch.distributed over RCCL when N > 1
+    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    P = pkg()
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
 
     def run_workload(workload, B, steps, warmup):
         md = P.Modulator(mode=1, device=local_rank, max_frames=B, chunks_per_frame=args.chunks)
@@ -121,7 +113,7 @@ def main():
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(stream):
             # synthetic hot-path input: uniform random bytes, resident in HBM
-            rs = np.random.RandomState(42 + rank)
+            rs = np.random.RandomState(grp.stream_seed(42))
             bits = np.frombuffer(rs.bytes(B * 28800), dtype=np.uint8).reshape(B, 28800)
             d_bits = torch.from_numpy(bits.copy()).to(dev)
             if from_bits:
@@ -145,23 +137,19 @@ def main():
             for _ in range(warmup):
                 step()
             stream.synchronize()
-            barrier()
-            torch.cuda.synchronize()
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
-            t0 = time.perf_counter()
-            e0.record(stream)
-            for _ in range(steps):
-                step()
-            e1.record(stream)
-            torch.cuda.synchronize()
-            barrier()
-            wall = time.perf_counter() - t0
+
+            def timed_steps():
+                # HIP events on the stream the kernels are launched on: per-launch kernel time
+                e0.record(stream)
+                for _ in range(steps):
+                    step()
+                e1.record(stream)
+
+            # barrier + synchronize | K steps | synchronize + barrier, MAX over ranks
+            wall = grp.timed(timed_steps, 1, torch.cuda.synchronize)
             ev_ms = e0.elapsed_time(e1)
-        if world > 1:
-            tt = torch.tensor([wall], dtype=torch.float64, device=dev)
-            dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-            wall = float(tt.item())
         md.close()
         del d_out, d_in, d_bits
         torch.cuda.empty_cache()
@@ -169,8 +157,7 @@ def main():
 
     B = args.frames
     wall, kern_ms = run_workload(args.workload, B, args.steps, args.warmup)
-    frames = world * B * args.steps
-    value = frames / wall
+    value = grp.job_frames_per_second(B, args.steps, wall)
     algo = ALGO_BYTES[args.workload]
     achieved = algo * B / (kern_ms * 1e-3) / 1e9  # GB/s per GPU, per-launch HIP-event time
 
@@ -228,8 +215,7 @@ def main():
             line["cpu_baseline"] = cpu_baseline(args.workload)
     if rank == 0:
         print(json.dumps(line), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    grp.close()
 
 
 if __name__ == "__main__":

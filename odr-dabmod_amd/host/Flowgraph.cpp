@@ -1,0 +1,70 @@
+#include "Flowgraph.h"
+
+#include <chrono>
+#include <cstdio>
+#include <sstream>
+
+int Node::process()
+{
+    std::vector<Buffer *> in, out;
+    for (auto &e : m_in) in.push_back(e->buffer().get());
+    for (auto &e : m_out) out.push_back(e->buffer().get());
+    const auto t0 = std::chrono::steady_clock::now();
+    const int ret = m_plugin->process(in, out);
+    m_time_us += std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count();
+
+    // metadata: through the plugin when it handles metadata, otherwise straight across
+    meta_vec_t all;
+    for (auto &e : m_in) {
+        for (auto &m : e->metadata()) all.push_back(m);
+        e->metadata().clear();
+    }
+    if (auto *mm = dynamic_cast<ModMetadata *>(m_plugin.get())) all = mm->process_metadata(all);
+    for (auto &e : m_out) e->metadata() = all;
+    return ret;
+}
+
+Flowgraph::~Flowgraph()
+{
+    if (m_show_time) std::fputs(processTimeReport().c_str(), stderr);
+}
+
+std::shared_ptr<Node> Flowgraph::nodeFor(const std::shared_ptr<ModPlugin> &p)
+{
+    for (auto &n : m_nodes)
+        if (n->plugin() == p) return n;
+    m_nodes.push_back(std::make_shared<Node>(p));
+    return m_nodes.back();
+}
+
+void Flowgraph::connect(std::shared_ptr<ModPlugin> input, std::shared_ptr<ModPlugin> output)
+{
+    auto src = nodeFor(input);
+    auto dst = nodeFor(output);
+    auto e = std::make_shared<Edge>(src, dst);
+    src->addOutputEdge(e);
+    dst->addInputEdge(e);
+    m_edges.push_back(e);
+}
+
+bool Flowgraph::run()
+{
+    for (auto &n : m_nodes)
+        if (n->process() == 0) return false;
+    return true;
+}
+
+std::string Flowgraph::processTimeReport() const
+{
+    double total = 0;
+    for (auto &n : m_nodes) total += n->processTimeUs();
+    std::ostringstream o;
+    o << "Process time:\n";
+    for (auto &n : m_nodes) {
+        char line[160];
+        std::snprintf(line, sizeof line, "  %30s: %10.0f us (%6.2f %%)\n", n->plugin()->name(),
+                      n->processTimeUs(), total > 0 ? 100.0 * n->processTimeUs() / total : 0.0);
+        o << line;
+    }
+    return o.str();
+}

@@ -1,0 +1,617 @@
+// GpuStages.cpp -- see GpuStages.h.  Everything numerical happens behind the
+// C-ABI of include/dabgpu.h; this file is argument plumbing, parameter parsing
+// and the reference's error conventions.
+#include "GpuStages.h"
+
+#include "../../include/dabgpu.h"
+
+#include <algorithm>
+#include <cctype>
+#include <cstring>
+#include <fstream>
+#include <iomanip>
+#include <sstream>
+#include <stdexcept>
+
+namespace dabgpu_host {
+
+Context::Context(int mode, int max_frames)
+{
+    dabgpu_config cfg{};
+    cfg.mode = mode;
+    cfg.device = 0;
+    cfg.max_frames = max_frames;
+    cfg.chunks_per_frame = 0;
+    if (const char *d = std::getenv("DABGPU_DEVICE")) cfg.device = std::atoi(d);
+    const int rc = dabgpu_create(&cfg, &m_ctx);
+    if (rc != DABGPU_OK)
+        throw std::runtime_error(std::string("dabgpu_create: ") + dabgpu_last_error(nullptr));
+}
+
+Context::~Context() { dabgpu_destroy(m_ctx); }
+
+void Context::check(int rc) const
+{
+    if (rc != DABGPU_OK) throw std::runtime_error(dabgpu_last_error(m_ctx));
+}
+
+int mode_from_carriers(size_t carriers)
+{
+    switch (carriers) {
+        case 1536: return 1;
+        case 384: return 2;
+        case 192: return 3;
+        case 768: return 4;
+    }
+    throw std::runtime_error("unsupported number of carriers: " + std::to_string(carriers));
+}
+
+int mode_from_spacing(size_t spacing)
+{
+    switch (spacing) {
+        case 2048: return 1;
+        case 512: return 2;
+        case 256: return 3;
+        case 1024: return 4;
+    }
+    throw std::runtime_error("unsupported carrier spacing: " + std::to_string(spacing));
+}
+
+namespace {
+// run a (ctx, in, in_bytes, out, cap, &n) entry point with the producer-sizes-its-output protocol
+template <typename Fn> int run_codec(const Context &c, Fn fn, Buffer *const in, Buffer *out, size_t out_bytes)
+{
+    out->setLength(out_bytes);
+    size_t n = 0;
+    c.check(fn(c.get(), in->getData(), in->getLength(), out->getData(), out->getLength(), &n));
+    out->setLength(n);
+    return static_cast<int>(n);
+}
+
+[[noreturn]] void not_exported(const std::string &parameter, const std::string &rc_name)
+{
+    throw ParameterError("Parameter '" + parameter + "' is not exported by controllable " + rc_name);
+}
+}  // namespace
+}  // namespace dabgpu_host
+
+using dabgpu_host::run_codec;
+
+// ---------------------------------------------------------------- QpskSymbolMapper
+QpskSymbolMapper::QpskSymbolMapper(size_t carriers, bool fixedPoint)
+    : m_ctx(dabgpu_host::mode_from_carriers(carriers))
+{
+    if (fixedPoint) throw std::runtime_error("QpskSymbolMapper: the fixed-point engine is not offloaded");
+}
+
+int QpskSymbolMapper::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    run_codec(m_ctx, dabgpu_qpsk_process, dataIn, dataOut, dataIn->getLength() * 4 * sizeof(complexf));
+    return 1;
+}
+
+// ---------------------------------------------------------------- FrequencyInterleaver
+FrequencyInterleaver::FrequencyInterleaver(size_t mode, bool fixedPoint) : m_ctx(static_cast<int>(mode))
+{
+    if (fixedPoint) throw std::runtime_error("FrequencyInterleaver: the fixed-point engine is not offloaded");
+}
+
+int FrequencyInterleaver::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    run_codec(m_ctx, dabgpu_freq_interleave_process, dataIn, dataOut, dataIn->getLength());
+    return 1;
+}
+
+// ---------------------------------------------------------------- PhaseReference
+PhaseReference::PhaseReference(unsigned int dabmode, bool fixedPoint) : m_ctx(static_cast<int>(dabmode))
+{
+    if (fixedPoint) throw std::runtime_error("PhaseReference: the fixed-point engine is not offloaded");
+}
+
+int PhaseReference::process(Buffer *dataOut)
+{
+    dabgpu_geometry g;
+    m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
+    dataOut->setLength(static_cast<size_t>(g.carriers) * sizeof(complexf));
+    size_t n = 0;
+    m_ctx.check(dabgpu_phase_reference_process(m_ctx.get(), dataOut->getData(), dataOut->getLength(), &n));
+    return 1;
+}
+
+// ---------------------------------------------------------------- DifferentialModulator
+DifferentialModulator::DifferentialModulator(size_t carriers, bool fixedPoint)
+    : m_ctx(dabgpu_host::mode_from_carriers(carriers))
+{
+    if (fixedPoint) throw std::runtime_error("DifferentialModulator: the fixed-point engine is not offloaded");
+}
+
+int DifferentialModulator::process(std::vector<Buffer *> dataIn, Buffer *dataOut)
+{
+    if (dataIn.size() != 2)
+        throw std::runtime_error("DifferentialModulator::process nb of input streams not 2!");
+    dataOut->setLength(dataIn[0]->getLength() + dataIn[1]->getLength());
+    size_t n = 0;
+    m_ctx.check(dabgpu_diff_mod_process(m_ctx.get(), dataIn[0]->getData(), dataIn[0]->getLength(),
+                                        dataIn[1]->getData(), dataIn[1]->getLength(),
+                                        dataOut->getData(), dataOut->getLength(), &n));
+    return static_cast<int>(dataOut->getLength());
+}
+
+// ---------------------------------------------------------------- NullSymbol / SignalMultiplexer
+NullSymbol::NullSymbol(size_t numCarriers, size_t typeSize) : m_bytes(numCarriers * typeSize) {}
+
+int NullSymbol::process(Buffer *dataOut)
+{
+    dataOut->setLength(m_bytes);
+    std::memset(dataOut->getData(), 0, m_bytes);
+    return static_cast<int>(m_bytes);
+}
+
+int SignalMultiplexer::process(std::vector<Buffer *> dataIn, Buffer *dataOut)
+{
+    if (dataIn.size() != 2 && dataIn.size() != 3)
+        throw std::runtime_error("SignalMultiplexer::process needs 2 or 3 inputs");
+    *dataOut = *dataIn[dataIn.size() == 3 ? 2 : 0];  // TII symbol when present, else NULL symbol
+    *dataOut += *dataIn[1];
+    return static_cast<int>(dataOut->getLength());
+}
+
+// ---------------------------------------------------------------- OfdmGenerator
+OfdmGeneratorCF32::OfdmGeneratorCF32(size_t nbSymbols, size_t nbCarriers, size_t spacing,
+                                     bool &enableCfr, float &, float &, bool inverse)
+    : RemoteControllable("ofdm"), m_ctx(dabgpu_host::mode_from_spacing(spacing)),
+      m_nbSymbols(nbSymbols), m_nbCarriers(nbCarriers), m_spacing(spacing), m_cfr(enableCfr)
+{
+    if (nbCarriers > spacing) throw std::runtime_error("OfdmGenerator nbCarriers > spacing!");
+    if (!inverse) throw std::runtime_error("OfdmGenerator: forward transform is not offloaded");
+    RC_ADD_PARAMETER(cfr, "Enable crest factor reduction");
+}
+
+int OfdmGeneratorCF32::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    if (m_cfr) throw std::runtime_error("OfdmGenerator: crest factor reduction is not offloaded yet");
+    return run_codec(m_ctx, dabgpu_ofdm_process, dataIn, dataOut, m_nbSymbols * m_spacing * sizeof(complexf)) /
+           static_cast<int>(sizeof(complexf));
+}
+
+void OfdmGeneratorCF32::set_parameter(const std::string &parameter, const std::string &value)
+{
+    if (parameter == "cfr") {
+        std::stringstream ss(value);
+        bool on = false;
+        ss >> on;
+        if (on) throw ParameterError("crest factor reduction is not offloaded yet");
+        m_cfr = false;
+    } else {
+        dabgpu_host::not_exported(parameter, get_rc_name());
+    }
+}
+
+const std::string OfdmGeneratorCF32::get_parameter(const std::string &parameter) const
+{
+    if (parameter == "cfr") return m_cfr ? "1" : "0";
+    dabgpu_host::not_exported(parameter, get_rc_name());
+}
+
+const json::map_t OfdmGeneratorCF32::get_all_values() const
+{
+    json::map_t m;
+    m["cfr"].v = m_cfr;
+    return m;
+}
+
+// ---------------------------------------------------------------- GainControl
+GainControl::GainControl(size_t framesize, GainMode &gainMode, float &digGain, float normalise,
+                         float &varVariance)
+    : RemoteControllable("gain"), m_ctx(dabgpu_host::mode_from_spacing(framesize)), m_frameSize(framesize),
+      m_digGain(digGain), m_normalise(normalise), m_var_variance_rc(varVariance), m_gainmode(gainMode)
+{
+    RC_ADD_PARAMETER(digital, "Digital Gain");
+    RC_ADD_PARAMETER(mode, "Gainmode (fix|max|var)");
+    RC_ADD_PARAMETER(var, "Variance setting for gainmode var (default: 4)");
+    start_pipeline_thread();
+}
+
+GainControl::~GainControl() { stop_pipeline_thread(); }
+
+int GainControl::internal_process(Buffer *const dataIn, Buffer *dataOut)
+{
+    int mode;
+    float dig, var;
+    {
+        std::lock_guard<std::mutex> lock(m_mutex);
+        mode = static_cast<int>(m_gainmode);
+        dig = m_digGain;
+        var = m_var_variance_rc;
+    }
+    m_ctx.check(dabgpu_set_gain(m_ctx.get(), mode, dig, m_normalise, var));
+    return run_codec(m_ctx, dabgpu_gain_process, dataIn, dataOut, dataIn->getLength()) /
+           static_cast<int>(sizeof(complexf));
+}
+
+void GainControl::set_parameter(const std::string &parameter, const std::string &value)
+{
+    std::stringstream ss(value);
+    ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
+    if (parameter == "digital") {
+        float f;
+        ss >> f;
+        std::lock_guard<std::mutex> lock(m_mutex);
+        m_digGain = f;
+    } else if (parameter == "mode") {
+        std::string m;
+        ss >> m;
+        std::transform(m.begin(), m.end(), m.begin(), [](char c) { return std::tolower(c); });
+        GainMode g;
+        if (m == "fix") g = GainMode::GAIN_FIX;
+        else if (m == "max") g = GainMode::GAIN_MAX;
+        else if (m == "var") g = GainMode::GAIN_VAR;
+        else throw ParameterError("Gainmode " + m + " unknown");
+        std::lock_guard<std::mutex> lock(m_mutex);
+        m_gainmode = g;
+    } else if (parameter == "var") {
+        float f = 0;
+        ss >> f;
+        std::lock_guard<std::mutex> lock(m_mutex);
+        m_var_variance_rc = f;
+    } else {
+        dabgpu_host::not_exported(parameter, get_rc_name());
+    }
+}
+
+const std::string GainControl::get_parameter(const std::string &parameter) const
+{
+    std::stringstream ss;
+    std::lock_guard<std::mutex> lock(m_mutex);
+    if (parameter == "digital") ss << std::fixed << m_digGain;
+    else if (parameter == "mode")
+        ss << (m_gainmode == GainMode::GAIN_FIX ? "fix" : m_gainmode == GainMode::GAIN_MAX ? "max" : "var");
+    else if (parameter == "var") ss << std::fixed << m_var_variance_rc;
+    else dabgpu_host::not_exported(parameter, get_rc_name());
+    return ss.str();
+}
+
+const json::map_t GainControl::get_all_values() const
+{
+    json::map_t m;
+    std::lock_guard<std::mutex> lock(m_mutex);
+    m["digital"].v = static_cast<double>(m_digGain);
+    m["mode"].v = std::string(m_gainmode == GainMode::GAIN_FIX ? "fix"
+                              : m_gainmode == GainMode::GAIN_MAX ? "max" : "var");
+    m["var"].v = static_cast<double>(m_var_variance_rc);
+    return m;
+}
+
+// ---------------------------------------------------------------- GuardIntervalInserter
+GuardIntervalInserter::GuardIntervalInserter(size_t nbSymbols, size_t spacing, size_t nullSize,
+                                             size_t symSize, size_t &windowOverlap, FFTEngine fftEngine)
+    : RemoteControllable("guardinterval"), m_ctx(dabgpu_host::mode_from_spacing(spacing)),
+      m_windowOverlap(windowOverlap)
+{
+    if (nullSize == 0) throw std::logic_error("NULL symbol must be present");
+    if (fftEngine != FFTEngine::FFTW) throw std::runtime_error("GuardIntervalInserter: only the float engine is offloaded");
+    dabgpu_geometry g;
+    m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
+    if ((size_t)g.nb_symbols != nbSymbols || (size_t)g.null_size != nullSize || (size_t)g.sym_size != symSize)
+        throw std::runtime_error("GuardIntervalInserter: geometry does not match the transmission mode");
+    RC_ADD_PARAMETER(windowlen, "Window length for OFDM windowng [0 to disable]");
+    m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), windowOverlap));
+}
+
+int GuardIntervalInserter::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    dabgpu_geometry g;
+    m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
+    return run_codec(m_ctx, dabgpu_guard_process, dataIn, dataOut, g.tf_samples * sizeof(complexf));
+}
+
+void GuardIntervalInserter::set_parameter(const std::string &parameter, const std::string &value)
+{
+    if (parameter != "windowlen") dabgpu_host::not_exported(parameter, get_rc_name());
+    std::stringstream ss(value);
+    ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
+    size_t w = 0;
+    ss >> w;
+    std::lock_guard<std::mutex> lock(m_mutex);
+    m_windowOverlap = w;
+    m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), w));
+}
+
+const std::string GuardIntervalInserter::get_parameter(const std::string &parameter) const
+{
+    if (parameter != "windowlen") dabgpu_host::not_exported(parameter, get_rc_name());
+    std::lock_guard<std::mutex> lock(m_mutex);
+    return std::to_string(m_windowOverlap);
+}
+
+const json::map_t GuardIntervalInserter::get_all_values() const
+{
+    json::map_t m;
+    std::lock_guard<std::mutex> lock(m_mutex);
+    m["windowlen"].v = static_cast<uint64_t>(m_windowOverlap);
+    return m;
+}
+
+// ---------------------------------------------------------------- FIRFilter
+FIRFilter::FIRFilter(std::string &taps_file)
+    : RemoteControllable("firfilter"), m_ctx(1), m_taps_file(taps_file)
+{
+    RC_ADD_PARAMETER(ntaps, "(Read-only) number of filter taps.");
+    RC_ADD_PARAMETER(tapsfile, "Filename containing filter taps. When written to, the new file gets automatically loaded.");
+    load_filter_taps(m_taps_file);
+    start_pipeline_thread();
+}
+
+FIRFilter::~FIRFilter() { stop_pipeline_thread(); }
+
+// taps file: number of taps, then one tap per line (reference src/FIRFilter.cpp:103-133)
+void FIRFilter::load_filter_taps(const std::string &tapsFile)
+{
+    std::vector<float> taps;
+    if (tapsFile == "default") {
+        m_ctx.check(dabgpu_set_fir_default_taps(m_ctx.get()));
+        std::lock_guard<std::mutex> lock(m_taps_mutex);
+        m_taps.assign(45, 0.f);
+        return;
+    }
+    std::ifstream f(tapsFile.c_str());
+    if (!f) throw std::runtime_error("FIRFilter: Could not open taps file " + tapsFile);
+    int n = 0;
+    f >> n;
+    if (n <= 0) throw std::runtime_error("FIRFilter: taps file has invalid format.");
+    taps.resize(n);
+    for (int i = 0; i < n; ++i) {
+        f >> taps[i];
+        if (f.eof())
+            throw std::runtime_error("FIRFilter: file " + tapsFile + " should contain " + std::to_string(n) +
+                                     " taps, but EOF reached after " + std::to_string(i) + " taps!");
+    }
+    m_ctx.check(dabgpu_set_fir_taps(m_ctx.get(), taps.data(), taps.size()));
+    std::lock_guard<std::mutex> lock(m_taps_mutex);
+    m_taps = taps;
+}
+
+int FIRFilter::internal_process(Buffer *const dataIn, Buffer *dataOut)
+{
+    return run_codec(m_ctx, dabgpu_fir_process, dataIn, dataOut, dataIn->getLength());
+}
+
+void FIRFilter::set_parameter(const std::string &parameter, const std::string &value)
+{
+    if (parameter == "ntaps") throw ParameterError("Parameter 'ntaps' is read-only");
+    if (parameter != "tapsfile") dabgpu_host::not_exported(parameter, get_rc_name());
+    try {
+        load_filter_taps(value);
+        m_taps_file = value;
+    } catch (const std::runtime_error &e) {
+        throw ParameterError(e.what());
+    }
+}
+
+const std::string FIRFilter::get_parameter(const std::string &parameter) const
+{
+    std::lock_guard<std::mutex> lock(m_taps_mutex);
+    if (parameter == "ntaps") return std::to_string(m_taps.size());
+    if (parameter == "tapsfile") return m_taps_file;
+    dabgpu_host::not_exported(parameter, get_rc_name());
+}
+
+const json::map_t FIRFilter::get_all_values() const
+{
+    json::map_t m;
+    std::lock_guard<std::mutex> lock(m_taps_mutex);
+    m["ntaps"].v = static_cast<uint64_t>(m_taps.size());
+    m["tapsfile"].v = m_taps_file;
+    return m;
+}
+
+// ---------------------------------------------------------------- Resampler
+Resampler::Resampler(size_t inputRate, size_t outputRate, size_t resolution)
+    : m_ctx(dabgpu_host::mode_from_spacing(resolution))
+{
+    size_t a = inputRate, b = outputRate;
+    while (b) { const size_t t = a % b; a = b; b = t; }
+    m_L = outputRate / a;
+    m_M = inputRate / a;
+    m_ctx.check(dabgpu_set_resampler(m_ctx.get(), inputRate, outputRate));
+}
+
+int Resampler::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    run_codec(m_ctx, dabgpu_resampler_process, dataIn, dataOut, dataIn->getLength() * m_L / m_M);
+    return 1;
+}
+
+// ---------------------------------------------------------------- MemlessPoly
+MemlessPoly::MemlessPoly(std::string &coefs_file, unsigned int)
+    : RemoteControllable("memlesspoly"), m_ctx(1), m_coefs_file(coefs_file)
+{
+    RC_ADD_PARAMETER(ncoefs, "(Read-only) number of coefficients.");
+    RC_ADD_PARAMETER(coefs, "Predistortion coefficients, same format as file.");
+    RC_ADD_PARAMETER(coeffile, "Filename containing coefficients. When set, the file gets loaded.");
+    std::ifstream f(m_coefs_file);
+    load_coefficients(f);
+    start_pipeline_thread();
+}
+
+MemlessPoly::~MemlessPoly() { stop_pipeline_thread(); }
+
+// coefficient stream: format 1 = "1, 5, 5 AM values, 5 PM values"; format 2 = "2, scalefactor,
+// 32 LUT values" (reference src/MemlessPoly.cpp:145-232)
+void MemlessPoly::load_coefficients(std::istream &in)
+{
+    if (!in) throw std::runtime_error("MemlessPoly: Could not open file with coefs!");
+    uint32_t fmt = 0;
+    in >> fmt;
+    if (fmt == 1) {
+        int n = 0;
+        in >> n;
+        if (n <= 0) throw std::runtime_error("MemlessPoly: coefs file has invalid format.");
+        if (n != 5)
+            throw std::runtime_error("MemlessPoly: invalid number of coefs: " + std::to_string(n) + " expected 5");
+        std::vector<float> am(5), pm(5);
+        for (int i = 0; i < 10; ++i) {
+            float a;
+            in >> a;
+            (i < 5 ? am[i] : pm[i - 5]) = a;
+            if (in.eof()) throw std::runtime_error("MemlessPoly: coefs file invalid !");
+        }
+        m_ctx.check(dabgpu_set_poly(m_ctx.get(), am.data(), pm.data()));
+        std::lock_guard<std::mutex> lock(m_coefs_mutex);
+        m_am = am; m_pm = pm; m_is_lut = false; m_valid = true;
+    } else if (fmt == 2) {
+        float scale = 0;
+        in >> scale;
+        std::vector<float> lut(32);
+        for (auto &v : lut) in >> v;
+        m_ctx.check(dabgpu_set_lut(m_ctx.get(), scale, lut.data()));
+        std::lock_guard<std::mutex> lock(m_coefs_mutex);
+        m_lut = lut; m_lut_scale = scale; m_is_lut = true; m_valid = true;
+    } else {
+        std::lock_guard<std::mutex> lock(m_coefs_mutex);
+        m_valid = false;
+    }
+}
+
+std::string MemlessPoly::serialise_coefficients() const
+{
+    std::stringstream ss;
+    std::lock_guard<std::mutex> lock(m_coefs_mutex);
+    if (!m_valid) return ss.str();
+    if (!m_is_lut) {
+        ss << 1 << std::endl << m_am.size() << std::endl;
+        for (float c : m_am) ss << c << std::endl;
+        for (float c : m_pm) ss << c << std::endl;
+    } else {
+        ss << 2 << std::endl << m_lut.size() << std::endl << m_lut_scale << std::endl;
+        for (float c : m_lut) ss << c << std::endl;
+    }
+    return ss.str();
+}
+
+int MemlessPoly::internal_process(Buffer *const dataIn, Buffer *dataOut)
+{
+    bool valid;
+    {
+        std::lock_guard<std::mutex> lock(m_coefs_mutex);
+        valid = m_valid;
+    }
+    if (!valid) {
+        // the reference passes the frame through when no valid settings are loaded
+        *dataOut = *dataIn;
+        return static_cast<int>(dataOut->getLength());
+    }
+    return run_codec(m_ctx, dabgpu_poly_process, dataIn, dataOut, dataIn->getLength());
+}
+
+void MemlessPoly::set_parameter(const std::string &parameter, const std::string &value)
+{
+    if (parameter == "ncoefs") throw ParameterError("Parameter 'ncoefs' is read-only");
+    if (parameter == "coefs") {
+        std::stringstream ss(value);
+        try {
+            load_coefficients(ss);
+            std::ofstream f(m_coefs_file);     // the reference writes RC-set coefficients back
+            f << serialise_coefficients();
+        } catch (const std::runtime_error &e) {
+            throw ParameterError(e.what());
+        }
+    } else if (parameter == "coeffile") {
+        try {
+            std::ifstream f(value);
+            load_coefficients(f);
+            m_coefs_file = value;
+        } catch (const std::runtime_error &e) {
+            throw ParameterError(e.what());
+        }
+    } else {
+        dabgpu_host::not_exported(parameter, get_rc_name());
+    }
+}
+
+const std::string MemlessPoly::get_parameter(const std::string &parameter) const
+{
+    if (parameter == "ncoefs") {
+        std::lock_guard<std::mutex> lock(m_coefs_mutex);
+        return std::to_string(m_is_lut ? m_lut.size() : m_am.size());
+    }
+    if (parameter == "coefs") return serialise_coefficients();
+    if (parameter == "coeffile") return m_coefs_file;
+    dabgpu_host::not_exported(parameter, get_rc_name());
+}
+
+const json::map_t MemlessPoly::get_all_values() const
+{
+    json::map_t m;
+    m["coeffile"].v = m_coefs_file;
+    m["coefs"].v = serialise_coefficients();
+    return m;
+}
+
+// ---------------------------------------------------------------- DabGpuChain
+DabGpuChain::DabGpuChain(const Settings &s) : m_ctx(static_cast<int>(s.dabMode), 1)
+{
+    dabgpu_geometry g;
+    m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
+    m_in_bytes = g.tf_input_bytes;
+    if (s.enableGain) {
+        m_mask |= DABGPU_STAGE_GAIN;
+        m_ctx.check(dabgpu_set_gain(m_ctx.get(), static_cast<int>(s.gainMode), s.digitalGain, s.normalise,
+                                    s.gainmodeVariance));
+    }
+    m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), s.ofdmWindowOverlap));
+    if (!s.filterTapsFilename.empty()) {
+        m_mask |= DABGPU_STAGE_FIR;
+        if (s.filterTapsFilename == "default") {
+            m_ctx.check(dabgpu_set_fir_default_taps(m_ctx.get()));
+        } else {
+            std::ifstream f(s.filterTapsFilename);
+            if (!f) throw std::runtime_error("FIRFilter: Could not open taps file " + s.filterTapsFilename);
+            int n = 0;
+            f >> n;
+            if (n <= 0) throw std::runtime_error("FIRFilter: taps file has invalid format.");
+            std::vector<float> taps(n);
+            for (auto &t : taps) f >> t;
+            m_ctx.check(dabgpu_set_fir_taps(m_ctx.get(), taps.data(), taps.size()));
+        }
+    }
+    if (s.outputRate != 2048000) {
+        m_mask |= DABGPU_STAGE_RESAMPLE;
+        m_ctx.check(dabgpu_set_resampler(m_ctx.get(), 2048000, s.outputRate));
+    }
+    if (!s.polyCoefFilename.empty()) {
+        m_mask |= DABGPU_STAGE_POLY;
+        std::ifstream f(s.polyCoefFilename);
+        if (!f) throw std::runtime_error("MemlessPoly: Could not open file with coefs!");
+        uint32_t fmt = 0;
+        f >> fmt;
+        if (fmt == 1) {
+            int n = 0;
+            f >> n;
+            if (n != 5) throw std::runtime_error("MemlessPoly: invalid number of coefs");
+            float am[5], pm[5];
+            for (float &v : am) f >> v;
+            for (float &v : pm) f >> v;
+            m_ctx.check(dabgpu_set_poly(m_ctx.get(), am, pm));
+        } else if (fmt == 2) {
+            float scale = 0, lut[32];
+            f >> scale;
+            for (float &v : lut) f >> v;
+            m_ctx.check(dabgpu_set_lut(m_ctx.get(), scale, lut));
+        } else {
+            throw std::runtime_error("MemlessPoly: coef file has unknown format");
+        }
+    }
+}
+
+int DabGpuChain::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    if (dataIn->getLength() != m_in_bytes)
+        throw std::runtime_error("DabGpuChain::process input size not valid!");
+    dataOut->setLength(dabgpu_chain_out_bytes_per_frame(m_ctx.get(), m_mask));
+    size_t n = 0;
+    m_ctx.check(dabgpu_chain_process(m_ctx.get(), static_cast<const uint8_t *>(dataIn->getData()), 1, m_mask,
+                                     dataOut->getData(), dataOut->getLength(), &n));
+    dataOut->setLength(n);
+    return static_cast<int>(n);
+}

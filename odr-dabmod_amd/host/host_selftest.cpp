@@ -1,0 +1,298 @@
+// host_selftest.cpp -- driver for the C++ host mirror.
+//
+//   host_selftest cpu
+//       plumbing semantics without a GPU: Buffer, arity assertions, the
+//       0-return convention, PipelinedModCodec latency and metadata delay.
+//   host_selftest gpu <mode> <bits.bin> <nframes> <graph_out.iq> <chain_out.iq> [normalise]
+//       builds the inner flowgraph the way src/DabModulator.cpp:385-419 wires it
+//       (cifMap -> cifFreq -> cifDiff(+cifRef) -> cifSig(+cifNull) -> cifOfdm ->
+//       cifGain -> cifGuard -> cifFilter -> output) from the drop-in stages, feeds
+//       <nframes> blocks of hot-path input, and writes what reaches the sink; then
+//       runs the same frames through the single DabGpuChain plugin.
+#include "Flowgraph.h"
+#include "GpuStages.h"
+
+#include <cstdio>
+#include <cstring>
+#include <fstream>
+#include <iostream>
+#include <memory>
+#include <stdexcept>
+
+namespace {
+
+int g_checks = 0;
+#define CHECK(cond)                                                                            \
+    do {                                                                                       \
+        ++g_checks;                                                                            \
+        if (!(cond)) {                                                                         \
+            std::fprintf(stderr, "CHECK FAILED %s:%d: %s\n", __FILE__, __LINE__, #cond);       \
+            std::exit(1);                                                                      \
+        }                                                                                      \
+    } while (0)
+
+// feeds successive blocks of a byte vector (the role of cifPart / InputMemory)
+class BlockSource : public ModInput {
+public:
+    BlockSource(std::vector<uint8_t> data, size_t block) : m_data(std::move(data)), m_block(block) {}
+    int process(Buffer *out) override
+    {
+        if (m_pos + m_block > m_data.size()) return 0;
+        out->setData(m_data.data() + m_pos, m_block);
+        m_pos += m_block;
+        return static_cast<int>(m_block);
+    }
+    const char *name() override { return "BlockSource"; }
+
+private:
+    std::vector<uint8_t> m_data;
+    size_t m_block, m_pos = 0;
+};
+
+// appends everything it receives to a file (the role of OutputMemory + OutputFile)
+class FileSink : public ModOutput {
+public:
+    explicit FileSink(const std::string &path) : m_f(path, std::ios::binary) {}
+    int process(Buffer *in) override
+    {
+        m_f.write(static_cast<const char *>(in->getData()), static_cast<std::streamsize>(in->getLength()));
+        ++frames;
+        return static_cast<int>(in->getLength());
+    }
+    const char *name() override { return "FileSink"; }
+    int frames = 0;
+
+private:
+    std::ofstream m_f;
+};
+
+class AddOne : public ModCodec {
+public:
+    int process(Buffer *const in, Buffer *out) override
+    {
+        out->setLength(in->getLength());
+        for (size_t i = 0; i < in->getLength(); ++i)
+            static_cast<uint8_t *>(out->getData())[i] = static_cast<uint8_t>((*in)[i] + 1);
+        return 1;
+    }
+    const char *name() override { return "AddOne"; }
+};
+
+class EveryOther : public ModCodec {  // returns 0 on odd calls, like BlockPartitioner in modes with >1 frame/TF
+public:
+    int process(Buffer *const in, Buffer *out) override
+    {
+        *out = *in;
+        return (m_n++ & 1) ? static_cast<int>(out->getLength()) : 0;
+    }
+    const char *name() override { return "EveryOther"; }
+
+private:
+    int m_n = 0;
+};
+
+class PipeDouble : public PipelinedModCodec {
+public:
+    PipeDouble() { start_pipeline_thread(); }
+    ~PipeDouble() override { stop_pipeline_thread(); }
+    const char *name() override { return "PipeDouble"; }
+
+protected:
+    int internal_process(Buffer *const in, Buffer *out) override
+    {
+        out->setLength(in->getLength());
+        for (size_t i = 0; i < in->getLength(); ++i)
+            static_cast<uint8_t *>(out->getData())[i] = static_cast<uint8_t>((*in)[i] * 2);
+        return 1;
+    }
+};
+
+class CountSink : public ModOutput {
+public:
+    int process(Buffer *in) override
+    {
+        ++frames;
+        last = in->getLength() ? (*in)[0] : -1;
+        return 1;
+    }
+    const char *name() override { return "CountSink"; }
+    int frames = 0, last = -1;
+};
+
+int run_cpu()
+{
+    // Buffer: alignment, growth keeps contents, shrink keeps the allocation
+    Buffer b(5, "abcde");
+    CHECK(b.getLength() == 5 && reinterpret_cast<uintptr_t>(b.getData()) % 32 == 0);
+    void *p0 = b.getData();
+    b.setLength(3);
+    CHECK(b.getData() == p0 && b.getLength() == 3);
+    b.setLength(4096);
+    CHECK(std::memcmp(b.getData(), "abc", 3) == 0 && reinterpret_cast<uintptr_t>(b.getData()) % 32 == 0);
+    Buffer c;
+    c = b;
+    c += Buffer(2, "xy");
+    CHECK(c.getLength() == 4098 && c[4096] == 'x');
+    Buffer d(std::move(c));
+    CHECK(c.getLength() == 0 && c.getData() == nullptr && d.getLength() == 4098);
+    bool threw = false;
+    try { (void)d[5000]; } catch (const std::out_of_range &) { threw = true; }
+    CHECK(threw);
+
+    // arity assertions throw std::runtime_error naming the plugin
+    AddOne a1;
+    Buffer x(1, "a"), y;
+    threw = false;
+    ModPlugin *as_plugin = &a1;
+    try { as_plugin->process({&x, &x}, {&y}); } catch (const std::runtime_error &e) {
+        threw = std::string(e.what()).find("AddOne") != std::string::npos;
+    }
+    CHECK(threw);
+
+    // flowgraph: a node returning 0 stops the walk for that round
+    {
+        auto src = std::make_shared<BlockSource>(std::vector<uint8_t>{1, 2, 3, 4}, 1);
+        auto eo = std::make_shared<EveryOther>();
+        auto add = std::make_shared<AddOne>();
+        auto sink = std::make_shared<CountSink>();
+        Flowgraph fg;
+        fg.connect(src, eo);
+        fg.connect(eo, add);
+        fg.connect(add, sink);
+        CHECK(fg.run() == false && sink->frames == 0);
+        CHECK(fg.run() == true && sink->frames == 1 && sink->last == 3);
+        CHECK(fg.run() == false);
+        CHECK(fg.run() == true && sink->frames == 2 && sink->last == 5);
+        CHECK(fg.run() == false);  // source exhausted
+    }
+    // pipelined stage: call i returns frame i-1, call 0 returns nothing, input buffer is stolen
+    {
+        PipeDouble pd;
+        Buffer in(1, "\x03"), out;
+        CHECK(pd.process(&in, &out) == 0 && in.getLength() == 0 && in.getData() == nullptr);
+        in.setData("\x05", 1);
+        CHECK(pd.process(&in, &out) == 1 && out[0] == 6);
+        in.setData("\x07", 1);
+        CHECK(pd.process(&in, &out) == 1 && out[0] == 10);
+        flowgraph_metadata m0, m1;
+        m0.ts.fct = 10;
+        m1.ts.fct = 11;
+        CHECK(pd.process_metadata({m0}).empty());
+        meta_vec_t r = pd.process_metadata({m1});
+        CHECK(r.size() == 1 && r[0].ts.fct == 10);
+    }
+    // pipelined stage inside a graph: N rounds in, N-1 frames out
+    {
+        auto src = std::make_shared<BlockSource>(std::vector<uint8_t>{1, 2, 3, 4, 5}, 1);
+        auto pd = std::make_shared<PipeDouble>();
+        auto sink = std::make_shared<CountSink>();
+        Flowgraph fg;
+        fg.connect(src, pd);
+        fg.connect(pd, sink);
+        int ok = 0;
+        for (int i = 0; i < 5; ++i) ok += fg.run() ? 1 : 0;
+        CHECK(ok == 4 && sink->frames == 4 && sink->last == 8);
+    }
+    std::printf("host_selftest cpu: OK (%d checks)\n", g_checks);
+    return 0;
+}
+
+std::vector<uint8_t> read_all(const std::string &path)
+{
+    std::ifstream f(path, std::ios::binary);
+    if (!f) throw std::runtime_error("cannot open " + path);
+    return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int run_gpu(int argc, char **argv)
+{
+    if (argc < 7) {
+        std::fprintf(stderr, "usage: host_selftest gpu <mode> <bits.bin> <nframes> <graph.iq> <chain.iq> [normalise]\n");
+        return 2;
+    }
+    const unsigned mode = static_cast<unsigned>(std::atoi(argv[2]));
+    const std::vector<uint8_t> bits = read_all(argv[3]);
+    const size_t nframes = static_cast<size_t>(std::atoi(argv[4]));
+    const float normalise = argc > 7 ? static_cast<float>(std::atof(argv[7])) : 1.0f / 50000.0f;
+    // geometry, as DabModulator::setMode (src/DabModulator.cpp:84-122)
+    size_t nbSymbols = 76, nbCarriers = 1536, spacing = 2048, nullSize = 2656, symSize = 2552;
+    if (mode == 2) { nbCarriers = 384; spacing = 512; nullSize = 664; symSize = 638; }
+    if (mode == 3) { nbSymbols = 153; nbCarriers = 192; spacing = 256; nullSize = 345; symSize = 319; }
+    if (mode == 4) { nbCarriers = 768; spacing = 1024; nullSize = 1328; symSize = 1276; }
+    const size_t block = (nbSymbols - 1) * nbCarriers / 4;
+    if (bits.size() < nframes * block) throw std::runtime_error("bits file too short");
+
+    // the settings the stages hold references into (mod_settings_t in the reference)
+    GainMode gainMode = GainMode::GAIN_VAR;
+    float digitalGain = 1.0f, gainmodeVariance = 4.0f, cfrClip = 1.0f, cfrErrorClip = 1.0f;
+    bool enableCfr = false;
+    size_t windowOverlap = 0;
+    std::string tapsFile = "default";
+
+    {
+        auto cifPart = std::make_shared<BlockSource>(bits, block);
+        auto cifMap = std::make_shared<QpskSymbolMapper>(nbCarriers, false);
+        auto cifRef = std::make_shared<PhaseReference>(mode, false);
+        auto cifFreq = std::make_shared<FrequencyInterleaver>(mode, false);
+        auto cifDiff = std::make_shared<DifferentialModulator>(nbCarriers, false);
+        auto cifNull = std::make_shared<NullSymbol>(nbCarriers, sizeof(complexf));
+        auto cifSig = std::make_shared<SignalMultiplexer>();
+        auto cifOfdm = std::make_shared<OfdmGeneratorCF32>(1 + nbSymbols, nbCarriers, spacing, enableCfr,
+                                                           cfrClip, cfrErrorClip);
+        auto cifGain = std::make_shared<GainControl>(spacing, gainMode, digitalGain, normalise, gainmodeVariance);
+        auto cifGuard = std::make_shared<GuardIntervalInserter>(nbSymbols, spacing, nullSize, symSize,
+                                                                windowOverlap, FFTEngine::FFTW);
+        auto cifFilter = std::make_shared<FIRFilter>(tapsFile);
+        auto output = std::make_shared<FileSink>(argv[5]);
+
+        Flowgraph fg(true);
+        fg.connect(cifPart, cifMap);
+        fg.connect(cifMap, cifFreq);
+        fg.connect(cifRef, cifDiff);
+        fg.connect(cifFreq, cifDiff);
+        fg.connect(cifNull, cifSig);
+        fg.connect(cifDiff, cifSig);
+        fg.connect(cifSig, cifOfdm);
+        fg.connect(cifOfdm, cifGain);
+        fg.connect(cifGain, cifGuard);
+        fg.connect(cifGuard, cifFilter);
+        fg.connect(cifFilter, output);
+        int rounds_ok = 0;
+        for (size_t i = 0; i < nframes; ++i) rounds_ok += fg.run() ? 1 : 0;
+        // remote control through the stage interface
+        cifGain->set_parameter("mode", "VAR");
+        if (cifGain->get_parameter("mode") != "var") throw std::runtime_error("RC mode round trip failed");
+        std::printf("stage graph: %zu rounds, %d reached the sink (%d frames written)\n", nframes, rounds_ok,
+                    output->frames);
+    }
+    {
+        DabGpuChain::Settings s;
+        s.dabMode = mode;
+        s.normalise = normalise;
+        s.filterTapsFilename = "default";
+        auto cifPart = std::make_shared<BlockSource>(bits, block);
+        auto chain = std::make_shared<DabGpuChain>(s);
+        auto output = std::make_shared<FileSink>(argv[6]);
+        Flowgraph fg;
+        fg.connect(cifPart, chain);
+        fg.connect(chain, output);
+        for (size_t i = 0; i < nframes; ++i) fg.run();
+        std::printf("chain plugin: %d frames written\n", output->frames);
+    }
+    return 0;
+}
+
+}  // namespace
+
+int main(int argc, char **argv)
+{
+    try {
+        if (argc >= 2 && std::string(argv[1]) == "cpu") return run_cpu();
+        if (argc >= 2 && std::string(argv[1]) == "gpu") return run_gpu(argc, argv);
+        std::fprintf(stderr, "usage: host_selftest cpu | gpu ...\n");
+        return 2;
+    } catch (const std::exception &e) {
+        std::fprintf(stderr, "host_selftest: %s\n", e.what());
+        return 1;
+    }
+}
