@@ -507,6 +507,12 @@ void tf_kernel(const TfArgs a)
     // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
     float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
     float *mag_l = taps_l + kMaxTaps;
+    cf *unit8 = reinterpret_cast<cf *>(mag_l + 160);   // exp(i p pi/4) with exact 0 / +-1 entries
+    if (t < 8) {
+        const float cx = (float)((int)((kCX >> (2u * t)) & 3u) - 1);
+        const float cy = (float)((int)((kCX >> (2u * ((t + 6u) & 7u))) & 3u) - 1);
+        unit8[t] = mk(cx, cy);
+    }
     for (int i = t; i < kMaxTaps; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
     if (FROM_BITS)
         for (int i = t; i < a.g.nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
@@ -590,10 +596,8 @@ void tf_kernel(const TfArgs a)
             const float mg = s >= 1 ? mag_l[s - 1] : 0.f;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                const unsigned p = phase[c];
-                const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
-                const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
-                val[c] = s >= 1 ? mk(cx * mg, cy * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
+                const cf u = unit8[phase[c]];
+                val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
             }
         } else {
             const cf *sym = fcar + (size_t)min(s, nsym - 1) * (size_t)K;
@@ -614,7 +618,7 @@ void tf_kernel(const TfArgs a)
         // "blocks 0 .. s_begin-3 applied"
         for (int d = 0; d + 3 <= s_begin; ++d) advance(fbits + (size_t)d * (size_t)(K / 4));
         // stage the block of the first symbol (block s_begin-2) into bitbuf[0]
-        bitbuf[bit_slot] = fetch_block(s_begin - 2);
+        bitbuf[bit_slot] = fetch_block(s_begin - 2);   // (clamped; unused when the loop starts at s <= 1)
     }
 
     // gain of the NULL symbol = gain computed on symbol 1 (reference
@@ -666,7 +670,24 @@ void tf_kernel(const TfArgs a)
     cf nval[6];                 // carriers path: the next symbol's active carriers
     if (!FROM_BITS) load_active(s_begin, nval);
 
-    for (int s = s_begin; s < s_stop; ++s) {
+    // Coded-bits path: the NULL symbol is blank (no TII), its segment is exact zeros and its
+    // tail is a zero tail.  Peeling it off makes the guard length a loop constant, so the
+    // lane predicates of the prefix copy and of the boundary samples hoist out of the loop.
+    int s_loop = s_begin;
+    if (FROM_BITS && s_begin == 0) {
+        const int nz = len0 - C;                      // the last C outputs belong to `boundary`
+        for (int i = t; i < nz; i += (int)blockDim.x) fout[i] = mk(0.f, 0.f);
+        if (FIR) {
+            for (int i = t; i < kBnd; i += (int)blockDim.x) bnd[cur * kBnd + i] = mk(0.f, 0.f);
+            have_prev = true;
+            prev_pos = 0;
+            prev_seg = len0;
+        }
+        // bring the staged block to the state the loop expects at s = 1 (block index -1: none)
+        s_loop = 1;
+    }
+
+    for (int s = s_loop; s < s_stop; ++s) {
         const bool lookahead = s >= s_end;      // FIR only: no output for this symbol
         cf val[6], v[8];
         uint32_t pf = 0u;
@@ -681,8 +702,7 @@ void tf_kernel(const TfArgs a)
             if (s + 1 < s_stop) load_active(s + 1, nval);
         }
         place(val, v);
-        const bool blank = FROM_BITS && s == 0;  // NULL symbol without TII: exact zeros
-        if (!blank) F::template run<+1>(v, fbuf, fpar, tw, tt);
+        F::template run<+1>(v, fbuf, fpar, tw, tt);
 
         float g = 1.0f;
         if (GAIN) {
@@ -690,7 +710,7 @@ void tf_kernel(const TfArgs a)
             g = g * a.gain.constant;
         }
 
-        const int cpl = (s == 0) ? cp0 : cp;
+        const int cpl = (!FROM_BITS && s == 0) ? cp0 : cp;
         const int seg = N + cpl;
         // position of this segment in the frame's output stream
         const size_t pos = GUARD ? (s == 0 ? 0 : (size_t)len0 + (size_t)(s - 1) * (size_t)len)
@@ -712,7 +732,7 @@ void tf_kernel(const TfArgs a)
             if (have_prev) boundary(tail_prev, head, false);
             cur ^= 1;
             // ---- second IFFT: carriers times the filter's frequency response ----------
-            if (!lookahead && !blank) {
+            if (!lookahead) {
 #pragma unroll
                 for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
                 place(val, v);
@@ -775,7 +795,7 @@ size_t tf_lds_bytes(int logN, unsigned flags)
     size_t b = 2 * (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
     if (flags & TF_FIR) b += 3 * 128 * sizeof(float2);  // tail[2], head
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
-    b += (kMaxTaps + 160) * sizeof(float);  // taps + |y_s| table
+    b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
     return b;
 }
 
