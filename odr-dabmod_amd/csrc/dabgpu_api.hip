@@ -406,7 +406,8 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
 
     const size_t native = (mask & DABGPU_STAGE_NOGUARD) ? per : tf_samples(c->g);
     const bool post = mask & (DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY);
-    const bool fir_fits = (int)c->cur.taps.size() - 1 <= c->g.sym_size - c->g.N;
+    const bool fir_fits = (int)c->cur.taps.size() - 1 <= c->g.sym_size - c->g.N &&
+                          (int)c->cur.taps.size() <= tf_max_fused_taps();
     const bool windowed = (c->cur.overlap > 0 || ((mask & DABGPU_STAGE_FIR) && !fir_fits)) &&
                           !(mask & DABGPU_STAGE_NOGUARD);
     if (windowed && c->cur.overlap > 0) {

@@ -57,6 +57,7 @@ enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8 };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags);
+int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
 
 // Stand-alone stage kernels (per-stage drop-ins and the non-fused fallbacks).
 hipError_t launch_qpsk(const uint8_t *in, size_t nbytes, int K, float2 *out, hipStream_t s);

@@ -27,10 +27,21 @@
 
 // build-time tuning knobs (tools/variants.sh sweeps them)
 #ifndef DABGPU_TF_WAVES
-#define DABGPU_TF_WAVES 2      // __launch_bounds__ waves per SIMD for tf_kernel (2 -> <=256 VGPRs, no spills)
+#define DABGPU_TF_WAVES 3      // __launch_bounds__ waves per SIMD for the FIR variants of tf_kernel (<= 168 VGPRs)
 #endif
 #ifndef DABGPU_FIR_SCHED
 #define DABGPU_FIR_SCHED 1
+#endif
+#ifndef DABGPU_TW8_LDS
+#define DABGPU_TW8_LDS 1       // 1: the stride-8 stage's twiddles (they depend on lane%8 only) are read from a
+#endif                         //    56-entry LDS table instead of living in 14 VGPRs
+#ifndef DABGPU_FFT_DBUF
+#define DABGPU_FFT_DBUF 0      // FIR variants: 1 = two LDS exchange buffers (one barrier per exchange), 0 = one buffer,
+                               // two barriers (36 KB of LDS per workgroup -> three workgroups per CU); the
+                               // variants without FIR always double-buffer
+#endif
+#ifndef DABGPU_HK_LDS
+#define DABGPU_HK_LDS 1        // 1: the lane's 6 filter-response values live in LDS (6 x T float2)
 #endif
 #ifndef DABGPU_TW_POWERS
 // twiddles resident in registers per FFT stage: 0 = all seven W^r; 1 = W, W^2, W^4 (the
@@ -115,7 +126,7 @@ template <int LOGN> struct Fft {
     // One barrier per exchange: consecutive exchanges alternate between two LDS
     // buffers, so the next scatter can never overtake a lane still gathering from
     // the previous one (that lane is at most one barrier behind).
-    template <int NS> static DEV void exchange(cf *v, cf *lds, int t)
+    template <int NS, bool DBUF> static DEV void exchange(cf *v, cf *lds, int t)
     {
         if (NS < 64) {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
@@ -126,6 +137,7 @@ template <int LOGN> struct Fft {
             const cf *rp = lds + (t + (t >> 3));
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = rp[m * (T + T / 8)];
+            if (!DBUF) lds_barrier();
         } else {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
             cf *wp = lds + j0;
@@ -135,10 +147,12 @@ template <int LOGN> struct Fft {
             const cf *rp = lds + t;
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = rp[m * T];
+            if (!DBUF) lds_barrier();
         }
     }
 
-    static DEV void load_twiddles(const cf *__restrict__ wtab, int t, cf *tw)
+    // SKIP8: the stride-8 stage reads its twiddles from the LDS table (fill_tw8) instead
+    template <bool SKIP8 = false> static DEV void load_twiddles(const cf *__restrict__ wtab, int t, cf *tw)
     {
         int n = 0;
         int ns = 8;
@@ -148,7 +162,10 @@ template <int LOGN> struct Fft {
 #pragma unroll
             for (int r = 1; r < 8; ++r) {
                 const bool keep = TWM == 0 || (TWM == 1 && (r == 1 || r == 2 || r == 4)) || (TWM == 2 && r == 1);
-                if (keep) tw[n++] = wtab[(r * base) & (N - 1)];
+                if (keep) {
+                    if (!(SKIP8 && TWM == 0 && st == 1)) tw[n] = wtab[(r * base) & (N - 1)];
+                    ++n;
+                }
             }
             ns *= 8;
         }
@@ -159,6 +176,12 @@ template <int LOGN> struct Fft {
                 for (int r = 1; r < RF; ++r)
                     if (TWM == 0 || r == 1) tw[n++] = wtab[(r * (t + T * b)) & (N - 1)];
         }
+    }
+
+    // DABGPU_TW8_LDS: fill the 7 x 8 table of the stride-8 stage (call once, then barrier)
+    static DEV void fill_tw8(const cf *__restrict__ wtab, cf *tw8, int t)
+    {
+        if (t < 56) tw8[t] = wtab[(((t >> 3) + 1) * (t & 7) * (N / 64)) & (N - 1)];
     }
 
     // the seven twiddles W^1..W^7 of a radix-8 stage from the resident subset
@@ -190,33 +213,40 @@ template <int LOGN> struct Fft {
     // conjugate twiddles when S < 0 (table holds exp(+2 pi i m/N))
     template <int S> static DEV cf twid(cf w) { return S > 0 ? w : mk(w.x, -w.y); }
 
-    template <int S> static DEV void run(cf *v, cf *lds2, int &par, const cf *tw, int t)
+    template <int S, bool DBUF = true> static DEV void run(cf *v, cf *lds2, int &par, const cf *tw, int t,
+                                                           const cf *tw8 = nullptr)
     {
-#define DABGPU_NEXT_BUF (lds2 + ((par ^= 1) ? LDS_ELEMS : 0))
+#define DABGPU_NEXT_BUF (lds2 + ((DBUF && (par ^= 1)) ? LDS_ELEMS : 0))
         dft8<S>(v);
-        exchange<1>(v, DABGPU_NEXT_BUF, t);
+        exchange<1, DBUF>(v, DABGPU_NEXT_BUF, t);
         int n = 0;
         cf w[7];
         if (NR8 >= 2) {
-            stage_twiddles<S>(tw, n, w);
+            if (DABGPU_TW8_LDS && TWM == 0 && tw8) {
+#pragma unroll
+                for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw8[r * 8 + (t & 7)]);
+                n += 7;
+            } else {
+                stage_twiddles<S>(tw, n, w);
+            }
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (NR8 > 2 || RF > 1) exchange<8>(v, DABGPU_NEXT_BUF, t);
+            if (NR8 > 2 || RF > 1) exchange<8, DBUF>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
             stage_twiddles<S>(tw, n, w);
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (NR8 > 3 || RF > 1) exchange<64>(v, DABGPU_NEXT_BUF, t);
+            if (NR8 > 3 || RF > 1) exchange<64, DBUF>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 4) {
             stage_twiddles<S>(tw, n, w);
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (RF > 1) exchange<512>(v, DABGPU_NEXT_BUF, t);
+            if (RF > 1) exchange<512, DBUF>(v, DABGPU_NEXT_BUF, t);
         }
         if (RF == 4) {
 #pragma unroll
@@ -470,7 +500,10 @@ template <int NTP, int R> DEV void fir_block(const cf *__restrict__ sb, int j0,
 // ---------------------------------------------------------------------------
 // cos/sin of p*45deg as {-1,0,+1} codes: (CX >> 2p) & 3 = value + 1
 constexpr unsigned kCX = 0x901Au;
-constexpr int kBnd = 128;  // LDS slots per boundary buffer (>= kMaxTaps - 1)
+#ifndef DABGPU_KBND
+#define DABGPU_KBND 128
+#endif
+constexpr int kBnd = DABGPU_KBND;  // LDS slots per boundary buffer; the fused FIR handles ntaps <= kBnd
 
 // FIR inside the fused kernel ("spectral FIR").
 // The stream is a chain of cyclically extended symbols, and the FIR looks AHEAD
@@ -484,11 +517,12 @@ constexpr int kBnd = 128;  // LDS slots per boundary buffer (>= kMaxTaps - 1)
 // 2 FFTs + C*ntaps MACs instead of 1 FFT + N*ntaps MACs.
 
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR>
-__global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8, DABGPU_TF_WAVES)
+__global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8, FIR ? DABGPU_TF_WAVES : 2)
 void tf_kernel(const TfArgs a)
 {
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
+    constexpr bool DBUF = !FIR || DABGPU_FFT_DBUF;   // exchange buffers: see DABGPU_FFT_DBUF
     const int t = threadIdx.x;
     const bool lane_on = t < T;  // only N=256 (T=32) runs with idle lanes
     const int tt = lane_on ? t : 0;
@@ -496,7 +530,7 @@ void tf_kernel(const TfArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
     int fpar = 0;                                                       // which half the next exchange uses
-    double *red = reinterpret_cast<double *>(fbuf + 2 * F::LDS_ELEMS);  // 16 doubles
+    double *red = reinterpret_cast<double *>(fbuf + (DBUF ? 2 : 1) * F::LDS_ELEMS);  // 16 doubles
     cf *bnd = reinterpret_cast<cf *>(red + 16);                     // FIR: tail[2][kBnd], head[kBnd]
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 3 * kBnd : 0));
@@ -508,6 +542,9 @@ void tf_kernel(const TfArgs a)
     float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
     float *mag_l = taps_l + kMaxTaps;
     cf *unit8 = reinterpret_cast<cf *>(mag_l + 160);   // exp(i p pi/4) with exact 0 / +-1 entries
+    cf *hk_l = unit8 + 8;                               // DABGPU_HK_LDS: [6][T] filter response per lane
+    cf *tw8_l = hk_l + ((FIR && DABGPU_HK_LDS) ? 6 * T : 0);   // DABGPU_TW8_LDS: 7 x 8 twiddles
+    if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
     if (t < 8) {
         const float cx = (float)((int)((kCX >> (2u * t)) & 3u) - 1);
         const float cy = (float)((int)((kCX >> (2u * ((t + 6u) & 7u))) & 3u) - 1);
@@ -531,7 +568,7 @@ void tf_kernel(const TfArgs a)
 
     // ---- per-lane constants ------------------------------------------------
     cf tw[F::NTW > 0 ? F::NTW : 1];
-    F::load_twiddles(a.t.twiddle, tt, tw);
+    F::template load_twiddles<DABGPU_TW8_LDS != 0>(a.t.twiddle, tt, tw);
 
     // the lane's 6 active first-stage inputs: r = {0|3,1,2,5,6,7}; bin = t + T*r
     // interleaved position k: bins 1..K/2 -> k = bin-1 ; bins N-K/2.. -> k = bin-N+K
@@ -545,6 +582,7 @@ void tf_kernel(const TfArgs a)
             const int bin = tt + T * rr[c];
             kpos[c] = (bin <= K / 2) ? bin - 1 : bin - N + K;
             if (FIR) hk[c] = a.t.fir_h[bin];
+            if (FIR && DABGPU_HK_LDS) hk_l[c * T + tt] = hk[c];
         }
     }
     int bitpos[6];
@@ -628,7 +666,7 @@ void tf_kernel(const TfArgs a)
         cf val[6], v[8];
         load_active(1, val);
         place(val, v);
-        F::template run<+1>(v, fbuf, fpar, tw, tt);
+        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr);
         g_null = symbol_gain_fused<T>(v, a.gain, red + 8, tt, lane_on);
     }
 
@@ -702,7 +740,7 @@ void tf_kernel(const TfArgs a)
             if (s + 1 < s_stop) load_active(s + 1, nval);
         }
         place(val, v);
-        F::template run<+1>(v, fbuf, fpar, tw, tt);
+        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr);
 
         float g = 1.0f;
         if (GAIN) {
@@ -719,13 +757,26 @@ void tf_kernel(const TfArgs a)
             // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
             cf *tail_new = bnd + (cur ^ 1) * kBnd, *tail_prev = bnd + cur * kBnd, *head = bnd + 2 * kBnd;
             if (lane_on) {
+                // The last C samples sit in the top register slot(s); the head of the segment (the
+                // first C samples of the cyclic prefix) in slot m_h0 and maybe the following ones.
+                // Slot tests are wave-uniform, only the lane tests are vector work.
+                const int m_h0 = (N - cpl) / T;
+                if (C <= T) {      // the usual case (45 taps, T = 256): one tail slot, at most two head slots
+                    if (t >= T - C) tail_new[t - (T - C)] = cscale(v[7], g);
 #pragma unroll
-                for (int m = 0; m < 8; ++m) {
-                    const int n = t + T * m;
-                    const cf y = cscale(v[m], g);
-                    if (n >= N - C) tail_new[n - (N - C)] = y;                   // last C samples
-                    const int hn = n - (N - cpl);                               // head of the segment =
-                    if (hn >= 0 && hn < C) head[hn] = y;                         // start of the cyclic prefix
+                    for (int m = 0; m < 8; ++m) {
+                        if (m == m_h0 || m == m_h0 + 1) {
+                            const int hn = t + T * m - (N - cpl);
+                            if (hn >= 0 && hn < C) head[hn] = cscale(v[m], g);
+                        }
+                    }
+                } else {           // short FFTs (T = 32, 64) or long filters
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int tn = t + T * m - (N - C), hn = t + T * m - (N - cpl);
+                        if (tn >= 0) tail_new[tn] = cscale(v[m], g);
+                        if (hn >= 0 && hn < C) head[hn] = cscale(v[m], g);
+                    }
                 }
             }
             lds_barrier();
@@ -733,10 +784,11 @@ void tf_kernel(const TfArgs a)
             cur ^= 1;
             // ---- second IFFT: carriers times the filter's frequency response ----------
             if (!lookahead) {
+                if (FROM_BITS) load_active(s, val);        // cheaper to rebuild than to keep 12 registers live
 #pragma unroll
-                for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
+                for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], DABGPU_HK_LDS ? hk_l[c * T + tt] : hk[c]);
                 place(val, v);
-                F::template run<+1>(v, fbuf, fpar, tw, tt);
+                F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr);
             }
         }
         if (FROM_BITS) {
@@ -745,12 +797,13 @@ void tf_kernel(const TfArgs a)
         }
         if (lookahead) break;
         if (lane_on) {
+            const int m_cp = (N - cpl) / T;   // first register slot that is also copied into the prefix
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
                 const cf y = (GAIN || FIR) ? cscale(v[m], g) : v[m];
-                if (!FIR || n < N - C) fout[pos + cpl + n] = y;          // FIR: the last C belong to `boundary`
-                if (n >= N - cpl) fout[pos + n - (N - cpl)] = y;
+                if (!FIR || n < N - C) fout[pos + cpl + n] = y;            // FIR: the last C belong to `boundary`
+                if (m > m_cp || (m == m_cp && n >= N - cpl)) fout[pos + n - (N - cpl)] = y;
             }
         }
         have_prev = true;
@@ -792,19 +845,29 @@ template <int LOGN> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipS
 size_t tf_lds_bytes(int logN, unsigned flags)
 {
     const size_t N = (size_t)1 << logN;
-    size_t b = 2 * (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
-    if (flags & TF_FIR) b += 3 * 128 * sizeof(float2);  // tail[2], head
+    const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
+    size_t b = (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
+    if (flags & TF_FIR) b += 3 * DABGPU_KBND * sizeof(float2);  // tail[2], head
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
+#if DABGPU_HK_LDS
+    if (flags & TF_FIR) b += 6 * (N / 8) * sizeof(float2);
+#endif
+#if DABGPU_TW8_LDS
+    b += 56 * sizeof(float2);
+#endif
     return b;
 }
+
+int tf_max_fused_taps() { return DABGPU_KBND < kMaxTaps ? DABGPU_KBND : kMaxTaps; }
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
 {
     if (flags & TF_FIR) {
         // the fused (spectral) FIR needs its look-ahead to fit in a cyclic prefix
         const int C = a.ntaps - 1;
-        if (a.ntaps < 1 || a.ntaps > kMaxTaps || C > a.g.sym_size - a.g.N) return hipErrorInvalidValue;
+        if (a.ntaps < 1 || a.ntaps > kMaxTaps || a.ntaps > DABGPU_KBND || C > a.g.sym_size - a.g.N)
+            return hipErrorInvalidValue;
     }
     switch (a.g.logN) {
         case 8: return launch_tf_n<8>(a, flags, s);
