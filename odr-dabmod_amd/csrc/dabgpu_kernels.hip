@@ -516,10 +516,20 @@ constexpr int kBnd = DABGPU_KBND;  // LDS slots per boundary buffer; the fused F
 // of the next one (unfiltered, gain applied), kept in LDS.  Cost per symbol:
 // 2 FFTs + C*ntaps MACs instead of 1 FFT + N*ntaps MACs.
 
-template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR>
+// The transmission-mode geometry is a function of the FFT size (reference
+// src/DabModulator.cpp:84-122), so it is compile-time here; NT is the number of FIR taps
+// when known at compile time (the default 45-tap filter) or 0 for "read it from the args".
+template <int LOGN> struct ModeGeom;
+template <> struct ModeGeom<11> { static constexpr int nb_symbols = 76, K = 1536, null_size = 2656, sym_size = 2552; };
+template <> struct ModeGeom<9> { static constexpr int nb_symbols = 76, K = 384, null_size = 664, sym_size = 638; };
+template <> struct ModeGeom<8> { static constexpr int nb_symbols = 153, K = 192, null_size = 345, sym_size = 319; };
+template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768, null_size = 1328, sym_size = 1276; };
+
+template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8, FIR ? DABGPU_TF_WAVES : 2)
 void tf_kernel(const TfArgs a)
 {
+    typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
     constexpr bool DBUF = !FIR || DABGPU_FFT_DBUF;   // exchange buffers: see DABGPU_FFT_DBUF
@@ -552,19 +562,20 @@ void tf_kernel(const TfArgs a)
     }
     for (int i = t; i < kMaxTaps; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
     if (FROM_BITS)
-        for (int i = t; i < a.g.nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
+        for (int i = t; i < G::nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
     lds_barrier();
 
-    const int K = a.g.K, nsym = a.g.nb_symbols + 1;
+    constexpr int K = G::K, nsym = G::nb_symbols + 1;
     const int frame = blockIdx.x / a.chunks_per_frame;
     const int chunk = blockIdx.x - frame * a.chunks_per_frame;
     const int s_begin = chunk * a.syms_per_chunk;
     const int s_end = min(nsym, s_begin + a.syms_per_chunk);
     if (frame >= a.n_frames || s_begin >= nsym) return;
 
-    const int C = FIR ? a.ntaps - 1 : 0;  // FIR look-ahead
-    const int cp0 = GUARD ? a.g.null_size - N : 0, cp = GUARD ? a.g.sym_size - N : 0;
-    const int len0 = N + cp0, len = N + cp;
+    const int ntaps = NT ? NT : a.ntaps;
+    const int C = FIR ? ntaps - 1 : 0;  // FIR look-ahead
+    constexpr int cp0 = GUARD ? G::null_size - N : 0, cp = GUARD ? G::sym_size - N : 0;
+    constexpr int len0 = N + cp0, len = N + cp;
 
     // ---- per-lane constants ------------------------------------------------
     cf tw[F::NTW > 0 ? F::NTW : 1];
@@ -589,7 +600,7 @@ void tf_kernel(const TfArgs a)
     unsigned phase[6];
     const uint8_t *fbits = nullptr;
     if (FROM_BITS) {
-        fbits = a.bits + (size_t)frame * (size_t)(a.g.nb_symbols - 1) * (size_t)(K / 4);
+        fbits = a.bits + (size_t)frame * (size_t)(G::nb_symbols - 1) * (size_t)(K / 4);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             bitpos[c] = a.t.src_carrier[kpos[c]];
@@ -623,7 +634,7 @@ void tf_kernel(const TfArgs a)
     // branch makes the compiler re-wait vmcnt(0) -- i.e. for the previous symbol's stores --
     // at the top of the next iteration.
     auto fetch_block = [&](int d) __attribute__((always_inline)) -> uint32_t {
-        const int dd = min(max(d, 0), a.g.nb_symbols - 2);
+        const int dd = min(max(d, 0), G::nb_symbols - 2);
         return reinterpret_cast<const uint32_t *>(fbits + (size_t)dd * (size_t)(K / 4))[t < kBitWords ? t : 0];
     };
     const int bit_slot = t < kBitWords ? t : kBitWords;   // kBitWords = dummy slot
@@ -685,7 +696,7 @@ void tf_kernel(const TfArgs a)
             const int i = i0 + (t >> 2), q = t & 3;
             cf acc = mk(0.f, 0.f);
             if (i < C) {
-                for (int j = q; j < a.ntaps; j += 4) {
+                for (int j = q; j < ntaps; j += 4) {
                     const int u = i + j;
                     cf x = mk(0.f, 0.f);
                     if (u < C) x = tail[u];
@@ -818,14 +829,18 @@ void tf_kernel(const TfArgs a)
     }
 }
 
-template <int LOGN> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)
+template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)
 {
     constexpr int T = (1 << LOGN) / 8;
+    typedef ModeGeom<LOGN> G;
+    if (a.g.K != G::K || a.g.nb_symbols != G::nb_symbols || a.g.null_size != G::null_size ||
+        a.g.sym_size != G::sym_size)
+        return hipErrorInvalidValue;
     const dim3 block(T < 64 ? 64 : T);
     const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
     const size_t lds = tf_lds_bytes(LOGN, flags);
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
-    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR>), grid, block, lds, s, a)
+    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
@@ -870,10 +885,13 @@ hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
             return hipErrorInvalidValue;
     }
     switch (a.g.logN) {
-        case 8: return launch_tf_n<8>(a, flags, s);
-        case 9: return launch_tf_n<9>(a, flags, s);
-        case 10: return launch_tf_n<10>(a, flags, s);
-        case 11: return launch_tf_n<11>(a, flags, s);
+        // Mode I with the default filter length gets the compile-time tap count
+        case 8: return launch_tf_n<8, 0>(a, flags, s);
+        case 9: return launch_tf_n<9, 0>(a, flags, s);
+        case 10: return launch_tf_n<10, 0>(a, flags, s);
+        case 11:
+            return ((flags & TF_FIR) && a.ntaps == 45) ? launch_tf_n<11, 45>(a, flags, s)
+                                                       : launch_tf_n<11, 0>(a, flags, s);
     }
     return hipErrorInvalidValue;
 }
