@@ -35,6 +35,9 @@
 #ifndef DABGPU_TW8_LDS
 #define DABGPU_TW8_LDS 1       // 1: the stride-8 stage's twiddles (they depend on lane%8 only) are read from a
 #endif                         //    56-entry LDS table instead of living in 14 VGPRs
+#ifndef DABGPU_TW64_LDS
+#define DABGPU_TW64_LDS 0      // 1: the stride-64 stage's twiddles (lane%64) from a 7 x 64 LDS table as well
+#endif
 #ifndef DABGPU_FFT_DBUF
 #define DABGPU_FFT_DBUF 0      // FIR variants: 1 = two LDS exchange buffers (one barrier per exchange), 0 = one buffer,
                                // two barriers (36 KB of LDS per workgroup -> three workgroups per CU); the
@@ -152,7 +155,8 @@ template <int LOGN> struct Fft {
     }
 
     // SKIP8: the stride-8 stage reads its twiddles from the LDS table (fill_tw8) instead
-    template <bool SKIP8 = false> static DEV void load_twiddles(const cf *__restrict__ wtab, int t, cf *tw)
+    template <bool SKIP8 = false, bool SKIP64 = false>
+    static DEV void load_twiddles(const cf *__restrict__ wtab, int t, cf *tw)
     {
         int n = 0;
         int ns = 8;
@@ -163,7 +167,8 @@ template <int LOGN> struct Fft {
             for (int r = 1; r < 8; ++r) {
                 const bool keep = TWM == 0 || (TWM == 1 && (r == 1 || r == 2 || r == 4)) || (TWM == 2 && r == 1);
                 if (keep) {
-                    if (!(SKIP8 && TWM == 0 && st == 1)) tw[n] = wtab[(r * base) & (N - 1)];
+                    if (!(SKIP8 && TWM == 0 && st == 1) && !(SKIP64 && TWM == 0 && st == 2))
+                        tw[n] = wtab[(r * base) & (N - 1)];
                     ++n;
                 }
             }
@@ -182,6 +187,12 @@ template <int LOGN> struct Fft {
     static DEV void fill_tw8(const cf *__restrict__ wtab, cf *tw8, int t)
     {
         if (t < 56) tw8[t] = wtab[(((t >> 3) + 1) * (t & 7) * (N / 64)) & (N - 1)];
+    }
+
+    // DABGPU_TW64_LDS: 7 x 64 table of the stride-64 stage
+    static DEV void fill_tw64(const cf *__restrict__ wtab, cf *tw64, int t, int nthreads)
+    {
+        for (int i = t; i < 448; i += nthreads) tw64[i] = wtab[(((i >> 6) + 1) * (i & 63) * (N / 512)) & (N - 1)];
     }
 
     // the seven twiddles W^1..W^7 of a radix-8 stage from the resident subset
@@ -214,7 +225,7 @@ template <int LOGN> struct Fft {
     template <int S> static DEV cf twid(cf w) { return S > 0 ? w : mk(w.x, -w.y); }
 
     template <int S, bool DBUF = true> static DEV void run(cf *v, cf *lds2, int &par, const cf *tw, int t,
-                                                           const cf *tw8 = nullptr)
+                                                           const cf *tw8 = nullptr, const cf *tw64 = nullptr)
     {
 #define DABGPU_NEXT_BUF (lds2 + ((DBUF && (par ^= 1)) ? LDS_ELEMS : 0))
         dft8<S>(v);
@@ -235,7 +246,13 @@ template <int LOGN> struct Fft {
             if (NR8 > 2 || RF > 1) exchange<8, DBUF>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
-            stage_twiddles<S>(tw, n, w);
+            if (DABGPU_TW64_LDS && TWM == 0 && tw64) {
+#pragma unroll
+                for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw64[r * 64 + (t & 63)]);
+                n += 7;
+            } else {
+                stage_twiddles<S>(tw, n, w);
+            }
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
@@ -555,6 +572,9 @@ void tf_kernel(const TfArgs a)
     cf *hk_l = unit8 + 8;                               // DABGPU_HK_LDS: [6][T] filter response per lane
     cf *tw8_l = hk_l + ((FIR && DABGPU_HK_LDS) ? 6 * T : 0);   // DABGPU_TW8_LDS: 7 x 8 twiddles
     if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
+    cf *tw64_l = tw8_l + 56;                            // DABGPU_TW64_LDS: 7 x 64 twiddles (FIR variants)
+    constexpr bool TW64 = DABGPU_TW64_LDS && FIR && F::NR8 >= 3;
+    if (TW64) F::fill_tw64(a.t.twiddle, tw64_l, t, (int)blockDim.x);
     if (t < 8) {
         const float cx = (float)((int)((kCX >> (2u * t)) & 3u) - 1);
         const float cy = (float)((int)((kCX >> (2u * ((t + 6u) & 7u))) & 3u) - 1);
@@ -579,7 +599,7 @@ void tf_kernel(const TfArgs a)
 
     // ---- per-lane constants ------------------------------------------------
     cf tw[F::NTW > 0 ? F::NTW : 1];
-    F::template load_twiddles<DABGPU_TW8_LDS != 0>(a.t.twiddle, tt, tw);
+    F::template load_twiddles<DABGPU_TW8_LDS != 0, DABGPU_TW64_LDS && FIR && F::NR8 >= 3>(a.t.twiddle, tt, tw);
 
     // the lane's 6 active first-stage inputs: r = {0|3,1,2,5,6,7}; bin = t + T*r
     // interleaved position k: bins 1..K/2 -> k = bin-1 ; bins N-K/2.. -> k = bin-N+K
@@ -677,7 +697,7 @@ void tf_kernel(const TfArgs a)
         cf val[6], v[8];
         load_active(1, val);
         place(val, v);
-        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr);
+        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
         g_null = symbol_gain_fused<T>(v, a.gain, red + 8, tt, lane_on);
     }
 
@@ -751,7 +771,7 @@ void tf_kernel(const TfArgs a)
             if (s + 1 < s_stop) load_active(s + 1, nval);
         }
         place(val, v);
-        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr);
+        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
 
         float g = 1.0f;
         if (GAIN) {
@@ -799,7 +819,7 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], DABGPU_HK_LDS ? hk_l[c * T + tt] : hk[c]);
                 place(val, v);
-                F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr);
+                F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
             }
         }
         if (FROM_BITS) {
@@ -870,6 +890,9 @@ size_t tf_lds_bytes(int logN, unsigned flags)
 #endif
 #if DABGPU_TW8_LDS
     b += 56 * sizeof(float2);
+#endif
+#if DABGPU_TW64_LDS
+    if (flags & TF_FIR) b += 448 * sizeof(float2);
 #endif
     return b;
 }
