@@ -342,7 +342,8 @@ int check_resampler(dabgpu_ctx *c)
 }
 
 // stream of `total` samples at d_in -> resampled at d_out (stateful)
-int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out, hipStream_t s)
+int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out, hipStream_t s,
+                  bool fuse_poly = false)
 {
     int rc = check_resampler(c);
     if (rc) return rc;
@@ -356,6 +357,7 @@ int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out
     a.tw_out = (const float2 *)c->d_rs_tw_out.p;
     a.in = d_in; a.halo = (const float2 *)c->d_rs_halo.p;
     a.out = d_out; a.nhops = nhops;
+    a.poly = fuse_poly ? (const float *)c->d_coef.p : nullptr;
     HIPCHK(c, launch_resampler(a, s));
     // new halo = last two hops of the concatenation [halo | in]
     float2 *halo = (float2 *)c->d_rs_halo.p;
@@ -469,18 +471,22 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     if (post) {
         const float2 *cur = native_out;
         size_t n = n_frames * native;
+        bool poly_done = false;
         if (mask & DABGPU_STAGE_RESAMPLE) {
+            // the polynomial predistorter is an epilogue of the resampler's store (LUT mode is not)
+            const bool fuse = (mask & DABGPU_STAGE_POLY) && !c->cur.poly_is_lut;
             float2 *dst = d_out;
-            if (mask & DABGPU_STAGE_POLY) {
+            if ((mask & DABGPU_STAGE_POLY) && !fuse) {
                 HIPCHK(c, c->d_b.reserve(n_frames * per * sizeof(float2)));
                 dst = (float2 *)c->d_b.p;
             }
-            rc = run_resampler(c, cur, n, dst, s);
+            rc = run_resampler(c, cur, n, dst, s, fuse);
             if (rc) return rc;
             cur = dst;
             n = n_frames * per;
+            poly_done = fuse;
         }
-        if (mask & DABGPU_STAGE_POLY) {
+        if ((mask & DABGPU_STAGE_POLY) && !poly_done) {
             rc = run_poly(c, cur, n, d_out, s);
             if (rc) return rc;
         }

@@ -89,6 +89,7 @@ struct ResamplerArgs {
     const float2 *in;       // nhops * nin/2 samples (one stream)
     const float2 *halo;     // nin samples: the two hops before `in` (zeros at stream start)
     float2 *out;            // nhops * nout/2
+    const float *poly;      // nullptr, or am[5] at [0..4] and pm[5] at [8..12]: MemlessPoly fused into the store
     size_t nhops;
 };
 hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s);

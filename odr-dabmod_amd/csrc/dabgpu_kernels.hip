@@ -1271,13 +1271,33 @@ namespace {
 // A workgroup walks a run of consecutive hops; the overlap-add tail (second
 // half of Y) never leaves registers: lane t produces q = t + T m in every hop,
 // m < 4 being the first half and m >= 4 the tail.
-template <int LOGNIN, int Q> __global__ __launch_bounds__((1 << LOGNIN) / 8)
+// MemlessPoly polynomial (reference src/MemlessPoly.cpp:237-276) on one sample; shared by the
+// stand-alone kernel and the resampler's fused epilogue.
+struct PolyCoef { float a0, a1, a2, a3, a4, p0, p1, p2, p3, p4; };
+DEV cf poly_apply(cf x, const PolyCoef &c)
+{
+    const float m = x.x * x.x + x.y * x.y;
+    const float a = c.a0 + m * (c.a1 + m * (c.a2 + m * (c.a3 + m * c.a4)));
+    const float p = -1.0f * (c.p0 + m * (c.p1 + m * (c.p2 + m * (c.p3 + m * c.p4))));
+    const float q = p * p;
+    const float cr = (1.0f - q * (-0.5f + q * (0.486666f + q * (-0.00138888f))));
+    const float ci = p * (1.0f + q * (0.166666f + q * (0.00833333f)));
+    const float sr = x.x * a, si = x.y * a;
+    return mk(sr * cr - si * ci, sr * ci + si * cr);
+}
+
+template <int LOGNIN, int Q, bool POLY> __global__ __launch_bounds__((1 << LOGNIN) / 8)
 void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 {
     typedef Fft<LOGNIN> F;
-    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q;
+    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q, NOUT = NIN * Q;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);
+    cf *nyq = fbuf + 2 * F::LDS_ELEMS;   // [2]: the Nyquist bin of the current hop, double buffered
+    cf *tw8_l = nyq + 2;                  // 7 x 8 twiddles of the stride-8 stage
+    // overlap-add tail: 4Q values per lane, kept in LDS ([slot][lane], conflict-free) so that
+    // the kernel stays inside 256 VGPRs
+    cf *tail = tw8_l + 56;
     int fpar = 0;
     const int t = threadIdx.x;
     const long h0 = (long)blockIdx.x * hops_per_run;
@@ -1285,55 +1305,101 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     if (h0 >= (long)a.nhops) return;
 
     cf tw[F::NTW];
-    F::load_twiddles(a.tw_in, t, tw);
+    F::template load_twiddles<true>(a.tw_in, t, tw);
+    F::fill_tw8(a.tw_in, tw8_l, t);
     float win[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) win[m] = a.window[t + T * m];
-
-    cf tail[4 * Q];
+    // per-branch twiddle of bin k = t + T m:  W_nout^{kappa p} = W_nout^{t p} * e^{2 pi i m p / (8Q)}
+    // (* (-i)^p for the negative-frequency half, kappa = k - NIN): one table value per branch
+    // and lane, the rest are compile-time rotations.
+    cf wp[Q];
 #pragma unroll
-    for (int i = 0; i < 4 * Q; ++i) tail[i] = mk(0.f, 0.f);
+    for (int p = 1; p < Q; ++p) wp[p] = a.tw_out[(t * p) & (NOUT - 1)];
+    PolyCoef pc{};
+    if (POLY) {
+        pc.a0 = a.poly[0]; pc.a1 = a.poly[1]; pc.a2 = a.poly[2]; pc.a3 = a.poly[3]; pc.a4 = a.poly[4];
+        pc.p0 = a.poly[8]; pc.p1 = a.poly[9]; pc.p2 = a.poly[10]; pc.p3 = a.poly[11]; pc.p4 = a.poly[12];
+    }
+
+#pragma unroll
+    for (int i = 0; i < 4 * Q; ++i) tail[i * T + t] = mk(0.f, 0.f);
+    lds_barrier();
 
     // S = [halo (2 hops) | in]; hop h uses S[(h+1)*HIN .. (h+3)*HIN)
-    for (long h = h0 - 1; h < h1; ++h) {
-        cf v[8], Fk[8];
+    auto fetch = [&](long h, cf *x) __attribute__((always_inline)) {
         const long base = (h + 1) * HIN;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const long i = base + t + T * m;
-            const cf x = i < NIN ? a.halo[i] : a.in[i - NIN];
-            v[m] = mk(x.x * win[m], x.y * win[m]);
+            x[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
         }
-        F::template run<-1>(v, fbuf, fpar, tw, t);
+    };
+    cf xn[8];
+    fetch(h0 - 1, xn);
+
+    for (long h = h0 - 1; h < h1; ++h) {
+        cf v[8], u[8], Fk[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) u[m] = mk(xn[m].x * win[m], xn[m].y * win[m]);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) v[m] = u[m];
+        F::template run<-1>(v, fbuf, fpar, tw, t, tw8_l);
 #pragma unroll
         for (int m = 0; m < 8; ++m) Fk[m] = cscale(v[m], a.factor);
+        const int slot = (int)(h & 1);
+        if (t == 0) nyq[slot] = Fk[HIN / T];     // bin HIN lives in lane 0
+        lds_barrier();
 
-        cf *dst = a.out + (size_t)(h < 0 ? 0 : h) * HOUT;
         const bool emit = h >= h0;
+        cf *dst = a.out + (size_t)(emit ? h : 0) * HOUT;
+        // branches are produced two at a time and stored as 16-byte pairs (p, p+1)
+        cf o[8];
+        {
+            // branch p = 0 needs no transform: IDFT(DFT(u)) = NIN u, plus the second copy of
+            // the Nyquist bin, F[NIN/2] e^{i pi q}
+            const cf ny = nyq[slot];
+            const float sgn = (t & 1) ? -1.0f : 1.0f;          // q = t + T m, T even
+            const float sc = (float)NIN * a.factor;
 #pragma unroll
-        for (int p = 0; p < Q; ++p) {
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const int k = t + T * m;
-                if (p == 0) {
-                    v[m] = (k == HIN) ? cadd(Fk[m], Fk[m]) : Fk[m];
-                } else {
-                    // signed frequency kappa: k (k < HIN) or k - NIN (k > HIN); modulo nout
-                    const int up = (k * p) & (NIN * Q - 1);
-                    const int dn = ((k - NIN) * p) & (NIN * Q - 1);
-                    cf w;
-                    if (k < HIN) w = a.tw_out[up];
-                    else if (k > HIN) w = a.tw_out[dn];
-                    else w = cadd(a.tw_out[up], a.tw_out[dn]);
-                    v[m] = cmul(Fk[m], w);
-                }
-            }
-            F::template run<+1>(v, fbuf, fpar, tw, t);
+            for (int m = 0; m < 8; ++m) u[m] = mk(fmaf(u[m].x, sc, sgn * ny.x), fmaf(u[m].y, sc, sgn * ny.y));
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                const cf o = cadd(tail[m * Q + p], v[m]);
-                tail[m * Q + p] = v[m + 4];
-                if (emit) dst[(size_t)Q * (t + T * m) + p] = o;
+                o[2 * m] = cadd(tail[(m * Q) * T + t], u[m]);
+                tail[(m * Q) * T + t] = u[m + 4];
+            }
+        }
+#pragma unroll
+        for (int p = 1; p < Q; ++p) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                // e^{2 pi i m p / (8Q)}, times e^{-2 pi i p / Q} above Nyquist: compile-time constants
+                const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (8 * Q)) / (double)(8 * Q)
+                                   - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
+                const cf rot = mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
+                // (Fk * wp) * rot, in this order: Fk changes every hop, so nothing here is
+                // loop-invariant and the 24 products cannot be hoisted into 48 long-lived VGPRs
+                cf y = cmul(cmul(Fk[m], wp[p]), rot);
+                if (m == HIN / T && t == 0)      // Nyquist bin: placed at +NIN/2 and -NIN/2 by the reference
+                    y = cscale(Fk[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
+                v[m] = y;
+            }
+            // next hop's input is requested before the last stores of this hop (vmcnt retires in order)
+            if (p == Q - 1 && h + 1 < h1) fetch(h + 1, xn);
+            F::template run<+1>(v, fbuf, fpar, tw, t, tw8_l);
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                o[2 * m + (p & 1)] = cadd(tail[(m * Q + p) * T + t], v[m]);
+                tail[(m * Q + p) * T + t] = v[m + 4];
+            }
+            if ((p & 1) && emit) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    cf a0 = o[2 * m], a1 = o[2 * m + 1];
+                    if (POLY) { a0 = poly_apply(a0, pc); a1 = poly_apply(a1, pc); }
+                    float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m) + (p - 1));
+                    *d4 = make_float4(a0.x, a0.y, a1.x, a1.y);
+                }
             }
         }
     }
@@ -1347,10 +1413,17 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
     // stream is long enough, never shorter than 12 hops per run.
     int hpr = (int)std::max<size_t>(12, (a.nhops + 2047) / 2048);
     const dim3 grid((unsigned)((a.nhops + hpr - 1) / hpr)), block(NIN / 8);
-    const size_t lds = 2 * (size_t)(NIN + NIN / 8) * sizeof(float2);
+    const size_t lds = (2 * (size_t)(NIN + NIN / 8) + 2 + 56 + (size_t)4 * (a.nout / a.nin) * (NIN / 8)) * sizeof(float2);
+    const bool poly = a.poly != nullptr;
     switch (Q) {
-        case 2: hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2>), grid, block, lds, s, a, hpr); break;
-        case 4: hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4>), grid, block, lds, s, a, hpr); break;
+        case 2:
+            if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, true>), grid, block, lds, s, a, hpr);
+            else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
+            break;
+        case 4:
+            if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
+            else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
+            break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
