@@ -35,6 +35,9 @@
 #ifndef DABGPU_TW8_LDS
 #define DABGPU_TW8_LDS 1       // 1: the stride-8 stage's twiddles (they depend on lane%8 only) are read from a
 #endif                         //    56-entry LDS table instead of living in 14 VGPRs
+#ifndef DABGPU_DUAL_FFT
+#define DABGPU_DUAL_FFT 1       // FIR variants: unfiltered and filtered IFFT of a symbol as ONE packed transform
+#endif
 #ifndef DABGPU_TW64_LDS
 #define DABGPU_TW64_LDS 0      // 1: the stride-64 stage's twiddles (lane%64) from a 7 x 64 LDS table as well
 #endif
@@ -44,7 +47,7 @@
                                // variants without FIR always double-buffer
 #endif
 #ifndef DABGPU_HK_LDS
-#define DABGPU_HK_LDS 1        // 1: the lane's 6 filter-response values live in LDS (6 x T float2)
+#define DABGPU_HK_LDS 0        // 1: the lane's 6 filter-response values live in LDS (6 x T float2) instead of 12 VGPRs
 #endif
 #ifndef DABGPU_TW_POWERS
 // twiddles resident in registers per FFT stage: 0 = all seven W^r; 1 = W, W^2, W^4 (the
@@ -73,13 +76,37 @@ DEV cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
 DEV cf cmul(cf a, cf b) { return mk(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)); }
 DEV cf cscale(cf a, float s) { return mk(a.x * s, a.y * s); }
 
+// Two transforms in lockstep: re = (re_a, re_b), im = (im_a, im_b).  Every complex
+// operation is then a pair of packed-fp32 instructions with no lane shuffling at all (a
+// multiplication by +-i is a register rename plus a sign modifier), which the interleaved
+// (re, im) layout cannot offer.  The fused kernel runs the unfiltered and the filtered IFFT
+// of a symbol this way.
+struct c2 {
+    float2 re, im;
+};
+DEV c2 cadd(c2 a, c2 b) { return c2{a.re + b.re, a.im + b.im}; }
+DEV c2 csub(c2 a, c2 b) { return c2{a.re - b.re, a.im - b.im}; }
+DEV c2 cmul(c2 a, cf w) { return c2{a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x}; }
+
 // multiply by (S * i)
 template <int S> DEV cf mul_i(cf a) { return S > 0 ? mk(-a.y, a.x) : mk(a.y, -a.x); }
+template <int S> DEV c2 mul_i(c2 a) { return S > 0 ? c2{-a.im, a.re} : c2{a.im, -a.re}; }
+// multiply by exp(S i pi/4) and by exp(S 3 i pi/4)
+template <int S> DEV cf rot1(cf b) { return mk(kSqrtHalf * (b.x - S * b.y), kSqrtHalf * (S * b.x + b.y)); }
+template <int S> DEV cf rot3(cf b) { return mk(kSqrtHalf * (-b.x - S * b.y), kSqrtHalf * (S * b.x - b.y)); }
+template <int S> DEV c2 rot1(c2 b)
+{
+    return c2{(b.re - (float)S * b.im) * kSqrtHalf, ((float)S * b.re + b.im) * kSqrtHalf};
+}
+template <int S> DEV c2 rot3(c2 b)
+{
+    return c2{(-b.re - (float)S * b.im) * kSqrtHalf, ((float)S * b.re - b.im) * kSqrtHalf};
+}
 
 // 4-point DFT, exp(S 2 pi i nk/4), natural order in place
-template <int S> DEV void dft4(cf &x0, cf &x1, cf &x2, cf &x3)
+template <int S, typename V> DEV void dft4(V &x0, V &x1, V &x2, V &x3)
 {
-    const cf s0 = cadd(x0, x2), s1 = csub(x0, x2), s2 = cadd(x1, x3), s3 = mul_i<S>(csub(x1, x3));
+    const V s0 = cadd(x0, x2), s1 = csub(x0, x2), s2 = cadd(x1, x3), s3 = mul_i<S>(csub(x1, x3));
     x0 = cadd(s0, s2);
     x2 = csub(s0, s2);
     x1 = cadd(s1, s3);
@@ -87,15 +114,15 @@ template <int S> DEV void dft4(cf &x0, cf &x1, cf &x2, cf &x3)
 }
 
 // 8-point DFT (decimation in frequency), natural order in place
-template <int S> DEV void dft8(cf *v)
+template <int S, typename V> DEV void dft8(V *v)
 {
-    cf a0 = cadd(v[0], v[4]), b0 = csub(v[0], v[4]);
-    cf a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
-    cf a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
-    cf a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
-    b1 = mk(kSqrtHalf * (b1.x - S * b1.y), kSqrtHalf * (S * b1.x + b1.y));
+    V a0 = cadd(v[0], v[4]), b0 = csub(v[0], v[4]);
+    V a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
+    V a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
+    V a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
+    b1 = rot1<S>(b1);
     b2 = mul_i<S>(b2);
-    b3 = mk(kSqrtHalf * (-b3.x - S * b3.y), kSqrtHalf * (S * b3.x - b3.y));
+    b3 = rot3<S>(b3);
     dft4<S>(a0, a1, a2, a3);
     dft4<S>(b0, b1, b2, b3);
     v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
@@ -129,25 +156,29 @@ template <int LOGN> struct Fft {
     // One barrier per exchange: consecutive exchanges alternate between two LDS
     // buffers, so the next scatter can never overtake a lane still gathering from
     // the previous one (that lane is at most one barrier behind).
-    template <int NS, bool DBUF> static DEV void exchange(cf *v, cf *lds, int t)
+    // 8-byte elements (cf): padded i + (i >> 3) for strides 1 and 8.  16-byte elements (c2,
+    // ds_*_b128): only the stride-1 scatter needs the padding (modelled: writes conflict-free,
+    // reads 2-way); strides 8 and 64 are conflict-free unpadded.
+    template <int NS, bool DBUF, typename V> static DEV void exchange(V *v, V *lds, int t)
     {
-        if (NS < 64) {
+        constexpr bool PAD = sizeof(V) == 8 ? (NS < 64) : (NS == 1);
+        if (PAD) {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
-            cf *wp = lds + (j0 + (j0 >> 3));
+            V *wp = lds + (j0 + (j0 >> 3));
 #pragma unroll
             for (int r = 0; r < 8; ++r) wp[r * NS + (r * NS) / 8] = v[r];
             lds_barrier();
-            const cf *rp = lds + (t + (t >> 3));
+            const V *rp = lds + (t + (t >> 3));
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = rp[m * (T + T / 8)];
             if (!DBUF) lds_barrier();
         } else {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
-            cf *wp = lds + j0;
+            V *wp = lds + j0;
 #pragma unroll
             for (int r = 0; r < 8; ++r) wp[r * NS] = v[r];
             lds_barrier();
-            const cf *rp = lds + t;
+            const V *rp = lds + t;
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = rp[m * T];
             if (!DBUF) lds_barrier();
@@ -224,12 +255,13 @@ template <int LOGN> struct Fft {
     // conjugate twiddles when S < 0 (table holds exp(+2 pi i m/N))
     template <int S> static DEV cf twid(cf w) { return S > 0 ? w : mk(w.x, -w.y); }
 
-    template <int S, bool DBUF = true> static DEV void run(cf *v, cf *lds2, int &par, const cf *tw, int t,
-                                                           const cf *tw8 = nullptr, const cf *tw64 = nullptr)
+    template <int S, bool DBUF = true, typename V = cf>
+    static DEV void run(V *v, V *lds2, int &par, const cf *tw, int t, const cf *tw8 = nullptr,
+                        const cf *tw64 = nullptr)
     {
 #define DABGPU_NEXT_BUF (lds2 + ((DBUF && (par ^= 1)) ? LDS_ELEMS : 0))
         dft8<S>(v);
-        exchange<1, DBUF>(v, DABGPU_NEXT_BUF, t);
+        exchange<1, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         int n = 0;
         cf w[7];
         if (NR8 >= 2) {
@@ -243,7 +275,7 @@ template <int LOGN> struct Fft {
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (NR8 > 2 || RF > 1) exchange<8, DBUF>(v, DABGPU_NEXT_BUF, t);
+            if (NR8 > 2 || RF > 1) exchange<8, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
             if (DABGPU_TW64_LDS && TWM == 0 && tw64) {
@@ -256,14 +288,14 @@ template <int LOGN> struct Fft {
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (NR8 > 3 || RF > 1) exchange<64, DBUF>(v, DABGPU_NEXT_BUF, t);
+            if (NR8 > 3 || RF > 1) exchange<64, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 4) {
             stage_twiddles<S>(tw, n, w);
 #pragma unroll
             for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
             dft8<S>(v);
-            if (RF > 1) exchange<512, DBUF>(v, DABGPU_NEXT_BUF, t);
+            if (RF > 1) exchange<512, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (RF == 4) {
 #pragma unroll
@@ -278,14 +310,14 @@ template <int LOGN> struct Fft {
                     w2 = cmul(w1, w1);
                     w3 = cmul(w2, w1);
                 }
-                cf x0 = v[b], x1 = cmul(v[b + 2], w1), x2 = cmul(v[b + 4], w2), x3 = cmul(v[b + 6], w3);
+                V x0 = v[b], x1 = cmul(v[b + 2], w1), x2 = cmul(v[b + 4], w2), x3 = cmul(v[b + 6], w3);
                 dft4<S>(x0, x1, x2, x3);
                 v[b] = x0; v[b + 2] = x1; v[b + 4] = x2; v[b + 6] = x3;
             }
         } else if (RF == 2) {
 #pragma unroll
             for (int b = 0; b < 4; ++b) {
-                const cf x0 = v[b], x1 = cmul(v[b + 4], twid<S>(tw[n++]));
+                const V x0 = v[b], x1 = cmul(v[b + 4], twid<S>(tw[n++]));
                 v[b] = cadd(x0, x1);
                 v[b + 4] = csub(x0, x1);
             }
@@ -557,7 +589,7 @@ void tf_kernel(const TfArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
     int fpar = 0;                                                       // which half the next exchange uses
-    double *red = reinterpret_cast<double *>(fbuf + (DBUF ? 2 : 1) * F::LDS_ELEMS);  // 16 doubles
+    double *red = reinterpret_cast<double *>(fbuf + ((FIR && DABGPU_DUAL_FFT) ? 2 : 1) * (DBUF ? 2 : 1) * F::LDS_ELEMS);  // 16 doubles
     cf *bnd = reinterpret_cast<cf *>(red + 16);                     // FIR: tail[2][kBnd], head[kBnd]
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 3 * kBnd : 0));
@@ -770,8 +802,29 @@ void tf_kernel(const TfArgs a)
             for (int c = 0; c < 6; ++c) val[c] = nval[c];
             if (s + 1 < s_stop) load_active(s + 1, nval);
         }
-        place(val, v);
-        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+        constexpr bool DUAL = FIR && DABGPU_DUAL_FFT;
+        cf z[8];                                  // DUAL: the filtered symbol
+        if (DUAL) {
+            // unfiltered and filtered transform of the symbol in lockstep (see struct c2)
+            cf valf[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) valf[c] = cmul(val[c], DABGPU_HK_LDS ? hk_l[c * T + tt] : hk[c]);
+            place(val, v);
+            place(valf, z);
+            c2 v2[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v2[r] = c2{make_float2(v[r].x, z[r].x), make_float2(v[r].y, z[r].y)};
+            F::template run<+1, DBUF, c2>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt,
+                                          DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                v[m] = mk(v2[m].re.x, v2[m].im.x);
+                z[m] = mk(v2[m].re.y, v2[m].im.y);
+            }
+        } else {
+            place(val, v);
+            F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+        }
 
         float g = 1.0f;
         if (GAIN) {
@@ -813,8 +866,11 @@ void tf_kernel(const TfArgs a)
             lds_barrier();
             if (have_prev) boundary(tail_prev, head, false);
             cur ^= 1;
-            // ---- second IFFT: carriers times the filter's frequency response ----------
-            if (!lookahead) {
+            if (DUAL) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = z[m];
+            } else if (!lookahead) {
+                // ---- second IFFT: carriers times the filter's frequency response ------
                 if (FROM_BITS) load_active(s, val);        // cheaper to rebuild than to keep 12 registers live
 #pragma unroll
                 for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], DABGPU_HK_LDS ? hk_l[c * T + tt] : hk[c]);
@@ -881,7 +937,8 @@ size_t tf_lds_bytes(int logN, unsigned flags)
 {
     const size_t N = (size_t)1 << logN;
     const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
-    size_t b = (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2) + 16 * sizeof(double);
+    const size_t elem = ((flags & TF_FIR) && DABGPU_DUAL_FFT) ? 2 * sizeof(float2) : sizeof(float2);
+    size_t b = (dbuf ? 2 : 1) * (N + N / 8) * elem + 16 * sizeof(double);
     if (flags & TF_FIR) b += 3 * DABGPU_KBND * sizeof(float2);  // tail[2], head
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
