@@ -486,20 +486,20 @@ template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, 
     }
     float f0 = on ? sr : 0.f, f1 = on ? si : 0.f, f2 = on ? qr : 0.f, f3 = on ? qi : 0.f;
     f0 = wave_sum_dpp(f0); f1 = wave_sum_dpp(f1); f2 = wave_sum_dpp(f2); f3 = wave_sum_dpp(f3);
-    double d0 = f0, d1 = f1, d2 = f2, d3 = f3;
     if (NW > 1) {
         if ((t & 63) == 0) {
             red[4 * (t >> 6)] = f0; red[4 * (t >> 6) + 1] = f1;
             red[4 * (t >> 6) + 2] = f2; red[4 * (t >> 6) + 3] = f3;
         }
         lds_barrier();
-        d0 = d1 = d2 = d3 = 0.;
+        f0 = f1 = f2 = f3 = 0.f;
 #pragma unroll
         for (int w = 0; w < NW; ++w) {
-            d0 += (double)red[4 * w]; d1 += (double)red[4 * w + 1];
-            d2 += (double)red[4 * w + 2]; d3 += (double)red[4 * w + 3];
+            f0 += red[4 * w]; f1 += red[4 * w + 1];
+            f2 += red[4 * w + 2]; f3 += red[4 * w + 3];
         }
     }
+    const double d0 = f0, d1 = f1, d2 = f2, d3 = f3;
     const double mr = d0 * invN, mi = d1 * invN;
     const float vr = sqrtf((float)fmax(d2 * invN - mr * mr, 0.0)) * gp.var_variance,
                 vi = sqrtf((float)fmax(d3 * invN - mi * mi, 0.0)) * gp.var_variance;
@@ -590,9 +590,11 @@ void tf_kernel(const TfArgs a)
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
     int fpar = 0;                                                       // which half the next exchange uses
     double *red = reinterpret_cast<double *>(fbuf + ((FIR && DABGPU_DUAL_FFT) ? 2 : 1) * (DBUF ? 2 : 1) * F::LDS_ELEMS);  // 16 doubles
-    cf *bnd = reinterpret_cast<cf *>(red + 16);                     // FIR: tail[2][kBnd], head[kBnd]
+    // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
+    // that the boundary outputs read in[i + j] without a tail/head case split
+    cf *bnd = reinterpret_cast<cf *>(red + 16);
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
-    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 3 * kBnd : 0));
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * kBnd : 0));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
     // small read-only tables copied to LDS once: read through global memory they compile to
@@ -742,21 +744,20 @@ void tf_kernel(const TfArgs a)
     bool have_prev = false;
 
     // boundary outputs of the previous segment: 4 lanes per output, shuffle-reduced
-    auto boundary = [&](const cf *tail, const cf *head, bool head_zero) __attribute__((always_inline)) {
-        const float *taps = taps_l;
+    auto boundary = [&](const cf *src) __attribute__((always_inline)) {
+        // src = [tail (C) | head (C)]; output i of the C boundary outputs = sum_j taps[j] src[i + j].
+        // Four lanes (one DPP quad) share an output, lane q taking taps q, q+4, ...
         for (int i0 = 0; i0 < C; i0 += (int)blockDim.x / 4) {
             const int i = i0 + (t >> 2), q = t & 3;
+            const int ii = i < C ? i : 0;
             cf acc = mk(0.f, 0.f);
-            if (i < C) {
-                for (int j = q; j < ntaps; j += 4) {
-                    const int u = i + j;
-                    cf x = mk(0.f, 0.f);
-                    if (u < C) x = tail[u];
-                    else if (!head_zero) x = head[u - C];
-                    const float tp = taps[j];
-                    acc.x = fmaf(x.x, tp, acc.x);
-                    acc.y = fmaf(x.y, tp, acc.y);
-                }
+            // (kept rolled on purpose: unrolling its 12 iterations pushes the kernel into spilling)
+#pragma unroll 1
+            for (int j = q; j < ntaps; j += 4) {
+                const cf x = src[ii + j];
+                const float tp = taps_l[j];
+                acc.x = fmaf(x.x, tp, acc.x);
+                acc.y = fmaf(x.y, tp, acc.y);
             }
             acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);   // the 4 lanes of an output
             acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);   // are one DPP quad
@@ -779,7 +780,7 @@ void tf_kernel(const TfArgs a)
         const int nz = len0 - C;                      // the last C outputs belong to `boundary`
         for (int i = t; i < nz; i += (int)blockDim.x) fout[i] = mk(0.f, 0.f);
         if (FIR) {
-            for (int i = t; i < kBnd; i += (int)blockDim.x) bnd[cur * kBnd + i] = mk(0.f, 0.f);
+            for (int i = t; i < kBnd; i += (int)blockDim.x) bnd[cur * 2 * kBnd + i] = mk(0.f, 0.f);
             have_prev = true;
             prev_pos = 0;
             prev_seg = len0;
@@ -839,7 +840,7 @@ void tf_kernel(const TfArgs a)
                                  : (size_t)s * (size_t)N;
         if (FIR) {
             // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
-            cf *tail_new = bnd + (cur ^ 1) * kBnd, *tail_prev = bnd + cur * kBnd, *head = bnd + 2 * kBnd;
+            cf *tail_new = bnd + (cur ^ 1) * 2 * kBnd, *tail_prev = bnd + cur * 2 * kBnd, *head = tail_prev + C;
             if (lane_on) {
                 // The last C samples sit in the top register slot(s); the head of the segment (the
                 // first C samples of the cyclic prefix) in slot m_h0 and maybe the following ones.
@@ -864,7 +865,7 @@ void tf_kernel(const TfArgs a)
                 }
             }
             lds_barrier();
-            if (have_prev) boundary(tail_prev, head, false);
+            if (have_prev) boundary(tail_prev);
             cur ^= 1;
             if (DUAL) {
 #pragma unroll
@@ -901,7 +902,9 @@ void tf_kernel(const TfArgs a)
         // end of the frame: the look-ahead runs off the buffer, missing terms are
         // dropped (reference src/FIRFilter.cpp:186-191)
         lds_barrier();
-        boundary(bnd + cur * kBnd, bnd + 2 * kBnd, true);
+        for (int i = t; i < C; i += (int)blockDim.x) bnd[cur * 2 * kBnd + C + i] = mk(0.f, 0.f);   // zero head
+        lds_barrier();
+        boundary(bnd + cur * 2 * kBnd);
     }
 }
 
@@ -939,7 +942,7 @@ size_t tf_lds_bytes(int logN, unsigned flags)
     const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
     const size_t elem = ((flags & TF_FIR) && DABGPU_DUAL_FFT) ? 2 * sizeof(float2) : sizeof(float2);
     size_t b = (dbuf ? 2 : 1) * (N + N / 8) * elem + 16 * sizeof(double);
-    if (flags & TF_FIR) b += 3 * DABGPU_KBND * sizeof(float2);  // tail[2], head
+    if (flags & TF_FIR) b += 4 * DABGPU_KBND * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
 #if DABGPU_HK_LDS
