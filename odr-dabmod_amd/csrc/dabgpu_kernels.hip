@@ -592,7 +592,9 @@ void tf_kernel(const TfArgs a)
     double *red = reinterpret_cast<double *>(fbuf + ((FIR && DABGPU_DUAL_FFT) ? 2 : 1) * (DBUF ? 2 : 1) * F::LDS_ELEMS);  // 16 doubles
     // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
     // that the boundary outputs read in[i + j] without a tail/head case split
-    cf *bnd = reinterpret_cast<cf *>(red + 16);
+    // frequency-domain gain statistics (coded-bits path): one packed word of phases per lane
+    uint32_t *phw = reinterpret_cast<uint32_t *>(red + 16);          // [T]
+    cf *bnd = reinterpret_cast<cf *>(phw + (GAIN && FROM_BITS ? T : 0));
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * kBnd : 0));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
@@ -798,6 +800,24 @@ void tf_kernel(const TfArgs a)
             if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
             pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
             load_active(s, val);
+            if (GAIN && a.gain.mode == 2) {
+                // Gain statistics without touching the time domain.  With every carrier on the
+                // unit circle (times |y_s|) and a zero DC bin:
+                //   var(re) = |X|^2 (K/2 + S),  var(im) = |X|^2 (K/2 - S),
+                //   S = sum over carrier pairs {k, -k} of cos(pi/4 (p_k + p_-k)),
+                // because sum_n x[n]^2 = N sum_k X[k] X[-k].  Carrier -k of the lane's three positive
+                // carriers lives in lane T - t (lane 0 pairs with itself): exchange one packed word.
+                const unsigned w = (tt == 0) ? (phase[3] | (phase[5] << 3) | (phase[4] << 6))
+                                             : (phase[5] | (phase[4] << 3) | (phase[3] << 6));
+                phw[tt] = w;
+                lds_barrier();
+                const unsigned o = phw[(T - tt) & (T - 1)];
+                float part = unit8[(phase[0] + (o & 7u)) & 7u].x + unit8[(phase[1] + ((o >> 3) & 7u)) & 7u].x +
+                             unit8[(phase[2] + ((o >> 6) & 7u)) & 7u].x;
+                part = wave_sum_dpp(lane_on ? part : 0.f);
+                float *redf = reinterpret_cast<float *>(red + 8 * (s & 1));
+                if ((t & 63) == 0) redf[t >> 6] = part;      // combined after the transform's barriers
+            }
         } else {
 #pragma unroll
             for (int c = 0; c < 6; ++c) val[c] = nval[c];
@@ -829,7 +849,21 @@ void tf_kernel(const TfArgs a)
 
         float g = 1.0f;
         if (GAIN) {
-            g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
+            if (FROM_BITS && a.gain.mode == 2) {
+                const float *redf = reinterpret_cast<const float *>(red + 8 * (s & 1));
+                float S = 0.f;
+#pragma unroll
+                for (int w = 0; w < (T + 63) / 64; ++w) S += redf[w];
+                // |X| of the symbol: the table holds the COMPONENT magnitude; diagonal states
+                // (odd phase, the same parity on every carrier) have modulus sqrt(2) times that
+                const float mg = mag_l[s - 1];                               // the loop never sees s = 0 here
+                const float m2 = mg * mg * (float)(1u + (phase[0] & 1u));
+                const float vr = sqrtf(m2 * fmaxf((float)(K / 2) + S, 0.f)) * a.gain.var_variance;
+                const float vi = sqrtf(m2 * fmaxf((float)(K / 2) - S, 0.f)) * a.gain.var_variance;
+                g = ((int)vr == 0) ? 1.0f : 32767.0f / fmaxf(vr, vi);
+            } else {
+                g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
+            }
             g = g * a.gain.constant;
         }
 
@@ -942,6 +976,7 @@ size_t tf_lds_bytes(int logN, unsigned flags)
     const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
     const size_t elem = ((flags & TF_FIR) && DABGPU_DUAL_FFT) ? 2 * sizeof(float2) : sizeof(float2);
     size_t b = (dbuf ? 2 : 1) * (N + N / 8) * elem + 16 * sizeof(double);
+    if ((flags & TF_GAIN) && (flags & TF_FROM_BITS)) b += (N / 8) * sizeof(uint32_t);   // phase words
     if (flags & TF_FIR) b += 4 * DABGPU_KBND * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
