@@ -1388,7 +1388,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q, NOUT = NIN * Q;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);
-    cf *nyq = fbuf + 2 * F::LDS_ELEMS;   // [2]: the Nyquist bin of the current hop, double buffered
+    cf *nyq = fbuf + 2 * F::LDS_ELEMS;   // (exchange buffer = LDS_ELEMS 16-byte elements) [2]: Nyquist bin per hop parity
     cf *tw8_l = nyq + 2;                  // 7 x 8 twiddles of the stride-8 stage
     // overlap-add tail: 4Q values per lane, kept in LDS ([slot][lane], conflict-free) so that
     // the kernel stays inside 256 VGPRs
@@ -1430,26 +1430,43 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
             x[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
         }
     };
-    cf xn[8];
+    // Transforms are run two at a time as one packed dual IFFT (struct c2): the Q-1 branch
+    // IFFTs of hop h plus the FORWARD transform of hop h+1, which is an inverse transform of
+    // the conjugated input (DFT(x) = conj(IDFT(conj(x)))).  Q items per hop -> Q/2 passes.
+    c2 *fbuf2 = reinterpret_cast<c2 *>(fbuf);
+    cf xn[8], u[8], Fk[8];
     fetch(h0 - 1, xn);
-
-    for (long h = h0 - 1; h < h1; ++h) {
-        cf v[8], u[8], Fk[8];
+    {
+        cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) u[m] = mk(xn[m].x * win[m], xn[m].y * win[m]);
-#pragma unroll
-        for (int m = 0; m < 8; ++m) v[m] = u[m];
-        F::template run<-1>(v, fbuf, fpar, tw, t, tw8_l);
+        for (int m = 0; m < 8; ++m) { u[m] = mk(xn[m].x * win[m], xn[m].y * win[m]); v[m] = u[m]; }
+        F::template run<-1, false>(v, fbuf, fpar, tw, t, tw8_l);
 #pragma unroll
         for (int m = 0; m < 8; ++m) Fk[m] = cscale(v[m], a.factor);
+    }
+    if (h0 < h1) fetch(h0, xn);
+
+    // branch twiddle of bin t + T m for branch p (see above); Nyquist bin gets both copies
+    auto branch_in = [&](int p, int m) __attribute__((always_inline)) -> cf {
+        const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (8 * Q)) / (double)(8 * Q)
+                           - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
+        const cf rot = mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
+        // (Fk * wp) * rot, in this order: Fk changes every hop, so nothing is loop-invariant and
+        // the products cannot be hoisted into long-lived registers
+        cf y = cmul(cmul(Fk[m], wp[p]), rot);
+        if (m == HIN / T && t == 0)
+            y = cscale(Fk[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
+        return y;
+    };
+
+    for (long h = h0 - 1; h < h1; ++h) {
         const int slot = (int)(h & 1);
         if (t == 0) nyq[slot] = Fk[HIN / T];     // bin HIN lives in lane 0
         lds_barrier();
-
         const bool emit = h >= h0;
         cf *dst = a.out + (size_t)(emit ? h : 0) * HOUT;
-        // branches are produced two at a time and stored as 16-byte pairs (p, p+1)
-        cf o[8];
+
+        cf oa[4], ob[4];                          // one pair of branches waiting to be stored
         {
             // branch p = 0 needs no transform: IDFT(DFT(u)) = NIN u, plus the second copy of
             // the Nyquist bin, F[NIN/2] e^{i pi q}
@@ -1460,43 +1477,60 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
             for (int m = 0; m < 8; ++m) u[m] = mk(fmaf(u[m].x, sc, sgn * ny.x), fmaf(u[m].y, sc, sgn * ny.y));
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                o[2 * m] = cadd(tail[(m * Q) * T + t], u[m]);
+                oa[m] = cadd(tail[(m * Q) * T + t], u[m]);
                 tail[(m * Q) * T + t] = u[m + 4];
             }
         }
+        // windowed input of the next hop (zeros past the end of the run); its successor is
+        // requested right away, before any store of this hop (vmcnt retires in order)
+        const bool more = h + 1 < h1;
 #pragma unroll
-        for (int p = 1; p < Q; ++p) {
+        for (int m = 0; m < 8; ++m) u[m] = more ? mk(xn[m].x * win[m], xn[m].y * win[m]) : mk(0.f, 0.f);
+        if (h + 2 < h1) fetch(h + 2, xn);
+
+        cf Fn[8];
+#pragma unroll
+        for (int pass = 0; pass < Q / 2; ++pass) {
+            const int pa = 2 * pass + 1;                       // first item: branch pa
+            const int pb = pa + 1;                             // second item: branch pb, or the forward FFT
+            c2 v2[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
-                // e^{2 pi i m p / (8Q)}, times e^{-2 pi i p / Q} above Nyquist: compile-time constants
-                const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (8 * Q)) / (double)(8 * Q)
-                                   - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
-                const cf rot = mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
-                // (Fk * wp) * rot, in this order: Fk changes every hop, so nothing here is
-                // loop-invariant and the 24 products cannot be hoisted into 48 long-lived VGPRs
-                cf y = cmul(cmul(Fk[m], wp[p]), rot);
-                if (m == HIN / T && t == 0)      // Nyquist bin: placed at +NIN/2 and -NIN/2 by the reference
-                    y = cscale(Fk[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
-                v[m] = y;
+                const cf xa = branch_in(pa, m);
+                const cf xb = (pb < Q) ? branch_in(pb, m) : mk(u[m].x, -u[m].y);
+                v2[m] = c2{make_float2(xa.x, xb.x), make_float2(xa.y, xb.y)};
             }
-            // next hop's input is requested before the last stores of this hop (vmcnt retires in order)
-            if (p == Q - 1 && h + 1 < h1) fetch(h + 1, xn);
-            F::template run<+1>(v, fbuf, fpar, tw, t, tw8_l);
+            F::template run<+1, false, c2>(v2, fbuf2, fpar, tw, t, tw8_l);
+            // item a = branch pa (odd): completes the pair (pa-1, pa)
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                o[2 * m + (p & 1)] = cadd(tail[(m * Q + p) * T + t], v[m]);
-                tail[(m * Q + p) * T + t] = v[m + 4];
+                ob[m] = cadd(tail[(m * Q + pa) * T + t], mk(v2[m].re.x, v2[m].im.x));
+                tail[(m * Q + pa) * T + t] = mk(v2[m + 4].re.x, v2[m + 4].im.x);
             }
-            if ((p & 1) && emit) {
+            if (emit) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    cf a0 = o[2 * m], a1 = o[2 * m + 1];
+                    cf a0 = oa[m], a1 = ob[m];
                     if (POLY) { a0 = poly_apply(a0, pc); a1 = poly_apply(a1, pc); }
-                    float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m) + (p - 1));
+                    float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m) + (pa - 1));
                     *d4 = make_float4(a0.x, a0.y, a1.x, a1.y);
                 }
             }
+            if (pb < Q) {
+                // item b = branch pb (even): first half of the next pair
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    oa[m] = cadd(tail[(m * Q + pb) * T + t], mk(v2[m].re.y, v2[m].im.y));
+                    tail[(m * Q + pb) * T + t] = mk(v2[m + 4].re.y, v2[m + 4].im.y);
+                }
+            } else {
+                // item b = conj(DFT of the next hop's windowed input)
+#pragma unroll
+                for (int m = 0; m < 8; ++m) Fn[m] = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
+            }
         }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) Fk[m] = Fn[m];
     }
 }
 
