@@ -1402,9 +1402,10 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     cf tw[F::NTW];
     F::template load_twiddles<true>(a.tw_in, t, tw);
     F::fill_tw8(a.tw_in, tw8_l, t);
-    float win[8];
+    // the window lives in LDS (NIN floats): 8 fewer long-lived VGPRs in a kernel that sits at the 256 limit
+    float *win = reinterpret_cast<float *>(tail + 4 * Q * T);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) win[m] = a.window[t + T * m];
+    for (int m = 0; m < 8; ++m) win[t + T * m] = a.window[t + T * m];
     // per-branch twiddle of bin k = t + T m:  W_nout^{kappa p} = W_nout^{t p} * e^{2 pi i m p / (8Q)}
     // (* (-i)^p for the negative-frequency half, kappa = k - NIN): one table value per branch
     // and lane, the rest are compile-time rotations.
@@ -1439,7 +1440,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     {
         cf v[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { u[m] = mk(xn[m].x * win[m], xn[m].y * win[m]); v[m] = u[m]; }
+        for (int m = 0; m < 8; ++m) { u[m] = mk(xn[m].x * win[t + T * m], xn[m].y * win[t + T * m]); v[m] = u[m]; }
         F::template run<-1, false>(v, fbuf, fpar, tw, t, tw8_l);
 #pragma unroll
         for (int m = 0; m < 8; ++m) Fk[m] = cscale(v[m], a.factor);
@@ -1464,9 +1465,8 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         if (t == 0) nyq[slot] = Fk[HIN / T];     // bin HIN lives in lane 0
         lds_barrier();
         const bool emit = h >= h0;
-        cf *dst = a.out + (size_t)(emit ? h : 0) * HOUT;
 
-        cf oa[4], ob[4];                          // one pair of branches waiting to be stored
+        cf o[4 * Q];                              // all Q branches of the lane's 4 output samples
         {
             // branch p = 0 needs no transform: IDFT(DFT(u)) = NIN u, plus the second copy of
             // the Nyquist bin, F[NIN/2] e^{i pi q}
@@ -1477,7 +1477,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
             for (int m = 0; m < 8; ++m) u[m] = mk(fmaf(u[m].x, sc, sgn * ny.x), fmaf(u[m].y, sc, sgn * ny.y));
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                oa[m] = cadd(tail[(m * Q) * T + t], u[m]);
+                o[m * Q] = cadd(tail[(m * Q) * T + t], u[m]);
                 tail[(m * Q) * T + t] = u[m + 4];
             }
         }
@@ -1485,10 +1485,8 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         // requested right away, before any store of this hop (vmcnt retires in order)
         const bool more = h + 1 < h1;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) u[m] = more ? mk(xn[m].x * win[m], xn[m].y * win[m]) : mk(0.f, 0.f);
-        if (h + 2 < h1) fetch(h + 2, xn);
+        for (int m = 0; m < 8; ++m) u[m] = more ? mk(xn[m].x * win[t + T * m], xn[m].y * win[t + T * m]) : mk(0.f, 0.f);
 
-        cf Fn[8];
 #pragma unroll
         for (int pass = 0; pass < Q / 2; ++pass) {
             const int pa = 2 * pass + 1;                       // first item: branch pa
@@ -1501,36 +1499,44 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
                 v2[m] = c2{make_float2(xa.x, xb.x), make_float2(xa.y, xb.y)};
             }
             F::template run<+1, false, c2>(v2, fbuf2, fpar, tw, t, tw8_l);
-            // item a = branch pa (odd): completes the pair (pa-1, pa)
+            // item a = branch pa
 #pragma unroll
             for (int m = 0; m < 4; ++m) {
-                ob[m] = cadd(tail[(m * Q + pa) * T + t], mk(v2[m].re.x, v2[m].im.x));
+                o[m * Q + pa] = cadd(tail[(m * Q + pa) * T + t], mk(v2[m].re.x, v2[m].im.x));
                 tail[(m * Q + pa) * T + t] = mk(v2[m + 4].re.x, v2[m + 4].im.x);
-            }
-            if (emit) {
-#pragma unroll
-                for (int m = 0; m < 4; ++m) {
-                    cf a0 = oa[m], a1 = ob[m];
-                    if (POLY) { a0 = poly_apply(a0, pc); a1 = poly_apply(a1, pc); }
-                    float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m) + (pa - 1));
-                    *d4 = make_float4(a0.x, a0.y, a1.x, a1.y);
-                }
             }
             if (pb < Q) {
                 // item b = branch pb (even): first half of the next pair
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    oa[m] = cadd(tail[(m * Q + pb) * T + t], mk(v2[m].re.y, v2[m].im.y));
+                    o[m * Q + pb] = cadd(tail[(m * Q + pb) * T + t], mk(v2[m].re.y, v2[m].im.y));
                     tail[(m * Q + pb) * T + t] = mk(v2[m + 4].re.y, v2[m + 4].im.y);
                 }
             } else {
                 // item b = conj(DFT of the next hop's windowed input)
+                // (the current spectrum is dead once the last branch has been packed: overwrite it)
 #pragma unroll
-                for (int m = 0; m < 8; ++m) Fn[m] = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
+                for (int m = 0; m < 8; ++m) Fk[m] = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
             }
         }
+        // the input after next is requested before this hop's stores (vmcnt retires in order) ...
+        if (h + 2 < h1) fetch(h + 2, xn);
+        // ... and the Q branches of an output sample leave together: 8Q contiguous bytes per lane and
+        // slot, so HBM sees whole 32-byte sectors (16-byte pairs stored a transform apart cost 1.5x
+        // the write traffic)
+        if (emit) {
+            cf *dst = a.out + (size_t)h * HOUT;
 #pragma unroll
-        for (int m = 0; m < 8; ++m) Fk[m] = Fn[m];
+            for (int m = 0; m < 4; ++m) {
+                float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m));
+#pragma unroll
+                for (int p = 0; p < Q; p += 2) {
+                    cf a0 = o[m * Q + p], a1 = o[m * Q + p + 1];
+                    if (POLY) { a0 = poly_apply(a0, pc); a1 = poly_apply(a1, pc); }
+                    d4[p / 2] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                }
+            }
+        }
     }
 }
 
@@ -1540,9 +1546,11 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
     const int Q = a.nout / a.nin;
     // runs of hops: one extra (warm-up) hop per run; keep >= 2048 workgroups when the
     // stream is long enough, never shorter than 12 hops per run.
-    int hpr = (int)std::max<size_t>(12, (a.nhops + 2047) / 2048);
+    // (long runs amortise the warm-up hop: 96 hops = one Mode-I frame when the stream has >= 1024 of them)
+    int hpr = (int)std::max<size_t>(12, std::min<size_t>(96, a.nhops / 1024));
     const dim3 grid((unsigned)((a.nhops + hpr - 1) / hpr)), block(NIN / 8);
-    const size_t lds = (2 * (size_t)(NIN + NIN / 8) + 2 + 56 + (size_t)4 * (a.nout / a.nin) * (NIN / 8)) * sizeof(float2);
+    const size_t lds = (2 * (size_t)(NIN + NIN / 8) + 2 + 56 + (size_t)4 * (a.nout / a.nin) * (NIN / 8)) * sizeof(float2) +
+                       (size_t)NIN * sizeof(float);
     const bool poly = a.poly != nullptr;
     switch (Q) {
         case 2:
