@@ -1380,6 +1380,21 @@ DEV cf poly_apply(cf x, const PolyCoef &c)
     const float sr = x.x * a, si = x.y * a;
     return mk(sr * cr - si * ci, sr * ci + si * cr);
 }
+// two samples at a time: every operation is a packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32)
+DEV void poly_apply2(cf &s0, cf &s1, const PolyCoef &c)
+{
+    const float2 x = make_float2(s0.x, s1.x), y = make_float2(s0.y, s1.y);
+    const float2 m = x * x + y * y;
+    const float2 a = c.a0 + m * (c.a1 + m * (c.a2 + m * (c.a3 + m * c.a4)));
+    const float2 p = -1.0f * (c.p0 + m * (c.p1 + m * (c.p2 + m * (c.p3 + m * c.p4))));
+    const float2 q = p * p;
+    const float2 cr = (1.0f - q * (-0.5f + q * (0.486666f + q * (-0.00138888f))));
+    const float2 ci = p * (1.0f + q * (0.166666f + q * (0.00833333f)));
+    const float2 sr = x * a, si = y * a;
+    const float2 re = sr * cr - si * ci, im = sr * ci + si * cr;
+    s0 = mk(re.x, im.x);
+    s1 = mk(re.y, im.y);
+}
 
 template <int LOGNIN, int Q, bool POLY> __global__ __launch_bounds__((1 << LOGNIN) / 8)
 void resampler_kernel(const ResamplerArgs a, int hops_per_run)
@@ -1387,12 +1402,12 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     typedef Fft<LOGNIN> F;
     constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q, NOUT = NIN * Q;
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    cf *fbuf = reinterpret_cast<cf *>(smem);
-    cf *nyq = fbuf + 2 * F::LDS_ELEMS;   // (exchange buffer = LDS_ELEMS 16-byte elements) [2]: Nyquist bin per hop parity
-    cf *tw8_l = nyq + 2;                  // 7 x 8 twiddles of the stride-8 stage
-    // overlap-add tail: 4Q values per lane, kept in LDS ([slot][lane], conflict-free) so that
-    // the kernel stays inside 256 VGPRs
-    cf *tail = tw8_l + 56;
+    // two exchange buffers of 16-byte elements (packed dual transforms, one barrier per exchange)
+    c2 *fbuf2 = reinterpret_cast<c2 *>(smem);
+    cf *nyq = reinterpret_cast<cf *>(fbuf2 + 2 * F::LDS_ELEMS);   // [2]: Nyquist bin per hop parity
+    cf *tw8_l = nyq + 2;                                           // 7 x 8 twiddles of the stride-8 stage
+    // first half of the (symmetric) Hann window; w[i] = w[NIN-1-i] serves the second half
+    float *win = reinterpret_cast<float *>(tw8_l + 56);
     int fpar = 0;
     const int t = threadIdx.x;
     const long h0 = (long)blockIdx.x * hops_per_run;
@@ -1402,10 +1417,11 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     cf tw[F::NTW];
     F::template load_twiddles<true>(a.tw_in, t, tw);
     F::fill_tw8(a.tw_in, tw8_l, t);
-    // the window lives in LDS (NIN floats): 8 fewer long-lived VGPRs in a kernel that sits at the 256 limit
-    float *win = reinterpret_cast<float *>(tail + 4 * Q * T);
 #pragma unroll
-    for (int m = 0; m < 8; ++m) win[t + T * m] = a.window[t + T * m];
+    for (int m = 0; m < 4; ++m) win[t + T * m] = a.window[t + T * m];
+    auto wnd = [&](int m) __attribute__((always_inline)) -> float {
+        return m < 4 ? win[t + T * m] : win[T * (7 - m) + (T - 1 - t)];
+    };
     // per-branch twiddle of bin k = t + T m:  W_nout^{kappa p} = W_nout^{t p} * e^{2 pi i m p / (8Q)}
     // (* (-i)^p for the negative-frequency half, kappa = k - NIN): one table value per branch
     // and lane, the rest are compile-time rotations.
@@ -1417,9 +1433,6 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         pc.a0 = a.poly[0]; pc.a1 = a.poly[1]; pc.a2 = a.poly[2]; pc.a3 = a.poly[3]; pc.a4 = a.poly[4];
         pc.p0 = a.poly[8]; pc.p1 = a.poly[9]; pc.p2 = a.poly[10]; pc.p3 = a.poly[11]; pc.p4 = a.poly[12];
     }
-
-#pragma unroll
-    for (int i = 0; i < 4 * Q; ++i) tail[i * T + t] = mk(0.f, 0.f);
     lds_barrier();
 
     // S = [halo (2 hops) | in]; hop h uses S[(h+1)*HIN .. (h+3)*HIN)
@@ -1431,62 +1444,59 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
             x[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
         }
     };
-    // Transforms are run two at a time as one packed dual IFFT (struct c2): the Q-1 branch
-    // IFFTs of hop h plus the FORWARD transform of hop h+1, which is an inverse transform of
-    // the conjugated input (DFT(x) = conj(IDFT(conj(x)))).  Q items per hop -> Q/2 passes.
-    c2 *fbuf2 = reinterpret_cast<c2 *>(fbuf);
-    cf xn[8], u[8], Fk[8];
-    fetch(h0 - 1, xn);
+    // out_h = second_half(Y_{h-1}) + first_half(Y_h).  A shift by half the period is a sign
+    // flip of the odd bins, so out_h = first_half(IDFT_nout(stuff(G_h))) with
+    //     G_h[k] = F_h[k] + (-1)^k F_{h-1}[k]:
+    // the overlap-add happens on the nin-point spectra in registers ((-1)^k = (-1)^t for every
+    // bin of lane t) and no time-domain tail is carried from hop to hop.
+    // Transforms run two at a time as one packed dual IFFT (struct c2): the Q-1 branch IFFTs
+    // of hop h plus the FORWARD transform of hop h+1 (DFT(x) = conj(IDFT(conj(x)))).
+    const float sgn = (t & 1) ? -1.0f : 1.0f;
+    const float sc = (float)NIN * a.factor;
+    cf xn[8], G[8], Fc[8], b0[4];
     {
-        cf v[8];
+        // run prologue: F_{h0-1} and F_{h0} as one dual forward transform
+        cf xa[8];
+        fetch(h0 - 1, xa);
+        fetch(h0, xn);
+        c2 v2[8];
 #pragma unroll
-        for (int m = 0; m < 8; ++m) { u[m] = mk(xn[m].x * win[t + T * m], xn[m].y * win[t + T * m]); v[m] = u[m]; }
-        F::template run<-1, false>(v, fbuf, fpar, tw, t, tw8_l);
+        for (int m = 0; m < 8; ++m) {
+            const float w = wnd(m);
+            v2[m] = c2{make_float2(xa[m].x * w, xn[m].x * w), make_float2(-xa[m].y * w, -xn[m].y * w)};
+        }
 #pragma unroll
-        for (int m = 0; m < 8; ++m) Fk[m] = cscale(v[m], a.factor);
+        for (int m = 0; m < 4; ++m) b0[m] = cscale(xn[m], (wnd(m) + wnd(m + 4)) * sc);
+        F::template run<+1, true, c2>(v2, fbuf2, fpar, tw, t, tw8_l);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            Fc[m] = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
+            G[m] = mk(fmaf(sgn * a.factor, v2[m].re.x, Fc[m].x), fmaf(-sgn * a.factor, v2[m].im.x, Fc[m].y));
+        }
     }
-    if (h0 < h1) fetch(h0, xn);
+    if (h0 + 1 < h1) fetch(h0 + 1, xn);
 
     // branch twiddle of bin t + T m for branch p (see above); Nyquist bin gets both copies
     auto branch_in = [&](int p, int m) __attribute__((always_inline)) -> cf {
         const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (8 * Q)) / (double)(8 * Q)
                            - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
         const cf rot = mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
-        // (Fk * wp) * rot, in this order: Fk changes every hop, so nothing is loop-invariant and
+        // (G * wp) * rot, in this order: G changes every hop, so nothing is loop-invariant and
         // the products cannot be hoisted into long-lived registers
-        cf y = cmul(cmul(Fk[m], wp[p]), rot);
+        cf y = cmul(cmul(G[m], wp[p]), rot);
         if (m == HIN / T && t == 0)
-            y = cscale(Fk[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
+            y = cscale(G[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
         return y;
     };
 
-    for (long h = h0 - 1; h < h1; ++h) {
+    for (long h = h0; h < h1; ++h) {
         const int slot = (int)(h & 1);
-        if (t == 0) nyq[slot] = Fk[HIN / T];     // bin HIN lives in lane 0
-        lds_barrier();
-        const bool emit = h >= h0;
+        // bin HIN lives in lane 0; every lane reads it back after the first transform of the
+        // hop (at least one barrier later; the slot is rewritten two hops later)
+        if (t == 0) nyq[slot] = G[HIN / T];
+        const bool more = h + 1 < h1;
 
         cf o[4 * Q];                              // all Q branches of the lane's 4 output samples
-        {
-            // branch p = 0 needs no transform: IDFT(DFT(u)) = NIN u, plus the second copy of
-            // the Nyquist bin, F[NIN/2] e^{i pi q}
-            const cf ny = nyq[slot];
-            const float sgn = (t & 1) ? -1.0f : 1.0f;          // q = t + T m, T even
-            const float sc = (float)NIN * a.factor;
-#pragma unroll
-            for (int m = 0; m < 8; ++m) u[m] = mk(fmaf(u[m].x, sc, sgn * ny.x), fmaf(u[m].y, sc, sgn * ny.y));
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                o[m * Q] = cadd(tail[(m * Q) * T + t], u[m]);
-                tail[(m * Q) * T + t] = u[m + 4];
-            }
-        }
-        // windowed input of the next hop (zeros past the end of the run); its successor is
-        // requested right away, before any store of this hop (vmcnt retires in order)
-        const bool more = h + 1 < h1;
-#pragma unroll
-        for (int m = 0; m < 8; ++m) u[m] = more ? mk(xn[m].x * win[t + T * m], xn[m].y * win[t + T * m]) : mk(0.f, 0.f);
-
 #pragma unroll
         for (int pass = 0; pass < Q / 2; ++pass) {
             const int pa = 2 * pass + 1;                       // first item: branch pa
@@ -1495,28 +1505,39 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const cf xa = branch_in(pa, m);
-                const cf xb = (pb < Q) ? branch_in(pb, m) : mk(u[m].x, -u[m].y);
+                cf xb;
+                if (pb < Q) {
+                    xb = branch_in(pb, m);
+                } else {
+                    // conjugated windowed input of the next hop (zeros past the end of the run)
+                    const float w = more ? wnd(m) : 0.0f;
+                    xb = mk(xn[m].x * w, -xn[m].y * w);
+                }
                 v2[m] = c2{make_float2(xa.x, xb.x), make_float2(xa.y, xb.y)};
             }
-            F::template run<+1, false, c2>(v2, fbuf2, fpar, tw, t, tw8_l);
-            // item a = branch pa
+            F::template run<+1, true, c2>(v2, fbuf2, fpar, tw, t, tw8_l);
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                o[m * Q + pa] = cadd(tail[(m * Q + pa) * T + t], mk(v2[m].re.x, v2[m].im.x));
-                tail[(m * Q + pa) * T + t] = mk(v2[m + 4].re.x, v2[m + 4].im.x);
-            }
+            for (int m = 0; m < 4; ++m) o[m * Q + pa] = mk(v2[m].re.x, v2[m].im.x);
             if (pb < Q) {
-                // item b = branch pb (even): first half of the next pair
+#pragma unroll
+                for (int m = 0; m < 4; ++m) o[m * Q + pb] = mk(v2[m].re.y, v2[m].im.y);
+            } else {
+                // branch p = 0 needs no transform: IDFT(DFT(u)) = NIN u, i.e. the input samples
+                // under the sum of the two window halves (b0, prepared a hop ahead), plus the
+                // second copy of the Nyquist bin, G[NIN/2] e^{i pi q}  (q = t + T m, T even)
+                const cf ny = nyq[slot];
 #pragma unroll
                 for (int m = 0; m < 4; ++m) {
-                    o[m * Q + pb] = cadd(tail[(m * Q + pb) * T + t], mk(v2[m].re.y, v2[m].im.y));
-                    tail[(m * Q + pb) * T + t] = mk(v2[m + 4].re.y, v2[m + 4].im.y);
+                    o[m * Q] = mk(fmaf(sgn, ny.x, b0[m].x), fmaf(sgn, ny.y, b0[m].y));
+                    b0[m] = cscale(xn[m], (wnd(m) + wnd(m + 4)) * sc);
                 }
-            } else {
-                // item b = conj(DFT of the next hop's windowed input)
-                // (the current spectrum is dead once the last branch has been packed: overwrite it)
+                // item b = conj(F_{h+1}); the overlap-add with F_h gives the next hop's spectrum
 #pragma unroll
-                for (int m = 0; m < 8; ++m) Fk[m] = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
+                for (int m = 0; m < 8; ++m) {
+                    const cf fn = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
+                    G[m] = mk(fmaf(sgn, Fc[m].x, fn.x), fmaf(sgn, Fc[m].y, fn.y));
+                    Fc[m] = fn;
+                }
             }
         }
         // the input after next is requested before this hop's stores (vmcnt retires in order) ...
@@ -1524,17 +1545,15 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         // ... and the Q branches of an output sample leave together: 8Q contiguous bytes per lane and
         // slot, so HBM sees whole 32-byte sectors (16-byte pairs stored a transform apart cost 1.5x
         // the write traffic)
-        if (emit) {
-            cf *dst = a.out + (size_t)h * HOUT;
+        cf *dst = a.out + (size_t)h * HOUT;
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m));
+        for (int m = 0; m < 4; ++m) {
+            float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m));
 #pragma unroll
-                for (int p = 0; p < Q; p += 2) {
-                    cf a0 = o[m * Q + p], a1 = o[m * Q + p + 1];
-                    if (POLY) { a0 = poly_apply(a0, pc); a1 = poly_apply(a1, pc); }
-                    d4[p / 2] = make_float4(a0.x, a0.y, a1.x, a1.y);
-                }
+            for (int p = 0; p < Q; p += 2) {
+                cf a0 = o[m * Q + p], a1 = o[m * Q + p + 1];
+                if (POLY) poly_apply2(a0, a1, pc);
+                d4[p / 2] = make_float4(a0.x, a0.y, a1.x, a1.y);
             }
         }
     }
@@ -1549,8 +1568,7 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
     // (long runs amortise the warm-up hop: 96 hops = one Mode-I frame when the stream has >= 1024 of them)
     int hpr = (int)std::max<size_t>(12, std::min<size_t>(96, a.nhops / 1024));
     const dim3 grid((unsigned)((a.nhops + hpr - 1) / hpr)), block(NIN / 8);
-    const size_t lds = (2 * (size_t)(NIN + NIN / 8) + 2 + 56 + (size_t)4 * (a.nout / a.nin) * (NIN / 8)) * sizeof(float2) +
-                       (size_t)NIN * sizeof(float);
+    const size_t lds = 2 * (size_t)(NIN + NIN / 8) * 16 + (2 + 56) * sizeof(float2) + (size_t)(NIN / 2) * sizeof(float);
     const bool poly = a.poly != nullptr;
     switch (Q) {
         case 2:

@@ -12,11 +12,15 @@ P = importlib.import_module("odr-dabmod_amd")
 B = %d
 md = P.Modulator(mode=1, max_frames=B)
 md.set_gain(2, 1.0, 1/50000., 4.0)
+md.set_resampler(2048000, 8192000)
+md.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0])
 bits = torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device="cuda")
 st = torch.cuda.Stream()
 res = {}
 with torch.cuda.stream(st):
-    for name, mask in (("bits+guard", 0), ("bits+gain+guard", 1), ("bits+guard+fir", 2), ("cfg3", 3)):
+    for name, mask in (("bits+guard", 0), ("bits+gain+guard", 1), ("bits+guard+fir", 2), ("cfg3", 3),
+                       ("cfg3+res", 7), ("cfg4", 15)):
+        if mask > 3 and B > 1024: B = 1024
         out = torch.empty((B, md.out_samples_per_frame(mask)), dtype=torch.complex64, device="cuda")
         for _ in range(2): md.chain_dev(bits, B, mask, out, stream=st.cuda_stream)
         st.synchronize()
