@@ -1477,15 +1477,19 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     if (h0 + 1 < h1) fetch(h0 + 1, xn);
 
     // branch twiddle of bin t + T m for branch p (see above); Nyquist bin gets both copies
-    auto branch_in = [&](int p, int m) __attribute__((always_inline)) -> cf {
+    auto branch_rot = [](int p, int m) __attribute__((always_inline)) -> cf {
         const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (8 * Q)) / (double)(8 * Q)
                            - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
-        const cf rot = mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
+        return mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
+    };
+    auto nyq_scale = [](int p) __attribute__((always_inline)) -> float {
+        return 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q);
+    };
+    auto branch_in = [&](int p, int m) __attribute__((always_inline)) -> cf {
         // (G * wp) * rot, in this order: G changes every hop, so nothing is loop-invariant and
         // the products cannot be hoisted into long-lived registers
-        cf y = cmul(cmul(G[m], wp[p]), rot);
-        if (m == HIN / T && t == 0)
-            y = cscale(G[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
+        cf y = cmul(cmul(G[m], wp[p]), branch_rot(p, m));
+        if (m == HIN / T && t == 0) y = cscale(G[m], nyq_scale(p));
         return y;
     };
 
@@ -1504,11 +1508,22 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
             c2 v2[8];
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
+                if (pb < Q) {
+                    // two branches: both twiddle products as packed fp32 operations
+                    const float2 wr = make_float2(wp[pa].x, wp[pb].x), wi = make_float2(wp[pa].y, wp[pb].y);
+                    const cf ra = branch_rot(pa, m), rb = branch_rot(pb, m);
+                    const float2 rr = make_float2(ra.x, rb.x), ri = make_float2(ra.y, rb.y);
+                    const float2 yr = G[m].x * wr - G[m].y * wi, yi = G[m].x * wi + G[m].y * wr;
+                    v2[m] = c2{yr * rr - yi * ri, yr * ri + yi * rr};
+                    if (m == HIN / T && t == 0) {
+                        const float2 ny2 = make_float2(nyq_scale(pa), nyq_scale(pb));
+                        v2[m] = c2{G[m].x * ny2, G[m].y * ny2};
+                    }
+                    continue;
+                }
                 const cf xa = branch_in(pa, m);
                 cf xb;
-                if (pb < Q) {
-                    xb = branch_in(pb, m);
-                } else {
+                {
                     // conjugated windowed input of the next hop (zeros past the end of the run)
                     const float w = more ? wnd(m) : 0.0f;
                     xb = mk(xn[m].x * w, -xn[m].y * w);
