@@ -143,6 +143,27 @@ DABGPU_API int dabgpu_resampler_process(dabgpu_ctx *ctx, const void *in, size_t 
 DABGPU_API int dabgpu_poly_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
                                    size_t out_cap, size_t *out_bytes);
 
+/* FormatConverter::process, float input path, src/FormatConverter.cpp:111-178:
+ * cf32 -> interleaved s16 / u8 / s8 with the reference's range test, truncation toward zero and
+ * count of clipped components (FormatConverter::get_num_clipped_samples, :186-189).
+ * An unknown format is DABGPU_E_INVALID ("FormatConverter: Invalid format", :171-173). */
+enum {
+    DABGPU_FMT_S16 = 1,
+    DABGPU_FMT_U8 = 2,
+    DABGPU_FMT_S8 = 3
+};
+/* bytes per I/Q pair, FormatConverter::get_format_size, src/FormatConverter.cpp:192-208 (0 = unknown) */
+DABGPU_API size_t dabgpu_format_size(int format);
+DABGPU_API int dabgpu_format_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, int format,
+                                     void *out, size_t out_cap, size_t *out_bytes,
+                                     size_t *num_clipped);
+/* same, device-resident and asynchronous on `stream`; *d_num_clipped (device, 8 bytes, may be
+ * NULL) is INCREMENTED by the number of clipped components */
+DABGPU_API int dabgpu_format_process_dev(dabgpu_ctx *ctx, const void *d_in, size_t n_floats,
+                                         int format, void *d_out, size_t out_cap,
+                                         size_t *out_bytes, unsigned long long *d_num_clipped,
+                                         void *stream);
+
 /* ---- the fused chain ----------------------------------------------------- */
 
 /* bytes of IQ produced per transmission frame for a stage mask */

@@ -29,7 +29,10 @@ EXPORTS = [
     "dabgpu_resampler_process", "dabgpu_poly_process", "dabgpu_chain_out_bytes_per_frame",
     "dabgpu_chain_process", "dabgpu_chain_process_dev", "dabgpu_symbols_process_dev",
     "dabgpu_synchronize", "dabgpu_time_chain_dev",
+    "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
 ]
+
+FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
 
 
 class DabGpuError(RuntimeError):
@@ -100,6 +103,10 @@ def load_library():
     lib.dabgpu_chain_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_symbols_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_synchronize.argtypes = [vp]
+    lib.dabgpu_format_size.argtypes = [C.c_int]
+    lib.dabgpu_format_size.restype = sz
+    lib.dabgpu_format_process.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, szp]
+    lib.dabgpu_format_process_dev.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, vp, vp]
     lib.dabgpu_time_chain_dev.argtypes = [vp, vp, sz, u, vp, sz, C.c_int, C.POINTER(C.c_float)]
     _lib = lib
     return lib
@@ -246,6 +253,31 @@ class Modulator:
     def poly(self, x):
         x = np.ascontiguousarray(x, np.complex64)
         return self._stage("poly", x, x.nbytes)
+
+    def format_convert(self, x, fmt):
+        """FormatConverter (float input): returns (integer array, clipped components).
+        An unknown format raises like the reference (src/FormatConverter.cpp:171-173)."""
+        x = np.ascontiguousarray(x).view(np.float32).ravel()
+        code, dt = FORMATS.get(fmt, (0, np.uint8))
+        out = np.empty(x.size, dt)
+        ob, nc = C.c_size_t(), C.c_size_t()
+        self._chk(self._lib.dabgpu_format_process(self._h, x.ctypes.data, x.nbytes, code, out.ctypes.data,
+                                                  out.nbytes, C.byref(ob), C.byref(nc)))
+        return out[:ob.value // out.itemsize], int(nc.value)
+
+    def format_convert_dev(self, d_in, fmt, d_out, d_clipped=None, stream=None):
+        """Device path: d_in complex64/float32 tensor -> d_out integer tensor (asynchronous);
+        d_clipped (int64 tensor of one element, optional) is incremented."""
+        code = FORMATS.get(fmt, (0, None))[0]
+        n = d_in.numel() * (2 if d_in.is_complex() else 1)
+        ob = C.c_size_t()
+        s = self._stream_handle(d_in, stream)
+        self._chk(self._lib.dabgpu_format_process_dev(
+            self._h, d_in.data_ptr(), n, code, d_out.data_ptr(), d_out.numel() * d_out.element_size(),
+            C.byref(ob), d_clipped.data_ptr() if d_clipped is not None else None, s))
+        if not s:
+            self.synchronize()
+        return ob.value
 
     # ---- fused chain -------------------------------------------------------
     def out_samples_per_frame(self, stages):

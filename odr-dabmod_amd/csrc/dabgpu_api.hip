@@ -97,7 +97,7 @@ struct dabgpu_ctx {
     size_t rs_L = 1, rs_M = 1;
     float rs_factor = 1.f;
     // scratch
-    DevBuf d_a, d_b, d_c, d_in, d_out;
+    DevBuf d_a, d_b, d_c, d_in, d_out, d_count;
 
     std::mutex mu;
     Settings set;                    // guarded by mu
@@ -593,7 +593,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
-                      &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out})
+                      &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -886,6 +886,54 @@ int dabgpu_poly_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *ou
     if ((rc = run_poly(c, (const float2 *)c->d_a.p, in_bytes / sizeof(float2), (float2 *)c->d_b.p, c->stream)))
         return rc;
     return io.out(out, c->d_b.p, in_bytes);
+}
+
+// ---- f-2 FormatConverter -------------------------------------------------------
+
+size_t dabgpu_format_size(int format)
+{
+    return format == DABGPU_FMT_S16 ? 4 : (format == DABGPU_FMT_U8 || format == DABGPU_FMT_S8) ? 2 : 0;
+}
+
+int dabgpu_format_process_dev(dabgpu_ctx *c, const void *d_in, size_t n_floats, int format, void *d_out,
+                              size_t out_cap, size_t *out_bytes, unsigned long long *d_num_clipped,
+                              void *stream)
+{
+    CTXCHK(c);
+    const size_t elem = dabgpu_format_size(format) / 2;
+    if (!elem) return fail(c, DABGPU_E_INVALID, "FormatConverter: Invalid format");
+    int rc = check_out(c, n_floats * elem, out_cap, out_bytes);
+    if (rc) return rc;
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!d_num_clipped) {
+        HIPCHK(c, c->d_count.reserve(16));
+        d_num_clipped = (unsigned long long *)c->d_count.p + 1;      // scratch slot, never read
+    }
+    HIPCHK(c, launch_format((const float *)d_in, n_floats, format, d_out, d_num_clipped, s));
+    return DABGPU_OK;
+}
+
+int dabgpu_format_process(dabgpu_ctx *c, const void *in, size_t in_bytes, int format, void *out,
+                          size_t out_cap, size_t *out_bytes, size_t *num_clipped)
+{
+    CTXCHK(c);
+    const size_t elem = dabgpu_format_size(format) / 2;
+    if (!elem) return fail(c, DABGPU_E_INVALID, "FormatConverter: Invalid format");
+    const size_t n = in_bytes / sizeof(float);                       // src/FormatConverter.cpp:112
+    int rc = check_out(c, n * elem, out_cap, out_bytes);
+    if (rc) return rc;
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, n * sizeof(float)))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(n * elem, 16)));
+    HIPCHK(c, c->d_count.reserve(16));
+    HIPCHK(c, hipMemsetAsync(c->d_count.p, 0, 16, c->stream));
+    HIPCHK(c, launch_format((const float *)c->d_a.p, n, format, c->d_b.p, (unsigned long long *)c->d_count.p,
+                            c->stream));
+    unsigned long long cnt = 0;
+    HIPCHK(c, hipMemcpyAsync(&cnt, c->d_count.p, sizeof(cnt), hipMemcpyDeviceToHost, c->stream));
+    rc = io.out(out, c->d_b.p, n * elem);
+    if (num_clipped) *num_clipped = (size_t)cnt;
+    return rc;
 }
 
 // ---- chain -------------------------------------------------------------------

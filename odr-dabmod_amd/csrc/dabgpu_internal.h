@@ -76,6 +76,9 @@ hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, c
                       int ntaps, float2 *out, hipStream_t s);
 hipError_t launch_poly(const float2 *in, size_t nsamples, const float *am, const float *pm,
                        float2 *out, hipStream_t s);
+// f-2 FormatConverter: fmt 1 = s16, 2 = u8, 3 = s8; *clipped (device) is incremented
+hipError_t launch_format(const float *in, size_t nfloats, int fmt, void *out, unsigned long long *clipped,
+                         hipStream_t s);
 hipError_t launch_lut(const float2 *in, size_t nsamples, float scale, const float *lut,
                       float2 *out, hipStream_t s);
 

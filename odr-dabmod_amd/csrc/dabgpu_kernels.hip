@@ -1354,6 +1354,81 @@ hipError_t launch_lut(const float2 *in, size_t nsamples, float scale, const floa
 namespace {
 
 // ===========================================================================
+// f-2 FormatConverter, float input (reference src/FormatConverter.cpp:111-178): range test
+// against the integer limits (clipped components counted), otherwise float -> integer by
+// truncation toward zero; u8 adds 128.0f first.  FMT: 1 = s16, 2 = u8, 3 = s8.
+// HBM-bound elementwise: 8 floats per lane (two 16-byte loads, one 16- or 8-byte store), the
+// clip count reduced per wave and added to a device counter.
+template <int FMT> DEV int format_one(float x, unsigned &clipped)
+{
+    constexpr float lo = FMT == 1 ? -32768.0f : (FMT == 2 ? 0.0f : -128.0f);
+    constexpr float hi = FMT == 1 ? 32767.0f : (FMT == 2 ? 255.0f : 127.0f);
+    const float v = FMT == 2 ? x + 128.0f : x;
+    if (v < lo) { ++clipped; return (int)lo; }
+    if (v > hi) { ++clipped; return (int)hi; }
+    return (int)v;                       // v_cvt_i32_f32: toward zero, NaN -> 0
+}
+
+template <int FMT> __global__ __launch_bounds__(256)
+void format_kernel(const float *__restrict__ in, size_t n, void *__restrict__ out,
+                   unsigned long long *__restrict__ clipped_total)
+{
+    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    unsigned clipped = 0;
+    if (i0 + 8 <= n) {
+        const float4 a = reinterpret_cast<const float4 *>(in + i0)[0];
+        const float4 b = reinterpret_cast<const float4 *>(in + i0)[1];
+        const float x[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
+        int y[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) y[k] = format_one<FMT>(x[k], clipped);
+        if (FMT == 1) {
+            uint4 w;
+            w.x = (unsigned)(y[0] & 0xffff) | ((unsigned)y[1] << 16);
+            w.y = (unsigned)(y[2] & 0xffff) | ((unsigned)y[3] << 16);
+            w.z = (unsigned)(y[4] & 0xffff) | ((unsigned)y[5] << 16);
+            w.w = (unsigned)(y[6] & 0xffff) | ((unsigned)y[7] << 16);
+            reinterpret_cast<uint4 *>(reinterpret_cast<int16_t *>(out) + i0)[0] = w;
+        } else {
+            uint2 w;
+            w.x = (unsigned)(y[0] & 0xff) | ((unsigned)(y[1] & 0xff) << 8) | ((unsigned)(y[2] & 0xff) << 16) |
+                  ((unsigned)y[3] << 24);
+            w.y = (unsigned)(y[4] & 0xff) | ((unsigned)(y[5] & 0xff) << 8) | ((unsigned)(y[6] & 0xff) << 16) |
+                  ((unsigned)y[7] << 24);
+            reinterpret_cast<uint2 *>(reinterpret_cast<uint8_t *>(out) + i0)[0] = w;
+        }
+    } else {
+        for (size_t i = i0; i < n; ++i) {
+            const int y = format_one<FMT>(in[i], clipped);
+            if (FMT == 1) reinterpret_cast<int16_t *>(out)[i] = (int16_t)y;
+            else reinterpret_cast<uint8_t *>(out)[i] = (uint8_t)y;
+        }
+    }
+    unsigned tot = clipped;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
+    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(clipped_total, (unsigned long long)tot);
+}
+
+}  // namespace
+
+hipError_t launch_format(const float *in, size_t nfloats, int fmt, void *out, unsigned long long *clipped,
+                         hipStream_t s)
+{
+    if (nfloats == 0) return hipSuccess;
+    const dim3 grid(blocks_for((nfloats + 7) / 8, 256)), block(256);
+    switch (fmt) {
+        case 1: hipLaunchKernelGGL(format_kernel<1>, grid, block, 0, s, in, nfloats, out, clipped); break;
+        case 2: hipLaunchKernelGGL(format_kernel<2>, grid, block, 0, s, in, nfloats, out, clipped); break;
+        case 3: hipLaunchKernelGGL(format_kernel<3>, grid, block, 0, s, in, nfloats, out, clipped); break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+namespace {
+
+// ===========================================================================
 // a10 Resampler (src/Resampler.cpp:131-195), up-sampling by Q = nout/nin.
 //
 // Stateless restatement: out_h = second_half(Y_{h-1}) + first_half(Y_h),

@@ -422,6 +422,41 @@ int Resampler::process(Buffer *const dataIn, Buffer *dataOut)
     return 1;
 }
 
+// ---------------------------------------------------------------- FormatConverter
+namespace {
+int format_code(const std::string &f)
+{
+    return f == "s16" ? DABGPU_FMT_S16 : f == "u8" ? DABGPU_FMT_U8 : f == "s8" ? DABGPU_FMT_S8 : 0;
+}
+}  // namespace
+
+size_t FormatConverter::get_format_size(const std::string &format)
+{
+    const size_t n = dabgpu_format_size(format_code(format));
+    if (!n) throw std::runtime_error("FormatConverter: Invalid format " + format);  // reference :203-205
+    return n;
+}
+
+FormatConverter::FormatConverter(bool input_is_complexfix_wide, const std::string &format_out)
+    : m_ctx(1), m_format_out(format_out)
+{
+    if (input_is_complexfix_wide)
+        throw std::runtime_error("FormatConverter: the fixed-point engine is not offloaded");
+}
+
+int FormatConverter::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    const int code = format_code(m_format_out);
+    if (!code) throw std::runtime_error("FormatConverter: Invalid format " + m_format_out);
+    const size_t n = dataIn->getLength() / sizeof(float);
+    dataOut->setLength(n * dabgpu_format_size(code) / 2);
+    size_t nb = 0, clipped = 0;
+    m_ctx.check(dabgpu_format_process(m_ctx.get(), dataIn->getData(), dataIn->getLength(), code,
+                                      dataOut->getData(), dataOut->getLength(), &nb, &clipped));
+    m_num_clipped_samples.store(clipped);
+    return static_cast<int>(dataOut->getLength());
+}
+
 // ---------------------------------------------------------------- MemlessPoly
 MemlessPoly::MemlessPoly(std::string &coefs_file, unsigned int)
     : RemoteControllable("memlesspoly"), m_ctx(1), m_coefs_file(coefs_file)

@@ -15,6 +15,7 @@
 #include "ModPlugin.h"
 #include "RemoteControl.h"
 
+#include <atomic>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -219,6 +220,22 @@ private:
     bool m_valid = false, m_is_lut = false;
     std::vector<float> m_am, m_pm, m_lut;
     float m_lut_scale = 0.f;
+};
+
+// reference src/FormatConverter.h:42-66, .cpp:41-209 (float input only: the
+// fixed-point engine is not offloaded)
+class FormatConverter : public ModCodec {
+public:
+    static size_t get_format_size(const std::string &format);
+    FormatConverter(bool input_is_complexfix_wide, const std::string &format_out);
+    int process(Buffer *const dataIn, Buffer *dataOut) override;
+    const char *name() override { return "FormatConverter"; }
+    size_t get_num_clipped_samples() const { return m_num_clipped_samples.load(); }
+
+private:
+    dabgpu_host::Context m_ctx;
+    std::string m_format_out;
+    std::atomic<size_t> m_num_clipped_samples{0};
 };
 
 // The production plugin: cifPart output (28 800 B per Mode-I transmission frame)

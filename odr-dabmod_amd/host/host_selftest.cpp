@@ -207,7 +207,7 @@ std::vector<uint8_t> read_all(const std::string &path)
 int run_gpu(int argc, char **argv)
 {
     if (argc < 7) {
-        std::fprintf(stderr, "usage: host_selftest gpu <mode> <bits.bin> <nframes> <graph.iq> <chain.iq> [normalise]\n");
+        std::fprintf(stderr, "usage: host_selftest gpu <mode> <bits.bin> <nframes> <graph.iq> <chain.iq> [normalise] [chain.s16]\n");
         return 2;
     }
     const unsigned mode = static_cast<unsigned>(std::atoi(argv[2]));
@@ -278,6 +278,26 @@ int run_gpu(int argc, char **argv)
         fg.connect(chain, output);
         for (size_t i = 0; i < nframes; ++i) fg.run();
         std::printf("chain plugin: %d frames written\n", output->frames);
+    }
+    if (argc > 8) {
+        // file-output shape of the reference (src/DabModulator.cpp:395-419, normalise 1.0):
+        // chain -> FormatConverter("s16") -> sink
+        DabGpuChain::Settings s;
+        s.dabMode = mode;
+        s.normalise = 1.0f;
+        s.filterTapsFilename = "default";
+        auto cifPart = std::make_shared<BlockSource>(bits, block);
+        auto chain = std::make_shared<DabGpuChain>(s);
+        auto conv = std::make_shared<FormatConverter>(false, "s16");
+        auto output = std::make_shared<FileSink>(argv[8]);
+        Flowgraph fg;
+        fg.connect(cifPart, chain);
+        fg.connect(chain, conv);
+        fg.connect(conv, output);
+        for (size_t i = 0; i < nframes; ++i) fg.run();
+        std::printf("s16 chain: %d frames written, last frame clipped=%zu\n", output->frames,
+                    conv->get_num_clipped_samples());
+        if (FormatConverter::get_format_size("u8") != 2) throw std::runtime_error("get_format_size");
     }
     return 0;
 }

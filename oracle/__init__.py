@@ -90,6 +90,8 @@ def _load(name):
     lib.dabo_memless_poly.restype = None
     lib.dabo_memless_lut.argtypes = [_FP, C.c_size_t, C.c_float, _FP, _FP]
     lib.dabo_memless_lut.restype = None
+    lib.dabo_format_convert.argtypes = [_FP, C.c_size_t, C.c_int, C.c_void_p]
+    lib.dabo_format_convert.restype = C.c_size_t
     lib.dabo_chain_create.argtypes = [C.POINTER(_ChainCfg)]
     lib.dabo_chain_create.restype = C.c_void_p
     lib.dabo_chain_destroy.argtypes = [C.c_void_p]
@@ -274,6 +276,20 @@ def memless_lut(x, scalefactor, lut):
     return out
 
 
+FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
+
+
+def format_convert(x, fmt):
+    """f-2 FormatConverter (float input): returns (integer array, clipped components)."""
+    x = np.ascontiguousarray(x).view(np.float32).ravel()
+    if fmt not in FORMATS:
+        raise ValueError("FormatConverter: Invalid format " + fmt)
+    code, dt = FORMATS[fmt]
+    out = np.empty(x.size, dt)
+    n = lib().dabo_format_convert(_fp(x), x.size, code, out.ctypes.data_as(C.c_void_p))
+    return out, int(n)
+
+
 def dft_f64(x, sign):
     x = np.ascontiguousarray(x, np.complex128)
     out = np.empty_like(x)
@@ -345,6 +361,8 @@ def ref():
         r.ref_guard_interval.argtypes = [_FP, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, _FP]
         r.ref_fir_filter.argtypes = [_FP, C.c_size_t, C.c_char_p, _FP]
         r.ref_memless_poly.argtypes = [_FP, C.c_size_t, C.c_char_p, C.c_uint, _FP]
+        r.ref_format_convert.argtypes = [_FP, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t,
+                                         C.POINTER(C.c_size_t)]
         _ref = r
     return _ref
 
@@ -442,6 +460,18 @@ def ref_memless_poly(x, coef_file, num_threads=1):
     _rchk(ref().ref_memless_poly(_fp(x), x.size, coef_file.encode(), num_threads, _fp(out)),
           "memless_poly")
     return out
+
+
+def ref_format_convert(x, fmt):
+    x = np.ascontiguousarray(x).view(np.float32).ravel()
+    dt = FORMATS[fmt][1] if fmt in FORMATS else np.uint8
+    out = np.empty(x.size, dt)
+    clipped = C.c_size_t(0)
+    rc = ref().ref_format_convert(_fp(x), x.size, fmt.encode(), out.ctypes.data_as(C.c_void_p),
+                                  out.nbytes, C.byref(clipped))
+    if rc < 0:
+        raise ValueError("reference: format_convert failed (rc=%d)" % rc)
+    return out[:rc // out.itemsize], int(clipped.value)
 
 
 def tmp_path(suffix):

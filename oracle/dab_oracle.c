@@ -720,3 +720,38 @@ int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float
     }
     return 0;
 }
+
+/* ---------------------------------------------------------------------------
+ * f-2 FormatConverter, float input (reference src/FormatConverter.cpp:111-178):
+ * range test against the integer limits, clipped components counted, otherwise the
+ * C float -> integer conversion (truncation toward zero).  u8 adds 128.0f first. */
+size_t dabo_format_convert(const float *in, size_t n, int fmt, void *out)
+{
+    size_t clipped = 0;
+    if (fmt == DABO_FMT_S16) {
+        int16_t *o = (int16_t *)out;                 /* :116-131 */
+        for (size_t i = 0; i < n; ++i) {
+            if (in[i] < INT16_MIN) { o[i] = INT16_MIN; ++clipped; }
+            else if (in[i] > INT16_MAX) { o[i] = INT16_MAX; ++clipped; }
+            else o[i] = (int16_t)in[i];
+        }
+    } else if (fmt == DABO_FMT_U8) {
+        uint8_t *o = (uint8_t *)out;                 /* :133-151 */
+        for (size_t i = 0; i < n; ++i) {
+            const float samp = in[i] + 128.0f;
+            if (samp < 0) { o[i] = 0; ++clipped; }
+            else if (samp > UINT8_MAX) { o[i] = UINT8_MAX; ++clipped; }
+            else o[i] = (uint8_t)samp;
+        }
+    } else if (fmt == DABO_FMT_S8) {
+        int8_t *o = (int8_t *)out;                   /* :153-169 */
+        for (size_t i = 0; i < n; ++i) {
+            if (in[i] < INT8_MIN) { o[i] = INT8_MIN; ++clipped; }
+            else if (in[i] > INT8_MAX) { o[i] = INT8_MAX; ++clipped; }
+            else o[i] = (int8_t)in[i];
+        }
+    } else {
+        return (size_t)-1;                           /* :171-173 */
+    }
+    return clipped;
+}

@@ -122,6 +122,13 @@ enum {
     DABO_STAGE_POLY     = 1 << 3
 };
 
+/* f-2 FormatConverter, float input path (reference src/FormatConverter.cpp:111-178).
+ * fmt: 1 = s16, 2 = u8, 3 = s8.  n = number of FLOATS (2 per IQ sample); out holds n
+ * int16_t / uint8_t / int8_t.  Returns the number of clipped components, or (size_t)-1
+ * for an unknown format (the reference throws "FormatConverter: Invalid format"). */
+enum { DABO_FMT_S16 = 1, DABO_FMT_U8 = 2, DABO_FMT_S8 = 3 };
+size_t dabo_format_convert(const float *in, size_t n, int fmt, void *out);
+
 typedef struct {
     int mode;
     unsigned stages;      /* DABO_STAGE_* mask; qpsk..ofdm and guard always run */

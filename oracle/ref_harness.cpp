@@ -22,6 +22,7 @@
 #include "GuardIntervalInserter.h"
 #include "FIRFilter.h"
 #include "MemlessPoly.h"
+#include "FormatConverter.h"
 
 #include <cstring>
 #include <string>
@@ -167,6 +168,22 @@ int ref_memless_poly(const float *in, size_t nsamples, const char *coef_file,
         st.process(&b1, &bo);
         st.process(&b2, &bo);
         return copy_out(bo, out, nsamples * sizeof(complexf));
+    } catch (const std::exception &) { return -1; }
+}
+
+// f-2: FormatConverter (float input).  Returns bytes written, -1 on exception; *clipped = its counter.
+int ref_format_convert(const float *in, size_t nfloats, const char *fmt, void *out, size_t out_cap,
+                       size_t *clipped)
+{
+    try {
+        FormatConverter st(false, std::string(fmt));
+        Buffer bi, bo;
+        fill(bi, in, nfloats * sizeof(float));
+        st.process(&bi, &bo);
+        if (clipped) *clipped = st.get_num_clipped_samples();
+        if (bo.getLength() > out_cap) return -2;
+        memcpy(out, bo.getData(), bo.getLength());
+        return (int)bo.getLength();
     } catch (const std::exception &) { return -1; }
 }
 

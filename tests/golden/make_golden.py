@@ -27,7 +27,8 @@ import numpy as np
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, os.path.dirname(os.path.dirname(HERE)))
-from tests.golden.synth import synth_bits, synth_signal, POLY_AM, POLY_PM, LUT_SCALE, lut_table  # noqa: E402
+from tests.golden.synth import (synth_bits, synth_signal, POLY_AM, POLY_PM, LUT_SCALE, lut_table,  # noqa: E402
+                                format_input, format_edges)
 import oracle as O  # noqa: E402
 
 
@@ -91,6 +92,13 @@ def main():
         g["lut"] = {"sha256": sha(pl)}
         os.unlink(pf)
         os.unlink(lf)
+        # f-2 FormatConverter: a frame of samples with ~2 % out-of-range components, and the edges
+        for fmt in ("s16", "u8", "s8"):
+            xi = format_input(O.tf_samples(mode), 200 + mode, fmt)
+            yo, clipped = O.ref_format_convert(xi, fmt)
+            g["format_%s" % fmt] = {"sha256": sha(yo), "clipped": clipped}
+            ye, ce = O.ref_format_convert(format_edges(fmt), fmt)
+            g["format_edges_%s" % fmt] = {"out": [int(v) for v in ye], "clipped": ce}
         gold["modes"][str(mode)] = g
     with open(os.path.join(HERE, "golden.json"), "w") as fo:
         json.dump(gold, fo, indent=1, sort_keys=True)

@@ -16,7 +16,8 @@ import pytest
 
 import oracle as O
 from tests.conftest import load_pkg
-from tests.golden.synth import LUT_SCALE, POLY_AM, POLY_PM, lut_table, synth_bits, synth_signal
+from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, format_edges, format_input, lut_table, synth_bits,
+                                synth_signal)
 
 pytestmark = pytest.mark.gpu
 
@@ -209,6 +210,52 @@ def test_memless_poly_and_lut(mods):
     bad = np.abs(y - ref) > 1e-6 * np.abs(ref)
     assert bad.mean() <= 1e-5
     md.set_poly([1, 0, 0, 0, 0], [0, 0, 0, 0, 0])
+
+
+# --------------------------------------------------------------------------- f-2 FormatConverter
+@pytest.mark.parametrize("mode", [1, 3])
+@pytest.mark.parametrize("fmt", ["s16", "u8", "s8"])
+def test_format_converter_bit_exact_vs_reference_golden(mods, mode, fmt):
+    md, g = mods[mode], GOLD[str(mode)]
+    y, clipped = md.format_convert(format_input(md.geometry["tf_samples"], 200 + mode, fmt), fmt)
+    assert sha(y) == g["format_%s" % fmt]["sha256"]
+    assert clipped == g["format_%s" % fmt]["clipped"]
+    ye, ce = md.format_convert(format_edges(fmt), fmt)
+    assert [int(v) for v in ye] == g["format_edges_%s" % fmt]["out"]
+    assert ce == g["format_edges_%s" % fmt]["clipped"]
+
+
+@pytest.mark.parametrize("n", [0, 1, 7, 8, 9, 2047, 4099])
+def test_format_converter_ragged_lengths(mods, n):
+    """any float count (the reference loops over sizeIn floats): the vector body and the scalar tail"""
+    x = (synth_signal(4100, seed=77).view(np.float32) * np.float32(700))[:n]
+    for fmt in ("s16", "u8", "s8"):
+        y, c = mods[1].format_convert(x if fmt == "s16" else x / np.float32(256), fmt)
+        ref, rc = O.format_convert(x if fmt == "s16" else x / np.float32(256), fmt)
+        assert np.array_equal(y, ref) and c == rc
+
+
+def test_format_converter_errors_and_device_path(pkg, mods):
+    import torch
+    md = mods[1]
+    with pytest.raises(pkg.DabGpuError, match="Invalid format"):
+        md.format_convert(np.zeros(8, np.float32), "s32")
+    x = format_input(3 * md.geometry["tf_samples"], 9, "s16")
+    ref, rc = O.format_convert(x, "s16")
+    d_in = torch.from_numpy(x).cuda()
+    d_out = torch.empty(2 * x.size, dtype=torch.int16, device="cuda")
+    d_cnt = torch.zeros(1, dtype=torch.int64, device="cuda")
+    st = torch.cuda.Stream()
+    with torch.cuda.stream(st):
+        nb = md.format_convert_dev(d_in, "s16", d_out, d_cnt, stream=st.cuda_stream)
+        md.format_convert_dev(d_in, "s16", d_out, d_cnt, stream=st.cuda_stream)   # the counter accumulates
+    st.synchronize()
+    assert nb == ref.nbytes
+    assert np.array_equal(d_out.cpu().numpy(), ref)
+    assert int(d_cnt.item()) == 2 * rc
+    # too small an output buffer is an error, not a truncated write
+    with pytest.raises(pkg.DabGpuError, match="too small"):
+        md.format_convert_dev(d_in, "s16", d_out[:-8], d_cnt, stream=st.cuda_stream)
 
 
 @pytest.mark.parametrize("out_rate", [8192000, 4096000])

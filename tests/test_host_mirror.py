@@ -52,10 +52,10 @@ def test_flowgraph_of_drop_in_stages_matches_oracle(tmp_path, mode):
     n = 5
     per = O.tf_input_bytes(mode)
     bits = np.stack([synth_bits(per, seed=300 + i) for i in range(n)])
-    fbits, fgraph, fchain = (str(tmp_path / x) for x in ("bits.bin", "graph.iq", "chain.iq"))
+    fbits, fgraph, fchain, fs16 = (str(tmp_path / x) for x in ("bits.bin", "graph.iq", "chain.iq", "chain.s16"))
     bits.tofile(fbits)
-    r = subprocess.run([BIN, "gpu", str(mode), fbits, str(n), fgraph, fchain], capture_output=True,
-                       text=True, timeout=300)
+    r = subprocess.run([BIN, "gpu", str(mode), fbits, str(n), fgraph, fchain, repr(1.0 / 50000.0), fs16],
+                       capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stdout + r.stderr
     ref = O.Chain(mode=mode, stages=3, gain_mode=2, normalise=1.0 / 50000.0).process(bits)
     tf = O.tf_samples(mode)
@@ -68,3 +68,13 @@ def test_flowgraph_of_drop_in_stages_matches_oracle(tmp_path, mode):
         assert np.linalg.norm(graph[f] - ref[f]) / np.linalg.norm(ref[f]) < 1e-6
     for f in range(n):
         assert np.linalg.norm(chain[f] - ref[f]) / np.linalg.norm(ref[f]) < 1e-6
+    # chain -> FormatConverter("s16") -> sink at normalise 1.0: the integer stream of a file output.
+    # The float samples agree to ~1e-7 relative, so a truncation may fall on the other side of an
+    # integer for a few samples: at most one LSB, on less than 1 % of the components.
+    ref1 = O.Chain(mode=mode, stages=3, gain_mode=2, normalise=1.0).process(bits)
+    want, clipped = O.format_convert(ref1, "s16")
+    got = np.fromfile(fs16, dtype=np.int16)
+    assert got.size == want.size
+    d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+    assert d.max() <= 1 and (d != 0).mean() < 1e-2
+    assert "s16 chain: %d frames written" % n in r.stdout

@@ -9,7 +9,8 @@ import numpy as np
 import pytest
 
 import oracle as O
-from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, lut_table, synth_bits, synth_signal)
+from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, format_edges, format_input, lut_table, synth_bits,
+                                synth_signal)
 
 GOLD_DIR = os.path.join(os.path.dirname(__file__), "golden")
 GOLD = json.load(open(os.path.join(GOLD_DIR, "golden.json")))["modes"]
@@ -72,6 +73,24 @@ def test_float_stages_bit_exact_vs_reference(mode):
     assert sha(O.memless_poly(f, POLY_AM, POLY_PM)) == g["poly"]["sha256"]
     assert sha(O.memless_poly(f, [1, 0, 0, 0, 0], [0, 0, 0, 0, 0])) == g["poly_identity_file"]["sha256"]
     assert sha(O.memless_lut(f, LUT_SCALE, lut_table())) == g["lut"]["sha256"]
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+@pytest.mark.parametrize("fmt", ["s16", "u8", "s8"])
+def test_format_converter_bit_exact_vs_reference(mode, fmt):
+    """f-2: integer output and the clipped-component count are the reference's."""
+    g = GOLD[str(mode)]
+    y, clipped = O.format_convert(format_input(O.tf_samples(mode), 200 + mode, fmt), fmt)
+    assert sha(y) == g["format_%s" % fmt]["sha256"]
+    assert clipped == g["format_%s" % fmt]["clipped"]
+    ye, ce = O.format_convert(format_edges(fmt), fmt)
+    assert [int(v) for v in ye] == g["format_edges_%s" % fmt]["out"]
+    assert ce == g["format_edges_%s" % fmt]["clipped"]
+
+
+def test_format_converter_rejects_unknown_format():
+    with pytest.raises(ValueError):
+        O.format_convert(np.zeros(4, np.float32), "s32")
 
 
 def test_fir_default_taps_are_symmetric_lowpass():
