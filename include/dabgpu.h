@@ -143,6 +143,19 @@ DABGPU_API int dabgpu_resampler_process(dabgpu_ctx *ctx, const void *in, size_t 
 DABGPU_API int dabgpu_poly_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
                                    size_t out_cap, size_t *out_bytes);
 
+/* TII.  dabgpu_set_tii = tii_config_t + the RC parameters enable / comb / pattern /
+ * old_variant (src/TII.h:42-69, src/TII.cpp:339-372); invalid mode (only I and II carry TII), comb
+ * outside [0,23] or pattern outside [0,69] is DABGPU_E_INVALID with the reference's TIIError text
+ * (src/TII.cpp:119-150).  In the fused chain (dabgpu_chain_process*) an enabled TII replaces the
+ * null symbol on every other frame of the stream, starting with the first (TII::m_insert,
+ * src/TII.h:112, src/TII.cpp:226-242); the frame parity is per context and advances whether or
+ * not TII is enabled, like the reference's.
+ * dabgpu_tii_process = TII::process, src/TII.cpp:213-245: `in` is the PhaseReference symbol
+ * (carriers x cf32), out the TII symbol or zeros; each call toggles the insert flag. */
+DABGPU_API int dabgpu_set_tii(dabgpu_ctx *ctx, int enable, int comb, int pattern, int old_variant);
+DABGPU_API int dabgpu_tii_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
+                                  size_t out_cap, size_t *out_bytes);
+
 /* FormatConverter::process, float input path, src/FormatConverter.cpp:111-178:
  * cf32 -> interleaved s16 / u8 / s8 with the reference's range test, truncation toward zero and
  * count of clipped components (FormatConverter::get_num_clipped_samples, :186-189).

@@ -29,7 +29,7 @@ EXPORTS = [
     "dabgpu_resampler_process", "dabgpu_poly_process", "dabgpu_chain_out_bytes_per_frame",
     "dabgpu_chain_process", "dabgpu_chain_process_dev", "dabgpu_symbols_process_dev",
     "dabgpu_synchronize", "dabgpu_time_chain_dev",
-    "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
+    "dabgpu_set_tii", "dabgpu_tii_process", "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -103,6 +103,8 @@ def load_library():
     lib.dabgpu_chain_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_symbols_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_synchronize.argtypes = [vp]
+    lib.dabgpu_set_tii.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
+    lib.dabgpu_tii_process.argtypes = [vp, vp, sz, vp, sz, szp]
     lib.dabgpu_format_size.argtypes = [C.c_int]
     lib.dabgpu_format_size.restype = sz
     lib.dabgpu_format_process.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, szp]
@@ -253,6 +255,14 @@ class Modulator:
     def poly(self, x):
         x = np.ascontiguousarray(x, np.complex64)
         return self._stage("poly", x, x.nbytes)
+
+    def set_tii(self, enable, comb=0, pattern=0, old_variant=False):
+        self._chk(self._lib.dabgpu_set_tii(self._h, int(enable), comb, pattern, int(old_variant)))
+
+    def tii(self, phase):
+        """TII::process: phase reference symbol -> TII symbol (or zeros on idle calls)."""
+        x = np.ascontiguousarray(phase, np.complex64)
+        return self._stage("tii", x, x.nbytes)
 
     def format_convert(self, x, fmt):
         """FormatConverter (float input): returns (integer array, clipped components).

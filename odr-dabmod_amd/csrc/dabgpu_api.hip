@@ -75,6 +75,8 @@ struct Settings {
     bool poly_is_lut = false;
     float am[5] = {1, 0, 0, 0, 0}, pm[5] = {0, 0, 0, 0, 0};
     float lut_scale = 0.f, lut[32] = {0};
+    bool tii_enable = false, tii_old_variant = false;   // src/TII.h:42-69 (tii_config_t)
+    int tii_comb = 0, tii_pattern = 0;
     unsigned long long epoch = 1;  // bumped by every setter
     bool resampler_reset = true;
 };
@@ -98,6 +100,12 @@ struct dabgpu_ctx {
     float rs_factor = 1.f;
     // scratch
     DevBuf d_a, d_b, d_c, d_in, d_out, d_count;
+    // TII (f-4): carrier set, the one-frame carrier image and its native-rate response, gain of symbol 1
+    DevBuf d_acp, d_tii_car, d_tii_frame, d_gain1;
+    bool tii_insert = true;               // TII::m_insert (src/TII.h:112): this frame of the stream carries TII
+    unsigned long long tii_seg_epoch = 0; // settings epoch / stage mask the cached segment was built for
+    unsigned tii_seg_mask = ~0u;
+    int tii_seg_len = 0;
 
     std::mutex mu;
     Settings set;                    // guarded by mu
@@ -390,6 +398,115 @@ size_t out_samples_per_frame(const dabgpu_ctx *c, unsigned mask, size_t L, size_
 }
 
 // The chain on device pointers.  from_bits: d_in is coded bits, else carriers.
+// The native-rate part of the chain (everything up to and including FIRFilter) for n_frames frames
+// into native_out (`native` samples per frame).
+int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,
+               float2 *native_out, size_t native, float *gain1, hipStream_t s)
+{
+    TfArgs a;
+    a.g = c->g;
+    a.t = tables_of(c);
+    a.gain = gain_of(c);
+    a.ntaps = (int)c->cur.taps.size();
+    a.n_frames = (int)n_frames;
+    a.bits = from_bits ? (const uint8_t *)d_in : nullptr;
+    a.carriers = from_bits ? nullptr : (const float2 *)d_in;
+    a.gain1 = from_bits ? gain1 : nullptr;
+    unsigned flags = from_bits ? TF_FROM_BITS : 0;
+    if (mask & DABGPU_STAGE_GAIN) flags |= TF_GAIN;
+
+    if (!windowed) {
+        if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
+        if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
+        a.chunks_per_frame = auto_chunks(c, n_frames);
+        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.out = native_out;
+        a.out_stride = native;
+        HIPCHK(c, launch_tf(a, flags, s));
+    } else {
+        // OFDM windowing: IFFT(+gain) -> windowed guard -> FIR as separate kernels
+        const size_t nsymN = (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.N;
+        HIPCHK(c, c->d_b.reserve(n_frames * nsymN * sizeof(float2)));
+        a.chunks_per_frame = auto_chunks(c, n_frames);
+        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.out = (float2 *)c->d_b.p;
+        a.out_stride = nsymN;
+        HIPCHK(c, launch_tf(a, flags, s));
+        float2 *gout = native_out;
+        if (mask & DABGPU_STAGE_FIR) {
+            HIPCHK(c, c->d_c.reserve(n_frames * native * sizeof(float2)));
+            gout = (float2 *)c->d_c.p;
+        }
+        if (c->cur.overlap > 0)
+            HIPCHK(c, launch_guard_window((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
+                                          (const float *)c->d_window.p, gout, s));
+        else
+            HIPCHK(c, launch_guard_copy((const float2 *)c->d_b.p, n_frames, c->g, gout, s));
+        if (mask & DABGPU_STAGE_FIR)
+            HIPCHK(c, launch_fir(gout, native, n_frames, (const float *)c->d_taps.p,
+                                 (int)c->cur.taps.size(), native_out, s));
+    }
+
+    return DABGPU_OK;
+}
+
+// TII A_{c,p} in the reference's index convention (src/TII.cpp:247-337)
+int tii_carrier_set(int mode, int comb, int pattern, std::vector<uint8_t> &acp)
+{
+    const int K = mode == 1 ? 1536 : 384;
+    acp.assign((size_t)K, 0);
+    // the 70 patterns are the 8-bit words of weight 4 in increasing order, leftmost bit = b 0 (:34-104)
+    int word = 0;
+    for (int w = 0, idx = 0; w < 256; ++w)
+        if (__builtin_popcount((unsigned)w) == 4 && idx++ == pattern) word = w;
+    auto enable = [&](int k) {
+        const int ix = K / 2 + k + (k >= 0 ? -1 : 0);
+        if (ix < 0 || ix + 1 >= K) return false;
+        acp[(size_t)ix] = 1;
+        return true;
+    };
+    bool ok = true;
+    for (int b = 0; b < 8; ++b) {
+        if (!((word >> (7 - b)) & 1)) continue;
+        if (mode == 1) {
+            for (int base : {-768, -384, 1, 385}) ok = enable(base + 2 * comb + 48 * b) && ok;
+        } else {
+            ok = enable((b < 4 ? -192 : -191) + 2 * comb + 48 * b) && ok;
+        }
+    }
+    return ok ? DABGPU_OK : DABGPU_E_INVALID;
+}
+
+// (Re)build the stream contribution of one TII null symbol at unit gain for this stage mask:
+// TII symbol -> IFFT -> guard interval (-> FIR) of a frame whose other symbols are blank.
+int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t native, hipStream_t s)
+{
+    const unsigned key = mask & (DABGPU_STAGE_FIR | DABGPU_STAGE_NOGUARD);
+    if (c->tii_seg_epoch == c->applied_epoch && c->tii_seg_mask == key) return DABGPU_OK;
+    const size_t K = (size_t)c->g.K, car_bytes = (size_t)(c->g.nb_symbols + 1) * K * sizeof(float2);
+    std::vector<uint8_t> acp;
+    if (tii_carrier_set(c->g.mode, c->cur.tii_comb, c->cur.tii_pattern, acp))
+        return fail(c, DABGPU_E_INVALID, "TII::enable_carrier invalid k!");
+    HIPCHK(c, upload(c->d_acp, acp, s));
+    HIPCHK(c, c->d_tii_car.reserve(car_bytes + K * sizeof(float2)));
+    HIPCHK(c, c->d_tii_frame.reserve(native * sizeof(float2)));
+    HIPCHK(c, hipMemsetAsync(c->d_tii_car.p, 0, car_bytes, s));
+    float2 *phase = (float2 *)((char *)c->d_tii_car.p + car_bytes);
+    HIPCHK(c, launch_phase_reference((const uint8_t *)c->d_phq.p, c->g.K, phase, s));
+    HIPCHK(c, launch_tii(phase, (const uint8_t *)c->d_acp.p, c->g.K, c->cur.tii_old_variant ? 1 : 0, 1,
+                         (float2 *)c->d_tii_car.p, s));
+    int rc = run_native(c, c->d_tii_car.p, false, 1, key, windowed, (float2 *)c->d_tii_frame.p, native, nullptr, s);
+    if (rc) return rc;
+    // the response of the null symbol: its own segment plus whatever a windowed guard interval spills
+    // into the next one (zeros beyond; adding them is harmless)
+    const size_t ext = (mask & DABGPU_STAGE_NOGUARD) ? (size_t)c->g.N
+                                                     : (size_t)c->g.null_size + 2 * c->cur.overlap + 8;
+    c->tii_seg_len = (int)std::min(native, ext);
+    c->tii_seg_epoch = c->applied_epoch;
+    c->tii_seg_mask = key;
+    return DABGPU_OK;
+}
+
 int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask,
               float2 *d_out, size_t out_cap, size_t *out_bytes, hipStream_t s)
 {
@@ -425,48 +542,21 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
         native_out = (float2 *)c->d_a.p;
     }
 
-    TfArgs a;
-    a.g = c->g;
-    a.t = tables_of(c);
-    a.gain = gain_of(c);
-    a.ntaps = (int)c->cur.taps.size();
-    a.n_frames = (int)n_frames;
-    a.bits = from_bits ? (const uint8_t *)d_in : nullptr;
-    a.carriers = from_bits ? nullptr : (const float2 *)d_in;
-    unsigned flags = from_bits ? TF_FROM_BITS : 0;
-    if (mask & DABGPU_STAGE_GAIN) flags |= TF_GAIN;
-
-    if (!windowed) {
-        if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
-        if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
-        a.chunks_per_frame = auto_chunks(c, n_frames);
-        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
-        a.out = native_out;
-        a.out_stride = native;
-        HIPCHK(c, launch_tf(a, flags, s));
-    } else {
-        // OFDM windowing: IFFT(+gain) -> windowed guard -> FIR as separate kernels
-        const size_t nsymN = (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.N;
-        HIPCHK(c, c->d_b.reserve(n_frames * nsymN * sizeof(float2)));
-        a.chunks_per_frame = auto_chunks(c, n_frames);
-        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
-        a.out = (float2 *)c->d_b.p;
-        a.out_stride = nsymN;
-        HIPCHK(c, launch_tf(a, flags, s));
-        float2 *gout = native_out;
-        if (mask & DABGPU_STAGE_FIR) {
-            HIPCHK(c, c->d_c.reserve(n_frames * native * sizeof(float2)));
-            gout = (float2 *)c->d_c.p;
+    const bool tii = from_bits && c->cur.tii_enable;
+    float *gain1 = nullptr;
+    if (tii) {
+        if ((rc = ensure_tii_segment(c, mask, windowed, native, s))) return rc;
+        if (mask & DABGPU_STAGE_GAIN) {
+            HIPCHK(c, c->d_gain1.reserve(n_frames * sizeof(float)));
+            gain1 = (float *)c->d_gain1.p;
         }
-        if (c->cur.overlap > 0)
-            HIPCHK(c, launch_guard_window((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
-                                          (const float *)c->d_window.p, gout, s));
-        else
-            HIPCHK(c, launch_guard_copy((const float2 *)c->d_b.p, n_frames, c->g, gout, s));
-        if (mask & DABGPU_STAGE_FIR)
-            HIPCHK(c, launch_fir(gout, native, n_frames, (const float *)c->d_taps.p,
-                                 (int)c->cur.taps.size(), native_out, s));
     }
+    if ((rc = run_native(c, d_in, from_bits, n_frames, mask, windowed, native_out, native, gain1, s))) return rc;
+    if (tii)
+        HIPCHK(c, launch_tii_add(native_out, native, (const float2 *)c->d_tii_frame.p, c->tii_seg_len, gain1,
+                                 c->tii_insert ? 1 : 0, n_frames, s));
+    // the insert flag toggles once per frame of the stream whether or not TII is enabled (src/TII.cpp:241-242)
+    if (from_bits && (n_frames & 1)) c->tii_insert = !c->tii_insert;
 
     if (post) {
         const float2 *cur = native_out;
@@ -593,7 +683,8 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
-                      &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count})
+                      &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
+                      &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -642,6 +733,23 @@ int dabgpu_set_window_overlap(dabgpu_ctx *c, size_t overlap)
     if (!c) return DABGPU_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
     c->set.overlap = overlap;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_tii(dabgpu_ctx *c, int enable, int comb, int pattern, int old_variant)
+{
+    if (!c) return DABGPU_E_INVALID;
+    // src/TII.cpp:119-150
+    if (c->g.mode != 1 && c->g.mode != 2)
+        return fail(c, DABGPU_E_INVALID, "TII::TII DAB mode " + std::to_string(c->g.mode) + " not valid!");
+    if (pattern < 0 || pattern > 69) return fail(c, DABGPU_E_INVALID, "TII::TII pattern not valid!");
+    if (comb < 0 || comb > 23) return fail(c, DABGPU_E_INVALID, "TII::TII comb not valid!");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->set.tii_enable = enable != 0;
+    c->set.tii_comb = comb;
+    c->set.tii_pattern = pattern;
+    c->set.tii_old_variant = old_variant != 0;
     ++c->set.epoch;
     return DABGPU_OK;
 }
@@ -755,6 +863,32 @@ int dabgpu_null_symbol_process(dabgpu_ctx *c, void *out, size_t out_cap, size_t 
     HostIO io(c);
     HIPCHK(c, c->d_b.reserve(need));
     HIPCHK(c, hipMemsetAsync(c->d_b.p, 0, need, c->stream));
+    return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_tii_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,
+                       size_t *out_bytes)
+{
+    CTXCHK(c);
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    const size_t need = (size_t)c->g.K * sizeof(float2);
+    if (c->g.mode != 1 && c->g.mode != 2)
+        return fail(c, DABGPU_E_INVALID, "TII::TII DAB mode " + std::to_string(c->g.mode) + " not valid!");
+    if (!in || in_bytes != need) return fail(c, DABGPU_E_INVALID, "TII::process input size not valid!");
+    if ((rc = check_out(c, need, out_cap, out_bytes))) return rc;
+    std::vector<uint8_t> acp;
+    if (tii_carrier_set(c->g.mode, c->cur.tii_comb, c->cur.tii_pattern, acp))
+        return fail(c, DABGPU_E_INVALID, "TII::enable_carrier invalid k!");
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, upload(c->d_acp, acp, c->stream));
+    c->tii_seg_epoch = 0;                      // d_acp is shared with the chain's cached segment
+    HIPCHK(c, c->d_b.reserve(need));
+    const int insert = (c->cur.tii_enable && c->tii_insert) ? 1 : 0;       // src/TII.cpp:226
+    HIPCHK(c, launch_tii((const float2 *)c->d_a.p, (const uint8_t *)c->d_acp.p, c->g.K,
+                         c->cur.tii_old_variant ? 1 : 0, insert, (float2 *)c->d_b.p, c->stream));
+    c->tii_insert = !c->tii_insert;                                        // :241-242
     return io.out(out, c->d_b.p, need);
 }
 

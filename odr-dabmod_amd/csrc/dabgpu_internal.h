@@ -51,6 +51,7 @@ struct TfArgs {
     const float2 *carriers;   // else: n_frames * (nb_symbols+1)*K samples
     float2 *out;
     size_t out_stride;        // samples per frame in `out`
+    float *gain1;             // FROM_BITS, optional: per frame, the multiplier applied to symbol 1 (TII)
 };
 
 enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8 };
@@ -76,6 +77,11 @@ hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, c
                       int ntaps, float2 *out, hipStream_t s);
 hipError_t launch_poly(const float2 *in, size_t nsamples, const float *am, const float *pm,
                        float2 *out, hipStream_t s);
+// f-4 TII: the sparse symbol (stand-alone stage), and its addition to a stream whose null symbol is blank
+hipError_t launch_tii(const float2 *in, const uint8_t *acp, int K, int old_variant, int insert, float2 *out,
+                      hipStream_t s);
+hipError_t launch_tii_add(float2 *out, size_t stride, const float2 *seg, int seg_len, const float *gain1,
+                          int insert0, size_t n_frames, hipStream_t s);
 // f-2 FormatConverter: fmt 1 = s16, 2 = u8, 3 = s8; *clipped (device) is incremented
 hipError_t launch_format(const float *in, size_t nfloats, int fmt, void *out, unsigned long long *clipped,
                          hipStream_t s);

@@ -865,6 +865,9 @@ void tf_kernel(const TfArgs a)
                 g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
             }
             g = g * a.gain.constant;
+            // TII (f-4): the null symbol of the coded-bits path is added afterwards, scaled by the
+            // multiplier of symbol 1 (src/GainControl.cpp:139-144)
+            if (FROM_BITS && a.gain1 != nullptr && s == 1 && t == 0) a.gain1[frame] = g;
         }
 
         const int cpl = (!FROM_BITS && s == 0) ? cp0 : cp;
@@ -1354,6 +1357,38 @@ hipError_t launch_lut(const float2 *in, size_t nsamples, float scale, const floa
 namespace {
 
 // ===========================================================================
+// f-4 TII (reference src/TII.cpp:172-211): the sparse TII symbol from the phase reference symbol.
+// Gather form of the reference's loop "if (Acp[i]) { out[i] = in[i]; out[i+1] = old ? in[i+1] : in[i]; }".
+__global__ void tii_kernel(const cf *__restrict__ in, const uint8_t *__restrict__ acp, int K, int old_variant,
+                           int insert, cf *__restrict__ out)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= K) return;
+    cf y = mk(0.f, 0.f);
+    if (insert) {
+        if (acp[i]) y = in[i];
+        else if (i > 0 && acp[i - 1]) y = old_variant ? in[i] : in[i - 1];
+    }
+    out[i] = y;
+}
+
+// Everything after the IFFT is linear, and the null symbol takes the gain of symbol 1: on a frame
+// that carries TII the stream is the stream with a blank null symbol plus g_1 times a constant
+// segment (the TII symbol through IFFT, guard interval and FIR, computed once per setting).
+__global__ void tii_add_kernel(cf *__restrict__ out, size_t stride, const cf *__restrict__ seg, int seg_len,
+                               const float *__restrict__ gain1, int insert0)
+{
+    const int f = blockIdx.y;
+    if (((f & 1) == 0) != (insert0 != 0)) return;     // TII::m_insert toggles per frame
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= seg_len) return;
+    const float g = gain1 ? gain1[f] : 1.0f;
+    cf *o = out + (size_t)f * stride + n;
+    const cf x = seg[n], y = *o;
+    *o = mk(fmaf(g, x.x, y.x), fmaf(g, x.y, y.y));
+}
+
+// ===========================================================================
 // f-2 FormatConverter, float input (reference src/FormatConverter.cpp:111-178): range test
 // against the integer limits (clipped components counted), otherwise float -> integer by
 // truncation toward zero; u8 adds 128.0f first.  FMT: 1 = s16, 2 = u8, 3 = s8.
@@ -1411,6 +1446,22 @@ void format_kernel(const float *__restrict__ in, size_t n, void *__restrict__ ou
 }
 
 }  // namespace
+
+hipError_t launch_tii(const float2 *in, const uint8_t *acp, int K, int old_variant, int insert, float2 *out,
+                      hipStream_t s)
+{
+    hipLaunchKernelGGL(tii_kernel, dim3((K + 255) / 256), dim3(256), 0, s, in, acp, K, old_variant, insert, out);
+    return hipGetLastError();
+}
+
+hipError_t launch_tii_add(float2 *out, size_t stride, const float2 *seg, int seg_len, const float *gain1,
+                          int insert0, size_t n_frames, hipStream_t s)
+{
+    if (n_frames == 0 || seg_len <= 0) return hipSuccess;
+    hipLaunchKernelGGL(tii_add_kernel, dim3((seg_len + 255) / 256, (unsigned)n_frames), dim3(256), 0, s, out,
+                       stride, seg, seg_len, gain1, insert0);
+    return hipGetLastError();
+}
 
 hipError_t launch_format(const float *in, size_t nfloats, int fmt, void *out, unsigned long long *clipped,
                          hipStream_t s)

@@ -1,5 +1,8 @@
 #include "Flowgraph.h"
 
+#include <algorithm>
+#include <iterator>
+
 #include <chrono>
 #include <cstdio>
 #include <sstream>
@@ -41,6 +44,12 @@ void Flowgraph::connect(std::shared_ptr<ModPlugin> input, std::shared_ptr<ModPlu
 {
     auto src = nodeFor(input);
     auto dst = nodeFor(output);
+    // Nodes run in list order.  A consumer that was already listed ahead of a producer connected
+    // later (cifSig, when tii is wired after it) moves to the end of the list, exactly as the
+    // reference does (src/Flowgraph.cpp:299-308: only the output node moves).
+    auto is = std::find(m_nodes.begin(), m_nodes.end(), src), id = std::find(m_nodes.begin(), m_nodes.end(), dst);
+    if (std::distance(m_nodes.begin(), is) > std::distance(m_nodes.begin(), id))
+        m_nodes.splice(m_nodes.end(), m_nodes, id);
     auto e = std::make_shared<Edge>(src, dst);
     src->addOutputEdge(e);
     dst->addInputEdge(e);

@@ -422,6 +422,103 @@ int Resampler::process(Buffer *const dataIn, Buffer *dataOut)
     return 1;
 }
 
+// ---------------------------------------------------------------- TII
+namespace {
+// the TIIError the reference constructor throws for a mode without TII (src/TII.cpp:144-149),
+// before a device context is created
+int tii_mode(unsigned int dabmode)
+{
+    if (dabmode != 1 && dabmode != 2)
+        throw TIIError("TII::TII DAB mode " + std::to_string(dabmode) + " not valid!");
+    return static_cast<int>(dabmode);
+}
+}  // namespace
+
+TII::TII(unsigned int dabmode, tii_config_t &tii_config, bool fixedPoint)
+    : RemoteControllable("tii"), m_ctx(tii_mode(dabmode)), m_conf(tii_config)
+{
+    if (fixedPoint) throw std::runtime_error("TII: the fixed-point engine is not offloaded");
+    RC_ADD_PARAMETER(enable, "enable TII [0-1]");
+    RC_ADD_PARAMETER(comb, "TII comb number [0-23]");
+    RC_ADD_PARAMETER(pattern, "TII pattern number [0-69]");
+    RC_ADD_PARAMETER(old_variant, "select old TII variant for old (buggy) receivers [0-1]");
+    push_settings();
+}
+
+void TII::push_settings()
+{
+    if (dabgpu_set_tii(m_ctx.get(), m_conf.enable, m_conf.comb, m_conf.pattern, m_conf.old_variant) != DABGPU_OK)
+        throw TIIError(dabgpu_last_error(m_ctx.get()));
+}
+
+const char *TII::name()
+{
+    // computed on demand: comb and pattern are RC-mutable (reference src/TII.cpp:159-170)
+    std::lock_guard<std::mutex> lock(m_mutex);
+    m_name = "TII(c:" + std::to_string(m_conf.comb) + " p:" + std::to_string(m_conf.pattern) +
+             " vrnt:" + (m_conf.old_variant ? "old" : "new") + ")";
+    return m_name.c_str();
+}
+
+int TII::process(Buffer *dataIn, Buffer *dataOut)
+{
+    if (dataIn == nullptr) throw TIIError("TII::process input size not valid!");
+    dataOut->setLength(dataIn->getLength());
+    size_t n = 0;
+    if (dabgpu_tii_process(m_ctx.get(), dataIn->getData(), dataIn->getLength(), dataOut->getData(),
+                           dataOut->getLength(), &n) != DABGPU_OK)
+        throw TIIError(dabgpu_last_error(m_ctx.get()));
+    dataOut->setLength(n);
+    return 1;
+}
+
+void TII::set_parameter(const std::string &parameter, const std::string &value)
+{
+    std::stringstream ss(value);
+    ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
+    std::lock_guard<std::mutex> lock(m_mutex);
+    if (parameter == "enable") {
+        ss >> m_conf.enable;
+    } else if (parameter == "pattern") {
+        int v = 0;
+        ss >> v;
+        if (v < 0 || v > 69) throw TIIError("TII pattern not valid!");
+        m_conf.pattern = v;
+    } else if (parameter == "comb") {
+        int v = 0;
+        ss >> v;
+        if (v < 0 || v > 23) throw TIIError("TII comb not valid!");
+        m_conf.comb = v;
+    } else if (parameter == "old_variant") {
+        ss >> m_conf.old_variant;
+    } else {
+        dabgpu_host::not_exported(parameter, get_rc_name());
+    }
+    push_settings();
+}
+
+const std::string TII::get_parameter(const std::string &parameter) const
+{
+    std::lock_guard<std::mutex> lock(m_mutex);
+    if (parameter == "enable") return m_conf.enable ? "1" : "0";
+    if (parameter == "pattern") return std::to_string(m_conf.pattern);
+    if (parameter == "comb") return std::to_string(m_conf.comb);
+    if (parameter == "old_variant") return m_conf.old_variant ? "1" : "0";
+    dabgpu_host::not_exported(parameter, get_rc_name());
+    return "";
+}
+
+const json::map_t TII::get_all_values() const
+{
+    json::map_t m;
+    std::lock_guard<std::mutex> lock(m_mutex);
+    m["enable"].v = m_conf.enable;
+    m["pattern"].v = static_cast<int64_t>(m_conf.pattern);
+    m["comb"].v = static_cast<int64_t>(m_conf.comb);
+    m["old_variant"].v = m_conf.old_variant;
+    return m;
+}
+
 // ---------------------------------------------------------------- FormatConverter
 namespace {
 int format_code(const std::string &f)
@@ -595,6 +692,8 @@ DabGpuChain::DabGpuChain(const Settings &s) : m_ctx(static_cast<int>(s.dabMode),
                                     s.gainmodeVariance));
     }
     m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), s.ofdmWindowOverlap));
+    if (s.tiiConfig.enable)
+        m_ctx.check(dabgpu_set_tii(m_ctx.get(), 1, s.tiiConfig.comb, s.tiiConfig.pattern, s.tiiConfig.old_variant));
     if (!s.filterTapsFilename.empty()) {
         m_mask |= DABGPU_STAGE_FIR;
         if (s.filterTapsFilename == "default") {

@@ -17,6 +17,7 @@
 
 #include <atomic>
 #include <mutex>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -222,6 +223,36 @@ private:
     float m_lut_scale = 0.f;
 };
 
+// reference src/TII.h:42-69 (settings) and :79-130, src/TII.cpp:106-245, RC :339-410
+struct tii_config_t {
+    bool enable = false;
+    int comb = 0;
+    int pattern = 0;
+    bool old_variant = false;
+};
+
+class TIIError : public std::runtime_error {
+public:
+    explicit TIIError(const std::string &msg) : std::runtime_error(msg) {}
+};
+
+class TII : public ModCodec, public RemoteControllable {
+public:
+    TII(unsigned int dabmode, tii_config_t &tii_config, bool fixedPoint);
+    int process(Buffer *dataIn, Buffer *dataOut) override;
+    const char *name() override;
+    void set_parameter(const std::string &parameter, const std::string &value) override;
+    const std::string get_parameter(const std::string &parameter) const override;
+    const json::map_t get_all_values() const override;
+
+private:
+    void push_settings();
+    dabgpu_host::Context m_ctx;
+    tii_config_t &m_conf;
+    std::string m_name;
+    mutable std::mutex m_mutex;
+};
+
 // reference src/FormatConverter.h:42-66, .cpp:41-209 (float input only: the
 // fixed-point engine is not offloaded)
 class FormatConverter : public ModCodec {
@@ -253,6 +284,7 @@ public:
         size_t outputRate = 2048000;
         std::string polyCoefFilename;     // "" = no predistortion
         size_t ofdmWindowOverlap = 0;
+        tii_config_t tiiConfig;           // TII on every other frame of the stream (modes I and II)
     };
     explicit DabGpuChain(const Settings &s);
     int process(Buffer *const dataIn, Buffer *dataOut) override;

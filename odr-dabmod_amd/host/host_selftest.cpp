@@ -165,6 +165,44 @@ int run_cpu()
         CHECK(fg.run() == true && sink->frames == 2 && sink->last == 5);
         CHECK(fg.run() == false);  // source exhausted
     }
+    // a producer wired after its consumer (tii -> cifSig, src/DabModulator.cpp:392-395): the consumer
+    // moves behind it in the run order (reference src/Flowgraph.cpp:299-308)
+    {
+        class Concat : public ModMux {
+        public:
+            int process(std::vector<Buffer *> in, Buffer *out) override
+            {
+                out->setLength(0);
+                for (Buffer *b : in) *out += *b;
+                return static_cast<int>(out->getLength());
+            }
+            const char *name() override { return "Concat"; }
+        };
+        auto s1 = std::make_shared<BlockSource>(std::vector<uint8_t>{1, 2}, 1);
+        auto s2 = std::make_shared<BlockSource>(std::vector<uint8_t>{7, 8}, 1);
+        auto late = std::make_shared<AddOne>();
+        auto mux = std::make_shared<Concat>();
+        class LastByteSink : public ModOutput {
+        public:
+            int process(Buffer *in) override
+            {
+                len = in->getLength();
+                last = len ? (*in)[len - 1] : -1;
+                return 1;
+            }
+            const char *name() override { return "LastByteSink"; }
+            size_t len = 0;
+            int last = -1;
+        };
+        auto sink = std::make_shared<LastByteSink>();
+        Flowgraph fg;
+        fg.connect(s1, mux);
+        fg.connect(s2, late);
+        fg.connect(late, mux);     // `late` is listed after `mux`: mux must move to the end
+        fg.connect(mux, sink);
+        CHECK(fg.run() == true && sink->len == 2 && sink->last == 8);    // {1, 7+1}
+        CHECK(fg.run() == true && sink->len == 2 && sink->last == 9);    // {2, 8+1}
+    }
     // pipelined stage: call i returns frame i-1, call 0 returns nothing, input buffer is stolen
     {
         PipeDouble pd;
@@ -207,7 +245,7 @@ std::vector<uint8_t> read_all(const std::string &path)
 int run_gpu(int argc, char **argv)
 {
     if (argc < 7) {
-        std::fprintf(stderr, "usage: host_selftest gpu <mode> <bits.bin> <nframes> <graph.iq> <chain.iq> [normalise] [chain.s16]\n");
+        std::fprintf(stderr, "usage: host_selftest gpu <mode> <bits.bin> <nframes> <graph.iq> <chain.iq> [normalise] [chain.s16] [tii comb,pattern]\n");
         return 2;
     }
     const unsigned mode = static_cast<unsigned>(std::atoi(argv[2]));
@@ -228,6 +266,13 @@ int run_gpu(int argc, char **argv)
     bool enableCfr = false;
     size_t windowOverlap = 0;
     std::string tapsFile = "default";
+    // optional: TII "comb,pattern" (SURVEY 8 f-4), wired like src/DabModulator.cpp:178-190,392-395
+    tii_config_t tiiConfig;
+    if (argc > 9) {
+        if (std::sscanf(argv[9], "%d,%d", &tiiConfig.comb, &tiiConfig.pattern) != 2)
+            throw std::runtime_error("tii argument: comb,pattern");
+        tiiConfig.enable = true;
+    }
 
     {
         auto cifPart = std::make_shared<BlockSource>(bits, block);
@@ -252,6 +297,13 @@ int run_gpu(int argc, char **argv)
         fg.connect(cifFreq, cifDiff);
         fg.connect(cifNull, cifSig);
         fg.connect(cifDiff, cifSig);
+        std::shared_ptr<TII> tii;
+        if (tiiConfig.enable) {
+            tii = std::make_shared<TII>(mode, tiiConfig, false);
+            auto tiiRef = std::make_shared<PhaseReference>(mode, false);
+            fg.connect(tiiRef, tii);
+            fg.connect(tii, cifSig);
+        }
         fg.connect(cifSig, cifOfdm);
         fg.connect(cifOfdm, cifGain);
         fg.connect(cifGain, cifGuard);
@@ -262,6 +314,16 @@ int run_gpu(int argc, char **argv)
         // remote control through the stage interface
         cifGain->set_parameter("mode", "VAR");
         if (cifGain->get_parameter("mode") != "var") throw std::runtime_error("RC mode round trip failed");
+        if (tii) {
+            const int comb0 = tiiConfig.comb;      // the stage holds a reference into tiiConfig
+            tii->set_parameter("comb", "7");
+            if (tii->get_parameter("comb") != "7" || std::string(tii->name()).find("c:7") == std::string::npos)
+                throw std::runtime_error("RC tii comb round trip failed");
+            bool threw = false;
+            try { tii->set_parameter("pattern", "70"); } catch (const TIIError &) { threw = true; }
+            if (!threw) throw std::runtime_error("TII pattern 70 must be rejected");
+            tii->set_parameter("comb", std::to_string(comb0));
+        }
         std::printf("stage graph: %zu rounds, %d reached the sink (%d frames written)\n", nframes, rounds_ok,
                     output->frames);
     }
@@ -270,6 +332,7 @@ int run_gpu(int argc, char **argv)
         s.dabMode = mode;
         s.normalise = normalise;
         s.filterTapsFilename = "default";
+        s.tiiConfig = tiiConfig;
         auto cifPart = std::make_shared<BlockSource>(bits, block);
         auto chain = std::make_shared<DabGpuChain>(s);
         auto output = std::make_shared<FileSink>(argv[6]);

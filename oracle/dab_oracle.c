@@ -638,6 +638,8 @@ struct dabo_chain {
     float *phase;           /* K */
     float *a, *b;           /* ping-pong scratch */
     size_t out_per_tf;
+    uint8_t *acp;           /* TII carrier set, K */
+    int tii_insert;         /* TII::m_insert, src/TII.h:112 (starts true, toggles per frame) */
 };
 
 /* Stage order of src/DabModulator.cpp:385-419 (TII/CIC/CFR/FormatConverter off). */
@@ -664,6 +666,14 @@ dabo_chain *dabo_chain_create(const dabo_chain_cfg *cfg)
     c->b = (float *)malloc(sizeof(float) * 2 * big);
     c->phase = (float *)malloc(sizeof(float) * 2 * (size_t)c->m.carriers);
     dabo_phase_reference(c->m.mode, c->phase, NULL);
+    c->tii_insert = 1;
+    if (cfg->tii_enable) {
+        c->acp = (uint8_t *)calloc((size_t)c->m.carriers, 1);
+        if (dabo_tii_pattern(cfg->mode, cfg->tii_comb, cfg->tii_pattern, c->acp)) {
+            dabo_chain_destroy(c);
+            return NULL;
+        }
+    }
     return c;
 }
 
@@ -671,7 +681,7 @@ void dabo_chain_destroy(dabo_chain *c)
 {
     if (!c) return;
     dabo_resampler_destroy(c->rs);
-    free(c->taps); free(c->phase); free(c->a); free(c->b);
+    free(c->taps); free(c->phase); free(c->a); free(c->b); free(c->acp);
     free(c);
 }
 
@@ -688,8 +698,13 @@ int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float
         int rc = 0;
         rc |= dabo_qpsk_map(bits + f * inb, inb, m->carriers, a);
         rc |= dabo_freq_interleave(a, ndata, m->mode, b);
-        /* null symbol (K zeros) ++ diff-mod output */
+        /* null symbol (K zeros), or the TII symbol (SignalMultiplexer input 2,
+         * src/SignalMultiplexer.cpp:63-66) ++ diff-mod output */
         memset(a, 0, K * 2 * sizeof(float));
+        if (c->acp) {
+            dabo_tii_process(c->phase, m->carriers, c->acp, c->cfg.tii_old_variant, c->tii_insert, a);
+            c->tii_insert = !c->tii_insert;
+        }
         rc |= dabo_diff_mod(c->phase, b, ndata, m->carriers, a + 2 * K);
         rc |= dabo_ofdm_generate(a, (int)nsym, m->carriers, m->spacing, b);
         t = a; a = b; b = t;                       /* a = ofdm out */
@@ -719,6 +734,71 @@ int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float
         memcpy(out + 2 * f * c->out_per_tf, a, n * 2 * sizeof(float));
     }
     return 0;
+}
+
+/* ---------------------------------------------------------------------------
+ * f-4 TII (reference src/TII.cpp).  The 70 patterns of EN 300 401 table 64 are the 8-bit
+ * words of weight 4 in increasing numerical order (:34-104), bit b = 0 being the leftmost. */
+static int tii_pattern_bit(int pattern, int b)
+{
+    int idx = 0;
+    for (int w = 0; w < 256; ++w) {
+        int pop = 0;
+        for (int i = 0; i < 8; ++i) pop += (w >> i) & 1;
+        if (pop != 4) continue;
+        if (idx == pattern) return (w >> (7 - b)) & 1;
+        ++idx;
+    }
+    return 0;
+}
+
+static int tii_enable_carrier(int carriers, int k, uint8_t *acp)
+{
+    const int ix = carriers / 2 + k + (k >= 0 ? -1 : 0);      /* :251-256 */
+    if (ix < 0 || ix + 1 >= carriers) return -1;               /* :258-260 */
+    acp[ix] = 1;
+    return 0;
+}
+
+int dabo_tii_pattern(int mode, int comb, int pattern, uint8_t *acp)
+{
+    if (mode != 1 && mode != 2) return -1;                     /* :119-145 */
+    if (pattern < 0 || pattern > 69 || comb < 0 || comb > 23) return -1;
+    const int carriers = mode == 1 ? 1536 : 384;
+    memset(acp, 0, (size_t)carriers);
+    int rc = 0;
+    if (mode == 1) {
+        /* :280-316: k = base + 2 comb + 48 b inside each quarter of the spectrum */
+        static const int base[4] = {-768, -384, 1, 385};
+        static const int last[4] = {-385, -1, 384, 768};
+        for (int q = 0; q < 4; ++q)
+            for (int b = 0; b < 8; ++b) {
+                const int k = base[q] + 2 * comb + 48 * b;
+                if (k <= last[q] && tii_pattern_bit(pattern, b)) rc |= tii_enable_carrier(carriers, k, acp);
+            }
+    } else {
+        /* :317-333: -192 + 2c + 48b for b < 4, -191 + 2c + 48b for b >= 4, k in [-192, 192] */
+        for (int b = 0; b < 8; ++b) {
+            const int k = (b < 4 ? -192 : -191) + 2 * comb + 48 * b;
+            if (k >= -192 && k <= 192 && tii_pattern_bit(pattern, b)) rc |= tii_enable_carrier(carriers, k, acp);
+        }
+    }
+    return rc;
+}
+
+void dabo_tii_process(const float *in, int carriers, const uint8_t *acp, int old_variant, int insert,
+                      float *out)
+{
+    memset(out, 0, sizeof(float) * 2 * (size_t)carriers);      /* :223-224 */
+    if (!insert) return;
+    for (int i = 0; i < carriers; ++i) {                        /* :186-210 */
+        if (!acp[i]) continue;
+        out[2 * i] = in[2 * i];
+        out[2 * i + 1] = in[2 * i + 1];
+        const int j = old_variant ? i + 1 : i;
+        out[2 * (i + 1)] = in[2 * j];
+        out[2 * (i + 1) + 1] = in[2 * j + 1];
+    }
 }
 
 /* ---------------------------------------------------------------------------

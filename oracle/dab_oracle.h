@@ -122,6 +122,16 @@ enum {
     DABO_STAGE_POLY     = 1 << 3
 };
 
+/* f-4 TII (reference src/TII.cpp:172-263,265-337).
+ * dabo_tii_pattern: acp[carriers] <- 1 where A_{c,p} is set, in the reference's own index
+ * convention (ix = K/2 + k - (k >= 0), :251-262).  Returns 0, or -1 for a mode other than I/II,
+ * comb outside [0,23], pattern outside [0,69] (the reference throws TIIError, :119-150).
+ * dabo_tii_process: out[K] <- 0; when insert != 0: for every set ix, out[ix] = in[ix],
+ * out[ix+1] = old_variant ? in[ix+1] : in[ix]   (:172-211; `in` is the phase reference symbol). */
+int dabo_tii_pattern(int mode, int comb, int pattern, uint8_t *acp);
+void dabo_tii_process(const float *in, int carriers, const uint8_t *acp, int old_variant, int insert,
+                      float *out);
+
 /* f-2 FormatConverter, float input path (reference src/FormatConverter.cpp:111-178).
  * fmt: 1 = s16, 2 = u8, 3 = s8.  n = number of FLOATS (2 per IQ sample); out holds n
  * int16_t / uint8_t / int8_t.  Returns the number of clipped components, or (size_t)-1
@@ -138,6 +148,9 @@ typedef struct {
     const float *taps; int ntaps;
     size_t in_rate, out_rate;      /* resampler */
     float am[5], pm[5];
+    /* f-4 TII (src/DabModulator.cpp:178-190,392-395): replaces the null symbol on every other
+     * frame of the stream, starting with the first */
+    int tii_enable, tii_comb, tii_pattern, tii_old_variant;
 } dabo_chain_cfg;
 
 typedef struct dabo_chain dabo_chain;

@@ -23,6 +23,7 @@
 #include "FIRFilter.h"
 #include "MemlessPoly.h"
 #include "FormatConverter.h"
+#include "TII.h"
 
 #include <cstring>
 #include <string>
@@ -168,6 +169,30 @@ int ref_memless_poly(const float *in, size_t nsamples, const char *coef_file,
         st.process(&b1, &bo);
         st.process(&b2, &bo);
         return copy_out(bo, out, nsamples * sizeof(complexf));
+    } catch (const std::exception &) { return -1; }
+}
+
+// f-4: TII fed by a PhaseReference, called ncalls times (the insert flag toggles per call).
+// out: ncalls x carriers complexf.  -1 on exception (TIIError for invalid mode/comb/pattern).
+int ref_tii(int mode, int enable, int comb, int pattern, int old_variant, int ncalls, float *out)
+{
+    try {
+        tii_config_t conf;
+        conf.enable = enable != 0;
+        conf.comb = comb;
+        conf.pattern = pattern;
+        conf.old_variant = old_variant != 0;
+        TII tii((unsigned)mode, conf, false);
+        PhaseReference ref((unsigned)mode, false);
+        Buffer bp, bo;
+        ref.process(&bp);
+        const size_t n = bp.getLength();
+        for (int i = 0; i < ncalls; ++i) {
+            tii.process(&bp, &bo);
+            if (bo.getLength() != n) return -2;
+            memcpy(reinterpret_cast<char *>(out) + (size_t)i * n, bo.getData(), n);
+        }
+        return 0;
     } catch (const std::exception &) { return -1; }
 }
 

@@ -99,6 +99,17 @@ def main():
             g["format_%s" % fmt] = {"sha256": sha(yo), "clipped": clipped}
             ye, ce = O.ref_format_convert(format_edges(fmt), fmt)
             g["format_edges_%s" % fmt] = {"out": [int(v) for v in ye], "clipped": ce}
+        # f-4 TII (modes I and II only): every comb x pattern, both variants, inserting and idle call
+        if mode in (1, 2):
+            for ov, name in ((0, "new"), (1, "old")):
+                allv = np.concatenate([O.ref_tii(mode, c, p, ov, True, 2).ravel()
+                                       for c in range(24) for p in range(70)])
+                g["tii_all_%s" % name] = {"sha256": sha(allv)}
+            one = O.ref_tii(mode, 3, 5, 0, True, 3)
+            g["tii_c3_p5"] = {"set": [int(i) for i in np.flatnonzero(one[0])], "head": head(one[0][one[0] != 0]),
+                              "idle_calls_all_zero": bool(not one[1].any()), "third_equals_first":
+                              bool(np.array_equal(one[0], one[2]))}
+            g["tii_disabled"] = {"all_zero": bool(not O.ref_tii(mode, 3, 5, 0, False, 2).any())}
         gold["modes"][str(mode)] = g
     with open(os.path.join(HERE, "golden.json"), "w") as fo:
         json.dump(gold, fo, indent=1, sort_keys=True)

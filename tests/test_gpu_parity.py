@@ -364,6 +364,123 @@ def test_chain_cfg4_resample_x4_and_poly(pkg):
     assert y.shape[1] == 4 * 196608
 
 
+# --------------------------------------------------------------------------- f-4 TII
+@pytest.mark.parametrize("mode", [1, 2])
+def test_tii_stage_bit_exact_vs_reference_golden(pkg, mode):
+    """TII::process through the C-ABI: every comb x pattern, both variants, inserting + idle call."""
+    g = GOLD[str(mode)]
+    md = pkg.Modulator(mode=mode, max_frames=1)
+    try:
+        pr = md.phase_reference()
+        for ov, name in ((False, "new"), (True, "old")):
+            parts = []
+            for c in range(24):
+                for p in range(70):
+                    md.set_tii(True, c, p, ov)
+                    parts += [md.tii(pr), md.tii(pr)]          # the insert flag toggles per call
+            assert sha(np.concatenate(parts)) == g["tii_all_%s" % name]["sha256"]
+        md.set_tii(True, 3, 5, False)
+        one = md.tii(pr)
+        assert [int(i) for i in np.flatnonzero(one)] == g["tii_c3_p5"]["set"]
+        assert not md.tii(pr).any()
+        md.set_tii(False, 3, 5, False)
+        assert not md.tii(pr).any() and not md.tii(pr).any()
+        with pytest.raises(pkg.DabGpuError, match="TII::process input size not valid"):
+            md.tii(pr[:-1])
+        for bad, msg in (((True, 24, 0), "comb not valid"), ((True, 0, 70), "pattern not valid")):
+            with pytest.raises(pkg.DabGpuError, match=msg):
+                md.set_tii(*bad)
+    finally:
+        md.close()
+
+
+def test_tii_is_rejected_for_modes_without_tii(pkg):
+    md = pkg.Modulator(mode=3, max_frames=1)
+    try:
+        with pytest.raises(pkg.DabGpuError, match="TII::TII DAB mode 3 not valid"):
+            md.set_tii(True, 0, 0)
+    finally:
+        md.close()
+
+
+def _tii_chain_case(pkg, mode, stages, oracle_kw, setup, tii=(3, 5, False), chunks=1):
+    """5 frames of one stream in calls of 3 + 2: frames 0, 2 and 4 carry TII."""
+    md = pkg.Modulator(mode=mode, max_frames=3, chunks_per_frame=chunks)
+    try:
+        setup(md)
+        md.set_tii(True, *tii)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=1100 + i) for i in range(5)])
+        y = np.concatenate([md.chain(bits[:3], stages), md.chain(bits[3:], stages)])
+        ref = O.Chain(mode=mode, stages=stages & 0xF, tii=tii, **oracle_kw).process(bits)
+        plain = O.Chain(mode=mode, stages=stages & 0xF, **oracle_kw).process(bits[:1])
+        assert y.shape == ref.shape
+        L = md.geometry["null_size"] * ref.shape[1] // O.tf_samples(mode)      # null segment at the output rate
+        for f in range(5):
+            assert rel_rms(y[f], ref[f]) < REL_RMS, (f, rel_rms(y[f], ref[f]))
+            if f % 2 == 0:
+                assert rel_rms(y[f][:L], ref[f][:L]) < 2e-6, (f, rel_rms(y[f][:L], ref[f][:L]))
+        # the oracle's TII frames really differ from a blank null symbol
+        assert np.linalg.norm(ref[0][:L] - plain[0][:L]) > 0.1 * np.linalg.norm(ref[0][:L])
+        return y, ref
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("chunks", [1, 5])
+def test_chain_cfg3_with_tii(pkg, mode, chunks):
+    _tii_chain_case(pkg, mode, pkg.STAGE_GAIN | pkg.STAGE_FIR, dict(gain_mode=2, normalise=1.0 / 50000.0),
+                    lambda md: md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0), chunks=chunks)
+
+
+@pytest.mark.parametrize("gain_mode", [0, 1])
+def test_chain_tii_other_gain_modes_and_old_variant(pkg, gain_mode):
+    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, dict(gain_mode=gain_mode),
+                    lambda md: md.set_gain(gain_mode, 1.0, 1.0, 4.0), tii=(23, 69, True))
+
+
+def test_chain_tii_without_gain_and_without_fir(pkg):
+    _tii_chain_case(pkg, 1, 0, {}, lambda md: None, tii=(0, 0, False))
+
+
+def test_chain_tii_windowed_guard(pkg):
+    def setup(md):
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_window_overlap(10)
+    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR,
+                    dict(gain_mode=2, normalise=1.0 / 50000.0, window_overlap=10), setup)
+
+
+def test_chain_cfg4_with_tii(pkg):
+    def setup(md):
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_resampler(2048000, 8192000)
+        md.set_poly(POLY_AM, POLY_PM)
+    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY,
+                    dict(gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000, am=POLY_AM, pm=POLY_PM), setup)
+
+
+def test_chain_tii_setting_change_rebuilds_the_segment(pkg):
+    """RC: comb / pattern change between frames takes effect at the next inserting frame."""
+    md = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_tii(True, 1, 2)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=1200 + i) for i in range(2)])
+        a = md.chain(bits, 3)
+        md.set_tii(True, 7, 9)
+        b = md.chain(bits, 3)
+        ra = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1 / 50000., tii=(1, 2, False)).process(bits)
+        rb = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1 / 50000., tii=(7, 9, False)).process(bits)
+        L = md.geometry["null_size"]
+        assert rel_rms(a[0][:L], ra[0][:L]) < 2e-6 and rel_rms(b[0][:L], rb[0][:L]) < 2e-6
+        assert rel_rms(a[0][:L], rb[0][:L]) > 0.1
+    finally:
+        md.close()
+
+
 # --------------------------------------------------------------------------- edge cases
 def test_size_checks_raise_like_the_reference(mods, pkg):
     md = mods[1]

@@ -78,3 +78,31 @@ def test_flowgraph_of_drop_in_stages_matches_oracle(tmp_path, mode):
     d = np.abs(got.astype(np.int32) - want.astype(np.int32))
     assert d.max() <= 1 and (d != 0).mean() < 1e-2
     assert "s16 chain: %d frames written" % n in r.stdout
+
+
+@pytest.mark.gpu
+def test_flowgraph_with_tii_matches_oracle(tmp_path):
+    """f-4: tiiRef -> TII -> cifSig (third input) in the stage graph, and tiiConfig in the fused plugin."""
+    import oracle as O
+    from tests.golden.synth import synth_bits
+    build_host()
+    n, mode, tii = 6, 1, (3, 5, False)
+    per = O.tf_input_bytes(mode)
+    bits = np.stack([synth_bits(per, seed=400 + i) for i in range(n)])
+    fbits, fgraph, fchain, fs16 = (str(tmp_path / x) for x in ("bits.bin", "graph.iq", "chain.iq", "chain.s16"))
+    bits.tofile(fbits)
+    r = subprocess.run([BIN, "gpu", str(mode), fbits, str(n), fgraph, fchain, repr(1.0 / 50000.0), fs16, "3,5"],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ref = O.Chain(mode=mode, stages=3, gain_mode=2, normalise=1.0 / 50000.0, tii=tii).process(bits)
+    tf, L = O.tf_samples(mode), O.mode_params(mode)["null_size"]
+    graph = np.fromfile(fgraph, dtype=np.complex64).reshape(-1, tf)
+    chain = np.fromfile(fchain, dtype=np.complex64).reshape(-1, tf)
+    assert graph.shape[0] == n - 2 and chain.shape[0] == n
+    for f in range(n):
+        for got in ([graph[f]] if f < n - 2 else []) + [chain[f]]:
+            assert np.linalg.norm(got - ref[f]) / np.linalg.norm(ref[f]) < 1e-6
+            if f % 2 == 0:       # frames 0, 2, 4 carry TII in their null symbol
+                assert np.linalg.norm(got[:L] - ref[f][:L]) / np.linalg.norm(ref[f][:L]) < 2e-6
+            else:
+                assert not got[:L - 44].any()

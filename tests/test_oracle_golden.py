@@ -88,6 +88,46 @@ def test_format_converter_bit_exact_vs_reference(mode, fmt):
     assert ce == g["format_edges_%s" % fmt]["clipped"]
 
 
+@pytest.mark.parametrize("mode", [1, 2])
+def test_tii_bit_exact_vs_reference(mode):
+    """f-4: every comb x pattern, old and new variant, inserting call and idle call."""
+    g = GOLD[str(mode)]
+    pr, _ = O.phase_reference(mode)
+    for ov, name in ((0, "new"), (1, "old")):
+        parts = []
+        for c in range(24):
+            for p in range(70):
+                acp = O.tii_pattern(mode, c, p)
+                parts += [O.tii_process(pr, acp, ov, True), O.tii_process(pr, acp, ov, False)]
+        assert sha(np.concatenate(parts)) == g["tii_all_%s" % name]["sha256"]
+    one = O.tii_process(pr, O.tii_pattern(mode, 3, 5), False, True)
+    assert [int(i) for i in np.flatnonzero(one)] == g["tii_c3_p5"]["set"]
+    assert g["tii_c3_p5"]["idle_calls_all_zero"] and g["tii_c3_p5"]["third_equals_first"]
+    assert g["tii_disabled"]["all_zero"]
+
+
+@pytest.mark.parametrize("args", [(3, 0, 0), (4, 0, 0), (1, 24, 0), (1, -1, 0), (1, 0, 70), (2, 0, -1)])
+def test_tii_rejects_what_the_reference_throws_on(args):
+    with pytest.raises(ValueError):
+        O.tii_pattern(*args)
+
+
+def test_chain_with_tii_alternates_frames():
+    """TII replaces the null symbol on frames 0, 2, 4 ... of a stream (TII::m_insert starts true)."""
+    bits = np.stack([synth_bits(O.tf_input_bytes(1), seed=60 + i) for i in range(3)])
+    plain = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1 / 50000.).process(bits)
+    tii = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1 / 50000., tii=(3, 5, False)).process(bits)
+    null = O.mode_params(1)["null_size"]
+    assert np.array_equal(plain[1], tii[1])
+    for f in (0, 2):
+        assert np.array_equal(plain[f][null:], tii[f][null:])
+        p_null = np.mean(np.abs(tii[f][:null - 44]) ** 2)
+        p_data = np.mean(np.abs(tii[f][null:]) ** 2)
+        assert not plain[f][:null - 44].any()
+        # 32 of 1536 carriers: 1/48 of the power of a data symbol (ETSI TR 101 496-3 5.4.2.2)
+        assert 0.7 / 48 < p_null / p_data < 1.4 / 48
+
+
 def test_format_converter_rejects_unknown_format():
     with pytest.raises(ValueError):
         O.format_convert(np.zeros(4, np.float32), "s32")
