@@ -143,6 +143,26 @@ DABGPU_API int dabgpu_resampler_process(dabgpu_ctx *ctx, const void *in, size_t 
 DABGPU_API int dabgpu_poly_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
                                    size_t out_cap, size_t *out_bytes);
 
+/* Crest-factor reduction inside OfdmGenerator: the constructor arguments / RC
+ * parameters cfr, clip, errorclip of OfdmGeneratorCF32 (src/OfdmGenerator.h:50-56, .cpp:376-404).
+ * When enabled every symbol is clipped, transformed forward, its error against the input
+ * constellation clipped, and transformed back (cfr_one_iteration, src/OfdmGenerator.cpp:310-373),
+ * in dabgpu_ofdm_process and in the chain entry points alike. */
+DABGPU_API int dabgpu_set_cfr(dabgpu_ctx *ctx, int enable, float clip, float error_clip);
+/* Per-frame raw statistics of the most recent call that ran with CFR on (frame = index inside that
+ * call); the reference's running averages (clip_stats, papr: src/OfdmGenerator.cpp:285-306,419-451,
+ * src/PAPRStats.cpp) are formed from these by the caller.  Waits for the call to finish. */
+typedef struct dabgpu_cfr_stats {
+    uint64_t num_clip, num_error_clip; /* samples / errors clipped in the frame (:275-276) */
+    uint64_t num_samples;              /* nbSymbols * spacing (:286) */
+    int mer_symbol;                    /* myMERCalcIndex of this frame (:198); 0 = no MER pushed (:250) */
+    double mer_sum_iq, mer_sum_delta;  /* the two sums of :262-266 for that symbol */
+    int nb_symbols;                    /* entries used below (transmission-frame symbols incl. null) */
+    double papr_before[154][2];        /* per symbol {peak, mean} of |x|^2 before CFR (PAPRStats::process_block) */
+    double papr_after[154][2];         /* after CFR; symbol 0 is not measured (:246-248) */
+} dabgpu_cfr_stats;
+DABGPU_API int dabgpu_get_cfr_stats(dabgpu_ctx *ctx, size_t frame, dabgpu_cfr_stats *out);
+
 /* TII.  dabgpu_set_tii = tii_config_t + the RC parameters enable / comb / pattern /
  * old_variant (src/TII.h:42-69, src/TII.cpp:339-372); invalid mode (only I and II carry TII), comb
  * outside [0,23] or pattern outside [0,69] is DABGPU_E_INVALID with the reference's TIIError text

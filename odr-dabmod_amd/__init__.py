@@ -29,7 +29,7 @@ EXPORTS = [
     "dabgpu_resampler_process", "dabgpu_poly_process", "dabgpu_chain_out_bytes_per_frame",
     "dabgpu_chain_process", "dabgpu_chain_process_dev", "dabgpu_symbols_process_dev",
     "dabgpu_synchronize", "dabgpu_time_chain_dev",
-    "dabgpu_set_tii", "dabgpu_tii_process", "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
+    "dabgpu_set_cfr", "dabgpu_get_cfr_stats", "dabgpu_set_tii", "dabgpu_tii_process", "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -51,6 +51,12 @@ def build(verbose=False):
 class _Config(C.Structure):
     _fields_ = [("mode", C.c_int), ("device", C.c_int), ("max_frames", C.c_int),
                 ("chunks_per_frame", C.c_int)]
+
+
+class _CfrStats(C.Structure):
+    _fields_ = [("num_clip", C.c_uint64), ("num_error_clip", C.c_uint64), ("num_samples", C.c_uint64),
+                ("mer_symbol", C.c_int), ("mer_sum_iq", C.c_double), ("mer_sum_delta", C.c_double),
+                ("nb_symbols", C.c_int), ("papr_before", C.c_double * 2 * 154), ("papr_after", C.c_double * 2 * 154)]
 
 
 class _Geometry(C.Structure):
@@ -103,6 +109,8 @@ def load_library():
     lib.dabgpu_chain_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_symbols_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_synchronize.argtypes = [vp]
+    lib.dabgpu_set_cfr.argtypes = [vp, C.c_int, C.c_float, C.c_float]
+    lib.dabgpu_get_cfr_stats.argtypes = [vp, sz, C.POINTER(_CfrStats)]
     lib.dabgpu_set_tii.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.dabgpu_tii_process.argtypes = [vp, vp, sz, vp, sz, szp]
     lib.dabgpu_format_size.argtypes = [C.c_int]
@@ -255,6 +263,21 @@ class Modulator:
     def poly(self, x):
         x = np.ascontiguousarray(x, np.complex64)
         return self._stage("poly", x, x.nbytes)
+
+    def set_cfr(self, enable, clip=1.0, error_clip=1.0):
+        """OfdmGenerator RC parameters cfr / clip / errorclip (src/OfdmGenerator.cpp:376-404)."""
+        self._chk(self._lib.dabgpu_set_cfr(self._h, int(enable), clip, error_clip))
+
+    def cfr_stats(self, frame=0):
+        """Raw CFR statistics of frame `frame` of the most recent call with CFR on."""
+        st = _CfrStats()
+        self._chk(self._lib.dabgpu_get_cfr_stats(self._h, frame, C.byref(st)))
+        n = st.nb_symbols
+        d = {k: getattr(st, k) for k in ("num_clip", "num_error_clip", "num_samples", "mer_symbol",
+                                         "mer_sum_iq", "mer_sum_delta", "nb_symbols")}
+        d["papr_before"] = np.array([[st.papr_before[i][0], st.papr_before[i][1]] for i in range(n)])
+        d["papr_after"] = np.array([[st.papr_after[i][0], st.papr_after[i][1]] for i in range(n)])
+        return d
 
     def set_tii(self, enable, comb=0, pattern=0, old_variant=False):
         self._chk(self._lib.dabgpu_set_tii(self._h, int(enable), comb, pattern, int(old_variant)))

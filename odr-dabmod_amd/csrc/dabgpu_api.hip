@@ -75,6 +75,8 @@ struct Settings {
     bool poly_is_lut = false;
     float am[5] = {1, 0, 0, 0, 0}, pm[5] = {0, 0, 0, 0, 0};
     float lut_scale = 0.f, lut[32] = {0};
+    bool cfr_enable = false;               // src/ConfigParser.h: enableCfr / cfrClip / cfrErrorClip
+    float cfr_clip = 1.0f, cfr_errclip = 1.0f;
     bool tii_enable = false, tii_old_variant = false;   // src/TII.h:42-69 (tii_config_t)
     int tii_comb = 0, tii_pattern = 0;
     unsigned long long epoch = 1;  // bumped by every setter
@@ -102,6 +104,12 @@ struct dabgpu_ctx {
     DevBuf d_a, d_b, d_c, d_in, d_out, d_count;
     // TII (f-4): carrier set, the one-frame carrier image and its native-rate response, gain of symbol 1
     DevBuf d_acp, d_tii_car, d_tii_frame, d_gain1;
+    // CFR statistics (f-3) of the most recent chain / OfdmGenerator call, and a scratch set for internal runs
+    DevBuf d_cfr_counts, d_cfr_mer, d_cfr_papr, d_cfr_tmp;
+    int cfr_mer_index = 0;                // myMERCalcIndex (src/OfdmGenerator.h:109): advances once per frame
+    int cfr_last_base = 0;
+    size_t cfr_last_frames = 0;
+    hipStream_t cfr_last_stream = nullptr;
     bool tii_insert = true;               // TII::m_insert (src/TII.h:112): this frame of the stream carries TII
     unsigned long long tii_seg_epoch = 0; // settings epoch / stage mask the cached segment was built for
     unsigned tii_seg_mask = ~0u;
@@ -401,9 +409,9 @@ size_t out_samples_per_frame(const dabgpu_ctx *c, unsigned mask, size_t L, size_
 // The native-rate part of the chain (everything up to and including FIRFilter) for n_frames frames
 // into native_out (`native` samples per frame).
 int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,
-               float2 *native_out, size_t native, float *gain1, hipStream_t s)
+               float2 *native_out, size_t native, float *gain1, hipStream_t s, bool keep_stats = true)
 {
-    TfArgs a;
+    TfArgs a{};
     a.g = c->g;
     a.t = tables_of(c);
     a.gain = gain_of(c);
@@ -414,6 +422,37 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
     a.gain1 = from_bits ? gain1 : nullptr;
     unsigned flags = from_bits ? TF_FROM_BITS : 0;
     if (mask & DABGPU_STAGE_GAIN) flags |= TF_GAIN;
+    if (c->cur.cfr_enable) {
+        // crest-factor reduction inside OfdmGenerator (f-3): statistics per frame, zeroed per call
+        const size_t nsym = (size_t)c->g.nb_symbols + 1;
+        const size_t b0 = n_frames * 2 * sizeof(unsigned), b1 = n_frames * 2 * sizeof(double),
+                     b2 = n_frames * nsym * 4 * sizeof(double);
+        flags |= TF_CFR;
+        a.cfr_clip = c->cur.cfr_clip;
+        a.cfr_errclip = c->cur.cfr_errclip;
+        if (keep_stats) {
+            HIPCHK(c, c->d_cfr_counts.reserve(b0));
+            HIPCHK(c, c->d_cfr_mer.reserve(b1));
+            HIPCHK(c, c->d_cfr_papr.reserve(b2));
+            a.cfr_counts = (unsigned *)c->d_cfr_counts.p;
+            a.cfr_mer = (double *)c->d_cfr_mer.p;
+            a.cfr_papr = (double *)c->d_cfr_papr.p;
+            a.cfr_mer_base = c->cfr_mer_index + 1;                       // src/OfdmGenerator.cpp:198
+            c->cfr_last_base = a.cfr_mer_base;
+            c->cfr_last_frames = n_frames;
+            c->cfr_last_stream = s;
+            c->cfr_mer_index = (int)((c->cfr_mer_index + n_frames) % nsym);
+        } else {
+            HIPCHK(c, c->d_cfr_tmp.reserve(b0 + b1 + b2 + 16));
+            a.cfr_mer = (double *)c->d_cfr_tmp.p;
+            a.cfr_papr = a.cfr_mer + n_frames * 2;
+            a.cfr_counts = (unsigned *)(a.cfr_papr + n_frames * nsym * 4);
+            a.cfr_mer_base = 0;
+        }
+        HIPCHK(c, hipMemsetAsync(a.cfr_counts, 0, b0, s));
+        HIPCHK(c, hipMemsetAsync(a.cfr_mer, 0, b1, s));
+        HIPCHK(c, hipMemsetAsync(a.cfr_papr, 0, b2, s));
+    }
 
     if (!windowed) {
         if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
@@ -495,7 +534,8 @@ int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t nativ
     HIPCHK(c, launch_phase_reference((const uint8_t *)c->d_phq.p, c->g.K, phase, s));
     HIPCHK(c, launch_tii(phase, (const uint8_t *)c->d_acp.p, c->g.K, c->cur.tii_old_variant ? 1 : 0, 1,
                          (float2 *)c->d_tii_car.p, s));
-    int rc = run_native(c, c->d_tii_car.p, false, 1, key, windowed, (float2 *)c->d_tii_frame.p, native, nullptr, s);
+    int rc = run_native(c, c->d_tii_car.p, false, 1, key, windowed, (float2 *)c->d_tii_frame.p, native, nullptr, s,
+                        false);
     if (rc) return rc;
     // the response of the null symbol: its own segment plus whatever a windowed guard interval spills
     // into the next one (zeros beyond; adding them is harmless)
@@ -527,7 +567,9 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     const bool post = mask & (DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY);
     const bool fir_fits = (int)c->cur.taps.size() - 1 <= c->g.sym_size - c->g.N &&
                           (int)c->cur.taps.size() <= tf_max_fused_taps();
-    const bool windowed = (c->cur.overlap > 0 || ((mask & DABGPU_STAGE_FIR) && !fir_fits)) &&
+    // one fused kernel, unless the guard interval is windowed, the filter does not fit it, or CFR is on
+    // (then: IFFT[+CFR][+gain] -> guard kernel -> FIR kernel)
+    const bool windowed = (c->cur.overlap > 0 || ((mask & DABGPU_STAGE_FIR) && !fir_fits) || c->cur.cfr_enable) &&
                           !(mask & DABGPU_STAGE_NOGUARD);
     if (windowed && c->cur.overlap > 0) {
         const size_t W = c->cur.overlap;
@@ -684,7 +726,8 @@ void dabgpu_destroy(dabgpu_ctx *c)
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
                       &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
-                      &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1})
+                      &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1,
+                      &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -734,6 +777,49 @@ int dabgpu_set_window_overlap(dabgpu_ctx *c, size_t overlap)
     std::lock_guard<std::mutex> lk(c->mu);
     c->set.overlap = overlap;
     ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_cfr(dabgpu_ctx *c, int enable, float clip, float error_clip)
+{
+    if (!c) return DABGPU_E_INVALID;
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->set.cfr_enable = enable != 0;
+    c->set.cfr_clip = clip;
+    c->set.cfr_errclip = error_clip;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_get_cfr_stats(dabgpu_ctx *c, size_t frame, dabgpu_cfr_stats *out)
+{
+    CTXCHK(c);
+    if (!out) return fail(c, DABGPU_E_INVALID, "null argument");
+    if (frame >= c->cfr_last_frames)
+        return fail(c, DABGPU_E_INVALID, "no CFR statistics for this frame (CFR off, or frame index out of range)");
+    const size_t nsym = (size_t)c->g.nb_symbols + 1;
+    HIPCHK(c, hipStreamSynchronize(c->cfr_last_stream ? c->cfr_last_stream : c->stream));
+    unsigned counts[2];
+    double mer[2];
+    std::vector<double> papr(nsym * 4);
+    HIPCHK(c, hipMemcpy(counts, (const unsigned *)c->d_cfr_counts.p + 2 * frame, sizeof counts, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(mer, (const double *)c->d_cfr_mer.p + 2 * frame, sizeof mer, hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemcpy(papr.data(), (const double *)c->d_cfr_papr.p + frame * nsym * 4, nsym * 4 * sizeof(double),
+                        hipMemcpyDeviceToHost));
+    std::memset(out, 0, sizeof *out);
+    out->num_clip = counts[0];
+    out->num_error_clip = counts[1];
+    out->num_samples = nsym * (size_t)c->g.N;
+    out->mer_symbol = (int)(((size_t)c->cfr_last_base + frame) % nsym);
+    out->mer_sum_iq = mer[0];
+    out->mer_sum_delta = mer[1];
+    out->nb_symbols = (int)nsym;
+    for (size_t s = 0; s < nsym; ++s) {
+        out->papr_before[s][0] = papr[4 * s];
+        out->papr_before[s][1] = papr[4 * s + 1];
+        out->papr_after[s][0] = papr[4 * s + 2];
+        out->papr_after[s][1] = papr[4 * s + 3];
+    }
     return DABGPU_OK;
 }
 

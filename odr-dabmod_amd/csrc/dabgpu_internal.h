@@ -52,9 +52,15 @@ struct TfArgs {
     float2 *out;
     size_t out_stride;        // samples per frame in `out`
     float *gain1;             // FROM_BITS, optional: per frame, the multiplier applied to symbol 1 (TII)
+    // TF_CFR: crest-factor reduction inside OfdmGenerator (f-3) and its statistics
+    float cfr_clip, cfr_errclip;
+    int cfr_mer_base;         // the MER symbol of frame f is (cfr_mer_base + f) % (nb_symbols + 1)
+    unsigned *cfr_counts;     // [frame][2]: clipped samples, clipped errors (pre-zeroed)
+    double *cfr_mer;          // [frame][2]: sum |before|^2, sum |after - before|^2 of the MER symbol (pre-zeroed)
+    double *cfr_papr;         // [frame][nb_symbols+1][4]: peak, mean of |x|^2 before / after CFR (pre-zeroed)
 };
 
-enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8 };
+enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16 };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags);

@@ -574,10 +574,14 @@ template <> struct ModeGeom<9> { static constexpr int nb_symbols = 76, K = 384, 
 template <> struct ModeGeom<8> { static constexpr int nb_symbols = 153, K = 192, null_size = 345, sym_size = 319; };
 template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768, null_size = 1328, sym_size = 1276; };
 
-template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT>
+// CFR (f-3, only without GUARD/FIR: the chain then continues with the stand-alone guard and FIR
+// kernels): crest-factor reduction of every symbol right after its IFFT, in registers -- clip, forward
+// FFT, error clip against the lane's own input bins, IFFT again -- plus the reference's statistics.
+template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8, FIR ? DABGPU_TF_WAVES : 2)
 void tf_kernel(const TfArgs a)
 {
+    static_assert(!CFR || (!GUARD && !FIR), "CFR variants stop after OfdmGenerator(+GainControl)");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
@@ -726,6 +730,96 @@ void tf_kernel(const TfArgs a)
         bitbuf[bit_slot] = fetch_block(s_begin - 2);   // (clamped; unused when the loop starts at s <= 1)
     }
 
+    // f-3 crest-factor reduction of one symbol held 8 samples per lane (reference
+    // src/OfdmGenerator.cpp:222-277 and cfr_one_iteration :310-373).  v: IFFT output in, CFR output
+    // out; refv: the lane's 8 input bins (a forward transform returns every bin to the lane it came
+    // from, so the error is formed in place).  stats: also the side statistics of symbol s.
+    auto cfr_symbol = [&](cf *v, const cf *refv, int s, bool stats) __attribute__((always_inline)) {
+        const float clip2 = a.cfr_clip * a.cfr_clip, eclip2 = a.cfr_errclip * a.cfr_errclip;   // :315, :339
+        const bool mer_sym = stats && s > 0 && s == (a.cfr_mer_base + frame) % nsym;             // :198, :250
+        cf before[8];
+        float pk = 0.f;
+        double sm = 0.;
+        unsigned nclip = 0, neclip = 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
+            pk = fmaxf(pk, mag2);
+            sm += (double)mag2;
+            before[m] = v[m];
+            if (mag2 > clip2) {                                   // :320-330
+                const float f = sqrtf(clip2 / mag2);
+                v[m] = cscale(v[m], f);
+                ++nclip;
+            }
+        }
+        if (stats) {
+            // PAPRStats::process_block before CFR (src/PAPRStats.cpp:41-60)
+            double dummy = 0.;
+            sm = lane_on ? sm : 0.;
+            pk = block_max<T>(lane_on ? pk : 0.f, red, t);
+            block_sum2<T>(sm, dummy, red, t);
+            if (t == 0) {
+                double *pp = a.cfr_papr + ((size_t)frame * nsym + s) * 4;
+                pp[0] = (double)pk;
+                pp[1] = sm / (double)N;
+            }
+        }
+        F::template run<-1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const cf c = cscale(v[m], 1.0f / (float)N);         // :349-350 (a power of two: exact)
+            cf e = csub(refv[m], c);
+            const float mag2 = e.x * e.x + e.y * e.y;
+            if (mag2 > eclip2) {                                  // :357-360
+                e = cscale(e, sqrtf(eclip2 / mag2));
+                ++neclip;
+            }
+            v[m] = cadd(c, e);
+        }
+        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+        if (stats) {
+            unsigned n1 = lane_on ? nclip : 0u, n2 = lane_on ? neclip : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { n1 += __shfl_xor(n1, o, 64); n2 += __shfl_xor(n2, o, 64); }
+            if ((t & 63) == 0) {
+                if (n1) atomicAdd(a.cfr_counts + 2 * (size_t)frame, n1);
+                if (n2) atomicAdd(a.cfr_counts + 2 * (size_t)frame + 1, n2);
+            }
+            if (s > 0) {                                          // :246-248: symbol 0 is skipped
+                float pk2 = 0.f;
+                double sm2 = 0., siq = 0., sdl = 0.;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
+                    pk2 = fmaxf(pk2, mag2);
+                    sm2 += (double)mag2;
+                    const cf d = csub(v[m], before[m]);
+                    siq += (double)(before[m].x * before[m].x + before[m].y * before[m].y);
+                    sdl += (double)(d.x * d.x + d.y * d.y);
+                }
+                double dummy = 0.;
+                sm2 = lane_on ? sm2 : 0.;
+                pk2 = block_max<T>(lane_on ? pk2 : 0.f, red, t);
+                block_sum2<T>(sm2, dummy, red, t);
+                if (t == 0) {
+                    double *pp = a.cfr_papr + ((size_t)frame * nsym + s) * 4;
+                    pp[2] = (double)pk2;
+                    pp[3] = sm2 / (double)N;
+                }
+                if (mer_sym) {                                    // :250-273 (wave-uniform branch)
+                    siq = lane_on ? siq : 0.;
+                    sdl = lane_on ? sdl : 0.;
+                    block_sum2<T>(siq, sdl, red, t);
+                    if (t == 0) {
+                        a.cfr_mer[2 * (size_t)frame] = siq;
+                        a.cfr_mer[2 * (size_t)frame + 1] = sdl;
+                    }
+                }
+            }
+        }
+    };
+
     // gain of the NULL symbol = gain computed on symbol 1 (reference
     // src/GainControl.cpp:139-144); only matters when symbol 0 is not blank.
     float g_null = 1.0f;
@@ -734,6 +828,11 @@ void tf_kernel(const TfArgs a)
         load_active(1, val);
         place(val, v);
         F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+        if (CFR) {
+            cf refv[8];
+            place(val, refv);
+            cfr_symbol(v, refv, 1, false);
+        }
         g_null = symbol_gain_fused<T>(v, a.gain, red + 8, tt, lane_on);
     }
 
@@ -800,7 +899,7 @@ void tf_kernel(const TfArgs a)
             if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
             pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
             load_active(s, val);
-            if (GAIN && a.gain.mode == 2) {
+            if (GAIN && !CFR && a.gain.mode == 2) {
                 // Gain statistics without touching the time domain.  With every carrier on the
                 // unit circle (times |y_s|) and a zero DC bin:
                 //   var(re) = |X|^2 (K/2 + S),  var(im) = |X|^2 (K/2 - S),
@@ -845,11 +944,16 @@ void tf_kernel(const TfArgs a)
         } else {
             place(val, v);
             F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+            if (CFR) {
+                cf refv[8];
+                place(val, refv);
+                cfr_symbol(v, refv, s, true);
+            }
         }
 
         float g = 1.0f;
         if (GAIN) {
-            if (FROM_BITS && a.gain.mode == 2) {
+            if (FROM_BITS && !CFR && a.gain.mode == 2) {
                 const float *redf = reinterpret_cast<const float *>(red + 8 * (s & 1));
                 float S = 0.f;
 #pragma unroll
@@ -957,9 +1061,17 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const size_t lds = tf_lds_bytes(LOGN, flags);
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
+#define TF_LAUNCH_CFR(FB, GN)                                                                  \
+    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, false, false, 0, true>), grid, block, lds, s, a)
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
+    if (flags & TF_CFR) {
+        if (gd || fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
+        if (fb) { if (gn) TF_LAUNCH_CFR(true, true); else TF_LAUNCH_CFR(true, false); }
+        else    { if (gn) TF_LAUNCH_CFR(false, true); else TF_LAUNCH_CFR(false, false); }
+        return hipGetLastError();
+    }
     if (fb) {
         if (gn) { if (fr) TF_LAUNCH(true, true, true, true); else if (gd) TF_LAUNCH(true, true, true, false); else TF_LAUNCH(true, true, false, false); }
         else    { if (fr) TF_LAUNCH(true, false, true, true); else if (gd) TF_LAUNCH(true, false, true, false); else TF_LAUNCH(true, false, false, false); }
@@ -968,6 +1080,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         else    { if (fr) TF_LAUNCH(false, false, true, true); else if (gd) TF_LAUNCH(false, false, true, false); else TF_LAUNCH(false, false, false, false); }
     }
 #undef TF_LAUNCH
+#undef TF_LAUNCH_CFR
     return hipGetLastError();
 }
 

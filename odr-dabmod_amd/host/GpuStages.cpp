@@ -9,6 +9,9 @@
 #include <cctype>
 #include <cstring>
 #include <fstream>
+#include <deque>
+#include <numeric>
+#include <cmath>
 #include <iomanip>
 #include <sstream>
 #include <stdexcept>
@@ -158,45 +161,128 @@ int SignalMultiplexer::process(std::vector<Buffer *> dataIn, Buffer *dataOut)
 
 // ---------------------------------------------------------------- OfdmGenerator
 OfdmGeneratorCF32::OfdmGeneratorCF32(size_t nbSymbols, size_t nbCarriers, size_t spacing,
-                                     bool &enableCfr, float &, float &, bool inverse)
+                                     bool &enableCfr, float &cfrClip, float &cfrErrorClip, bool inverse)
     : RemoteControllable("ofdm"), m_ctx(dabgpu_host::mode_from_spacing(spacing)),
-      m_nbSymbols(nbSymbols), m_nbCarriers(nbCarriers), m_spacing(spacing), m_cfr(enableCfr)
+      m_nbSymbols(nbSymbols), m_nbCarriers(nbCarriers), m_spacing(spacing), m_cfr(enableCfr),
+      m_cfrClip(cfrClip), m_cfrErrorClip(cfrErrorClip), m_paprBlocks(nbSymbols * 50)
 {
     if (nbCarriers > spacing) throw std::runtime_error("OfdmGenerator nbCarriers > spacing!");
     if (!inverse) throw std::runtime_error("OfdmGenerator: forward transform is not offloaded");
+    // reference src/OfdmGenerator.cpp:67-74
     RC_ADD_PARAMETER(cfr, "Enable crest factor reduction");
+    RC_ADD_PARAMETER(clip, "CFR: Clip to amplitude");
+    RC_ADD_PARAMETER(errorclip, "CFR: Limit error");
+    RC_ADD_PARAMETER(clip_stats, "CFR: statistics (clip ratio, errorclip ratio)");
+    RC_ADD_PARAMETER(papr, "PAPR measurements (before CFR, after CFR)");
 }
 
 int OfdmGeneratorCF32::process(Buffer *const dataIn, Buffer *dataOut)
 {
-    if (m_cfr) throw std::runtime_error("OfdmGenerator: crest factor reduction is not offloaded yet");
-    return run_codec(m_ctx, dabgpu_ofdm_process, dataIn, dataOut, m_nbSymbols * m_spacing * sizeof(complexf)) /
-           static_cast<int>(sizeof(complexf));
+    bool cfr;
+    {
+        std::lock_guard<std::mutex> lock(m_mutex);
+        cfr = m_cfr;
+        m_ctx.check(dabgpu_set_cfr(m_ctx.get(), m_cfr ? 1 : 0, m_cfrClip, m_cfrErrorClip));
+    }
+    if (m_paprClearRequest.exchange(false)) {            // reference :202-205
+        m_paprBefore.clear();
+        m_paprAfter.clear();
+    }
+    const int n = run_codec(m_ctx, dabgpu_ofdm_process, dataIn, dataOut, m_nbSymbols * m_spacing * sizeof(complexf)) /
+                  static_cast<int>(sizeof(complexf));
+    if (cfr) {
+        // the reference's running statistics (src/OfdmGenerator.cpp:232,246-306) from the raw per-frame figures
+        dabgpu_cfr_stats st;
+        m_ctx.check(dabgpu_get_cfr_stats(m_ctx.get(), 0, &st));
+        std::lock_guard<std::mutex> lock(m_mutex);
+        auto push = [](std::deque<double> &d, double v, size_t cap) {
+            d.push_back(v);
+            while (d.size() > cap) d.pop_front();
+        };
+        for (int s = 0; s < st.nb_symbols; ++s) {
+            push(m_paprBefore, st.papr_before[s][0], 2 * m_paprBlocks);   // stored as (peak, mean) pairs
+            push(m_paprBefore, st.papr_before[s][1], 2 * m_paprBlocks);
+            if (s > 0) {
+                push(m_paprAfter, st.papr_after[s][0], 2 * m_paprBlocks);
+                push(m_paprAfter, st.papr_after[s][1], 2 * m_paprBlocks);
+            }
+        }
+        constexpr size_t MAX_CLIP_STATS = 10;                               // :38
+        push(m_clipRatios, static_cast<double>(st.num_clip) / static_cast<double>(st.num_samples), MAX_CLIP_STATS);
+        push(m_errorClipRatios, static_cast<double>(st.num_error_clip) / static_cast<double>(st.num_samples),
+             MAX_CLIP_STATS);
+        if (st.mer_symbol > 0)
+            push(m_mers, st.mer_sum_delta > 0 ? 10.0 * std::log10(st.mer_sum_iq / st.mer_sum_delta) : 90.0,
+                 MAX_CLIP_STATS);
+    }
+    return n;
+}
+
+// PAPRStats::calculate_papr (reference src/PAPRStats.cpp:74-103) over stored (peak, mean) pairs
+double OfdmGeneratorCF32::papr_db(const std::deque<double> &pairs) const
+{
+    if (pairs.size() / 2 < m_paprBlocks) return 0;
+    double peak = 0, rms2 = 0;
+    for (size_t i = 0; i + 1 < pairs.size(); i += 2) {
+        peak = std::max(peak, pairs[i]);
+        rms2 += pairs[i + 1];
+    }
+    rms2 /= static_cast<double>(pairs.size() / 2);
+    return 10.0 * std::log10(peak / rms2);
 }
 
 void OfdmGeneratorCF32::set_parameter(const std::string &parameter, const std::string &value)
 {
+    std::stringstream ss(value);
+    ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
+    std::lock_guard<std::mutex> lock(m_mutex);
     if (parameter == "cfr") {
-        std::stringstream ss(value);
-        bool on = false;
-        ss >> on;
-        if (on) throw ParameterError("crest factor reduction is not offloaded yet");
-        m_cfr = false;
+        ss >> m_cfr;
+    } else if (parameter == "clip") {
+        ss >> m_cfrClip;
+    } else if (parameter == "errorclip") {
+        ss >> m_cfrErrorClip;
+    } else if (parameter == "clip_stats" || parameter == "papr") {
+        throw ParameterError("Parameter '" + parameter + "' is read-only");
     } else {
         dabgpu_host::not_exported(parameter, get_rc_name());
     }
+    m_paprClearRequest.store(true);
 }
 
 const std::string OfdmGeneratorCF32::get_parameter(const std::string &parameter) const
 {
-    if (parameter == "cfr") return m_cfr ? "1" : "0";
-    dabgpu_host::not_exported(parameter, get_rc_name());
+    std::stringstream ss;
+    std::lock_guard<std::mutex> lock(m_mutex);
+    if (parameter == "cfr") {
+        ss << m_cfr;
+    } else if (parameter == "clip") {
+        ss << std::fixed << m_cfrClip;
+    } else if (parameter == "errorclip") {
+        ss << std::fixed << m_cfrErrorClip;
+    } else if (parameter == "clip_stats") {
+        if (m_clipRatios.empty() || m_errorClipRatios.empty() || m_mers.empty()) {
+            ss << "No stats available";
+        } else {
+            auto avg = [](const std::deque<double> &d) {
+                return std::accumulate(d.begin(), d.end(), 0.0) / static_cast<double>(d.size());
+            };
+            ss << "Statistics : " << std::fixed << avg(m_clipRatios) * 100 << "% samples clipped, "
+               << avg(m_errorClipRatios) * 100 << "% errors clipped. MER after CFR: " << avg(m_mers) << " dB";
+        }
+    } else if (parameter == "papr") {
+        const double before = papr_db(m_paprBefore), after = papr_db(m_paprAfter);
+        ss << "PAPR [dB]: " << std::fixed << (before == 0 ? std::string("N/A") : std::to_string(before)) << ", "
+           << (after == 0 ? std::string("N/A") : std::to_string(after));
+    } else {
+        dabgpu_host::not_exported(parameter, get_rc_name());
+    }
+    return ss.str();
 }
 
 const json::map_t OfdmGeneratorCF32::get_all_values() const
 {
-    json::map_t m;
-    m["cfr"].v = m_cfr;
+    json::map_t m;   // (empty in the reference too: "TODO needs rework of the values", :453-458)
     return m;
 }
 
@@ -692,6 +778,7 @@ DabGpuChain::DabGpuChain(const Settings &s) : m_ctx(static_cast<int>(s.dabMode),
                                     s.gainmodeVariance));
     }
     m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), s.ofdmWindowOverlap));
+    if (s.enableCfr) m_ctx.check(dabgpu_set_cfr(m_ctx.get(), 1, s.cfrClip, s.cfrErrorClip));
     if (s.tiiConfig.enable)
         m_ctx.check(dabgpu_set_tii(m_ctx.get(), 1, s.tiiConfig.comb, s.tiiConfig.pattern, s.tiiConfig.old_variant));
     if (!s.filterTapsFilename.empty()) {

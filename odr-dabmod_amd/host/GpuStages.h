@@ -16,6 +16,7 @@
 #include "RemoteControl.h"
 
 #include <atomic>
+#include <deque>
 #include <mutex>
 #include <stdexcept>
 #include <string>
@@ -108,7 +109,8 @@ public:
     const char *name() override { return "SignalMultiplexer"; }
 };
 
-// reference src/OfdmGenerator.h:50-56, .cpp:42-308 (CFR not supported: next row f-3)
+// reference src/OfdmGenerator.h:50-56, .cpp:42-308; crest-factor reduction (f-3) and its RC statistics
+// clip_stats / papr (:376-451) included
 class OfdmGeneratorCF32 : public ModCodec, public RemoteControllable {
 public:
     OfdmGeneratorCF32(size_t nbSymbols, size_t nbCarriers, size_t spacing, bool &enableCfr,
@@ -120,9 +122,15 @@ public:
     const json::map_t get_all_values() const override;
 
 private:
+    double papr_db(const std::deque<double> &pairs) const;
     dabgpu_host::Context m_ctx;
     size_t m_nbSymbols, m_nbCarriers, m_spacing;
     bool &m_cfr;
+    float &m_cfrClip, &m_cfrErrorClip;
+    mutable std::mutex m_mutex;
+    std::atomic<bool> m_paprClearRequest{false};
+    size_t m_paprBlocks;                                   // PAPRStats(nbSymbols * 50), reference :60-61
+    std::deque<double> m_clipRatios, m_errorClipRatios, m_mers, m_paprBefore, m_paprAfter;
 };
 
 // reference src/GainControl.h:47-91, .cpp:48-192, RC :505-572
@@ -285,6 +293,8 @@ public:
         std::string polyCoefFilename;     // "" = no predistortion
         size_t ofdmWindowOverlap = 0;
         tii_config_t tiiConfig;           // TII on every other frame of the stream (modes I and II)
+        bool enableCfr = false;           // crest-factor reduction inside OfdmGenerator
+        float cfrClip = 1.0f, cfrErrorClip = 1.0f;
     };
     explicit DabGpuChain(const Settings &s);
     int process(Buffer *const dataIn, Buffer *dataOut) override;

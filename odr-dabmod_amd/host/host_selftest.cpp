@@ -245,7 +245,7 @@ std::vector<uint8_t> read_all(const std::string &path)
 int run_gpu(int argc, char **argv)
 {
     if (argc < 7) {
-        std::fprintf(stderr, "usage: host_selftest gpu <mode> <bits.bin> <nframes> <graph.iq> <chain.iq> [normalise] [chain.s16] [tii comb,pattern]\n");
+        std::fprintf(stderr, "usage: host_selftest gpu <mode> <bits.bin> <nframes> <graph.iq> <chain.iq> [normalise] [chain.s16] [tii comb,pattern | -] [cfr clip,errorclip]\n");
         return 2;
     }
     const unsigned mode = static_cast<unsigned>(std::atoi(argv[2]));
@@ -268,10 +268,16 @@ int run_gpu(int argc, char **argv)
     std::string tapsFile = "default";
     // optional: TII "comb,pattern" (SURVEY 8 f-4), wired like src/DabModulator.cpp:178-190,392-395
     tii_config_t tiiConfig;
-    if (argc > 9) {
+    if (argc > 9 && std::string(argv[9]) != "-") {
         if (std::sscanf(argv[9], "%d,%d", &tiiConfig.comb, &tiiConfig.pattern) != 2)
             throw std::runtime_error("tii argument: comb,pattern");
         tiiConfig.enable = true;
+    }
+    // optional: crest-factor reduction "clip,errorclip" 
+    if (argc > 10) {
+        if (std::sscanf(argv[10], "%f,%f", &cfrClip, &cfrErrorClip) != 2)
+            throw std::runtime_error("cfr argument: clip,errorclip");
+        enableCfr = true;
     }
 
     {
@@ -314,6 +320,16 @@ int run_gpu(int argc, char **argv)
         // remote control through the stage interface
         cifGain->set_parameter("mode", "VAR");
         if (cifGain->get_parameter("mode") != "var") throw std::runtime_error("RC mode round trip failed");
+        if (enableCfr) {
+            // RC statistics of the OfdmGenerator drop-in (reference src/OfdmGenerator.cpp:419-451)
+            auto *ofdm = dynamic_cast<OfdmGeneratorCF32 *>(cifOfdm.get());
+            std::printf("ofdm clip_stats: %s\nofdm papr: %s\n", ofdm->get_parameter("clip_stats").c_str(),
+                        ofdm->get_parameter("papr").c_str());
+            bool threw = false;
+            try { ofdm->set_parameter("papr", "1"); } catch (const ParameterError &) { threw = true; }
+            if (!threw) throw std::runtime_error("papr must be read-only");
+            if (ofdm->get_parameter("cfr") != "1") throw std::runtime_error("RC cfr read-back failed");
+        }
         if (tii) {
             const int comb0 = tiiConfig.comb;      // the stage holds a reference into tiiConfig
             tii->set_parameter("comb", "7");
@@ -333,6 +349,9 @@ int run_gpu(int argc, char **argv)
         s.normalise = normalise;
         s.filterTapsFilename = "default";
         s.tiiConfig = tiiConfig;
+        s.enableCfr = enableCfr;
+        s.cfrClip = cfrClip;
+        s.cfrErrorClip = cfrErrorClip;
         auto cifPart = std::make_shared<BlockSource>(bits, block);
         auto chain = std::make_shared<DabGpuChain>(s);
         auto output = std::make_shared<FileSink>(argv[6]);

@@ -41,7 +41,13 @@ class _ChainCfg(C.Structure):
                 ("in_rate", C.c_size_t), ("out_rate", C.c_size_t),
                 ("am", C.c_float * 5), ("pm", C.c_float * 5),
                 ("tii_enable", C.c_int), ("tii_comb", C.c_int), ("tii_pattern", C.c_int),
-                ("tii_old_variant", C.c_int)]
+                ("tii_old_variant", C.c_int),
+                ("cfr_enable", C.c_int), ("cfr_clip", C.c_float), ("cfr_error_clip", C.c_float)]
+
+
+class _CfrStats(C.Structure):
+    _fields_ = [("num_clip", C.c_size_t), ("num_error_clip", C.c_size_t), ("mer_sum_iq", C.c_double),
+                ("mer_sum_delta", C.c_double), ("mer_db", C.c_double)]
 
 
 _FP = C.POINTER(C.c_float)
@@ -92,6 +98,10 @@ def _load(name):
     lib.dabo_memless_poly.restype = None
     lib.dabo_memless_lut.argtypes = [_FP, C.c_size_t, C.c_float, _FP, _FP]
     lib.dabo_memless_lut.restype = None
+    lib.dabo_ofdm_generate_cfr.argtypes = [_FP, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_int, _FP,
+                                           C.POINTER(_CfrStats), C.POINTER(C.c_double)]
+    lib.dabo_papr_db.argtypes = [C.POINTER(C.c_double), C.c_size_t]
+    lib.dabo_papr_db.restype = C.c_double
     lib.dabo_tii_pattern.argtypes = [C.c_int, C.c_int, C.c_int, _U8P]
     lib.dabo_tii_process.argtypes = [_FP, C.c_int, _U8P, C.c_int, C.c_int, _FP]
     lib.dabo_tii_process.restype = None
@@ -104,6 +114,8 @@ def _load(name):
     lib.dabo_chain_out_samples_per_tf.argtypes = [C.c_void_p]
     lib.dabo_chain_out_samples_per_tf.restype = C.c_size_t
     lib.dabo_chain_process.argtypes = [C.c_void_p, _U8P, C.c_size_t, _FP]
+    lib.dabo_chain_cfr_stats.argtypes = [C.c_void_p, C.c_size_t, C.POINTER(C.c_double)]
+    lib.dabo_chain_cfr_stats.restype = C.POINTER(_CfrStats)
     lib.dabo_dft_f64.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int]
     lib.dabo_dft_f64.restype = None
     return lib
@@ -281,6 +293,22 @@ def memless_lut(x, scalefactor, lut):
     return out
 
 
+def ofdm_generate_cfr(x, nsym, carriers, spacing, clip, error_clip, mer_index):
+    """f-3: OfdmGenerator with CFR.  Returns (samples, stats dict, papr[nsym][4])."""
+    x = _c64(x)
+    out = np.empty(nsym * spacing, np.complex64)
+    st = _CfrStats()
+    papr = np.zeros((nsym, 4), np.float64)
+    _chk(lib().dabo_ofdm_generate_cfr(_fp(x), nsym, carriers, spacing, clip, error_clip, mer_index, _fp(out),
+                                      C.byref(st), papr.ctypes.data_as(C.POINTER(C.c_double))), "ofdm_cfr")
+    return out, {n: getattr(st, n) for n, _ in _CfrStats._fields_}, papr
+
+
+def papr_db(pairs):
+    pairs = np.ascontiguousarray(pairs, np.float64).reshape(-1, 2)
+    return float(lib().dabo_papr_db(pairs.ctypes.data_as(C.POINTER(C.c_double)), pairs.shape[0]))
+
+
 def tii_pattern(mode, comb, pattern):
     """f-4: A_{c,p} as a uint8 mask over the carriers (reference index convention)."""
     K = mode_params(mode)["carriers"]
@@ -326,8 +354,9 @@ class Chain:
 
     def __init__(self, mode=1, stages=0, gain_mode=GAIN_VAR, dig_gain=1.0, normalise=1.0,
                  var_variance=4.0, window_overlap=0, taps=None, in_rate=2048000,
-                 out_rate=2048000, am=(1, 0, 0, 0, 0), pm=(0, 0, 0, 0, 0), fast=False, tii=None):
-        """tii = (comb, pattern, old_variant) inserts TII on every other frame, or None."""
+                 out_rate=2048000, am=(1, 0, 0, 0, 0), pm=(0, 0, 0, 0, 0), fast=False, tii=None, cfr=None):
+        """tii = (comb, pattern, old_variant) inserts TII on every other frame, or None.
+        cfr = (clip, error_clip) enables crest-factor reduction inside OfdmGenerator."""
         self._l = fast_lib() if fast else lib()
         cfg = _ChainCfg()
         cfg.mode, cfg.stages, cfg.gain_mode = mode, stages, gain_mode
@@ -340,6 +369,8 @@ class Chain:
         cfg.pm = (C.c_float * 5)(*pm)
         if tii is not None:
             cfg.tii_enable, cfg.tii_comb, cfg.tii_pattern, cfg.tii_old_variant = 1, tii[0], tii[1], int(tii[2])
+        if cfr is not None:
+            cfg.cfr_enable, cfg.cfr_clip, cfg.cfr_error_clip = 1, cfr[0], cfr[1]
         self.mode = mode
         self._h = self._l.dabo_chain_create(C.byref(cfg))
         if not self._h:
@@ -355,6 +386,15 @@ class Chain:
         out = np.empty(n * self.out_samples_per_tf, np.complex64)
         _chk(self._l.dabo_chain_process(self._h, bits.ctypes.data_as(_U8P), n, _fp(out)), "chain")
         return out.reshape(n, self.out_samples_per_tf)
+
+    def cfr_stats(self, frame):
+        """CFR statistics of frame `frame` of the last process() call: (dict, papr[nsym][4]) or None."""
+        nsym = mode_params(self.mode)["nb_symbols"] + 1
+        papr = np.zeros((nsym, 4), np.float64)
+        p = self._l.dabo_chain_cfr_stats(self._h, frame, papr.ctypes.data_as(C.POINTER(C.c_double)))
+        if not p:
+            return None
+        return {n: getattr(p.contents, n) for n, _ in _CfrStats._fields_}, papr
 
     def __del__(self):
         if getattr(self, "_h", None):
@@ -388,6 +428,8 @@ def ref():
         r.ref_fir_filter.argtypes = [_FP, C.c_size_t, C.c_char_p, _FP]
         r.ref_memless_poly.argtypes = [_FP, C.c_size_t, C.c_char_p, C.c_uint, _FP]
         r.ref_tii.argtypes = [C.c_int] * 6 + [_FP]
+        r.ref_papr.argtypes = [_FP, C.c_size_t, C.c_size_t, C.c_size_t]
+        r.ref_papr.restype = C.c_double
         r.ref_format_convert.argtypes = [_FP, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t,
                                          C.POINTER(C.c_size_t)]
         _ref = r
@@ -487,6 +529,11 @@ def ref_memless_poly(x, coef_file, num_threads=1):
     _rchk(ref().ref_memless_poly(_fp(x), x.size, coef_file.encode(), num_threads, _fp(out)),
           "memless_poly")
     return out
+
+
+def ref_papr(x, blocklen, accumulate):
+    x = _c64(x)
+    return float(ref().ref_papr(_fp(x), x.size // blocklen, blocklen, accumulate))
 
 
 def ref_tii(mode, comb, pattern, old_variant=False, enable=True, ncalls=2):

@@ -284,6 +284,105 @@ int dabo_ofdm_generate(const float *in, int nsym, int carriers, int spacing, flo
     return 0;
 }
 
+/* f-3: the same loop with crest-factor reduction enabled (src/OfdmGenerator.cpp:207-283 with
+ * myCfr, cfr_one_iteration :310-373). */
+static void papr_block(const float *x, size_t n, double *peak, double *mean)
+{
+    /* PAPRStats::process_block, src/PAPRStats.cpp:41-60: std::norm in float, accumulated in double */
+    double pk = 0, rms2 = 0;
+    for (size_t i = 0; i < n; ++i) {
+        const float re = x[2 * i], im = x[2 * i + 1];
+        const double nrm = (double)(re * re + im * im);
+        if (nrm > pk) pk = nrm;
+        rms2 += nrm;
+    }
+    *peak = pk;
+    *mean = rms2 / (double)n;
+}
+
+int dabo_ofdm_generate_cfr(const float *in, int nsym, int carriers, int spacing, float clip,
+                           float error_clip, int mer_index, float *out, dabo_cfr_stats *st, double *papr)
+{
+    const size_t K = (size_t)carriers, N = (size_t)spacing;
+    if (K > N || (N & (N - 1)) != 0) return -1;
+    const size_t pos_dst = (K & 1) ? 0 : 1, pos_n = (K + 1) / 2, neg_dst = N - K / 2, neg_n = K / 2;
+    float *ref = (float *)malloc(2 * N * sizeof(float));      /* `reference`, :222-226 */
+    float *sym = (float *)malloc(2 * N * sizeof(float));      /* myFftOut */
+    float *before = (float *)malloc(2 * N * sizeof(float));   /* before_cfr, :234-238 */
+    float *post = (float *)malloc(2 * N * sizeof(float));     /* myCfrPostFft */
+    float *fin = (float *)malloc(2 * N * sizeof(float));      /* myFftIn, second pass */
+    double *w0 = (double *)malloc(2 * N * sizeof(double)), *w1 = (double *)malloc(2 * N * sizeof(double));
+    if (!ref || !sym || !before || !post || !fin || !w0 || !w1) return -1;
+    dabo_cfr_stats s0 = {0, 0, 0.0, 0.0, NAN};
+    const float clip_squared = clip * clip;                    /* :315 */
+    const float err_clip_squared = error_clip * error_clip;    /* :339 */
+    for (int s = 0; s < nsym; ++s) {
+        const float *i = in + 2 * (size_t)s * K;
+        memset(ref, 0, 2 * N * sizeof(float));
+        memcpy(ref + 2 * pos_dst, i, 2 * pos_n * sizeof(float));
+        memcpy(ref + 2 * neg_dst, i + 2 * pos_n, 2 * neg_n * sizeof(float));
+        dft_f32_via_f64(ref, sym, N, +1, w0, w1);              /* :228 */
+        double *pp = papr ? papr + 4 * (size_t)s : NULL;
+        if (pp) { papr_block(sym, N, &pp[0], &pp[1]); pp[2] = pp[3] = 0.0; }   /* :232 */
+        if (mer_index == s) memcpy(before, sym, 2 * N * sizeof(float));
+        /* clip, :320-330 */
+        for (size_t n = 0; n < N; ++n) {
+            const float mag_squared = sym[2 * n] * sym[2 * n] + sym[2 * n + 1] * sym[2 * n + 1];
+            if (mag_squared > clip_squared) {
+                const float f = sqrtf(clip_squared / mag_squared);
+                sym[2 * n] *= f;
+                sym[2 * n + 1] *= f;
+                ++s0.num_clip;
+            }
+        }
+        dft_f32_via_f64(sym, post, N, -1, w0, w1);             /* :333-334 */
+        /* error in the frequency domain, clipped, :341-366 */
+        for (size_t k = 0; k < N; ++k) {
+            const float cr = post[2 * k] / (float)N, ci = post[2 * k + 1] / (float)N;
+            float er = ref[2 * k] - cr, ei = ref[2 * k + 1] - ci;
+            const float mag_squared = er * er + ei * ei;
+            if (mag_squared > err_clip_squared) {
+                const float f = sqrtf(err_clip_squared / mag_squared);
+                er *= f;
+                ei *= f;
+                ++s0.num_error_clip;
+            }
+            fin[2 * k] = cr + er;
+            fin[2 * k + 1] = ci + ei;
+        }
+        dft_f32_via_f64(fin, sym, N, +1, w0, w1);              /* :369-370 */
+        if (s > 0 && pp) papr_block(sym, N, &pp[2], &pp[3]);   /* :246-248 */
+        if (s > 0 && mer_index == s) {                          /* :250-273 */
+            double sum_iq = 0, sum_delta = 0;
+            for (size_t n = 0; n < N; ++n) {
+                const float br = before[2 * n], bi = before[2 * n + 1];
+                const float dr = sym[2 * n] - br, di = sym[2 * n + 1] - bi;
+                sum_iq += (double)(br * br + bi * bi);
+                sum_delta += (double)(dr * dr + di * di);
+            }
+            s0.mer_sum_iq = sum_iq;
+            s0.mer_sum_delta = sum_delta;
+            s0.mer_db = sum_delta > 0 ? 10.0 * log10(sum_iq / sum_delta) : 90.0;
+        }
+        memcpy(out + 2 * (size_t)s * N, sym, 2 * N * sizeof(float));
+    }
+    if (st) *st = s0;
+    free(ref); free(sym); free(before); free(post); free(fin); free(w0); free(w1);
+    return 0;
+}
+
+/* PAPRStats::calculate_papr, src/PAPRStats.cpp:74-103 */
+double dabo_papr_db(const double *pm, size_t nblocks)
+{
+    double peak = 0, rms2 = 0;
+    for (size_t i = 0; i < nblocks; ++i) {
+        if (pm[2 * i] > peak) peak = pm[2 * i];
+        rms2 += pm[2 * i + 1];
+    }
+    rms2 /= (double)nblocks;
+    return 10.0 * log10(peak / rms2);
+}
+
 /* ------------------------------------------------------------------- a7 */
 
 /* The reference's x86 build runs the SSE code, which views a symbol of N
@@ -638,6 +737,8 @@ struct dabo_chain {
     float *phase;           /* K */
     float *a, *b;           /* ping-pong scratch */
     size_t out_per_tf;
+    int mer_index;          /* myMERCalcIndex, src/OfdmGenerator.h:109 */
+    dabo_cfr_stats *cfr_stats; double *cfr_papr; size_t cfr_frames;   /* last call */
     uint8_t *acp;           /* TII carrier set, K */
     int tii_insert;         /* TII::m_insert, src/TII.h:112 (starts true, toggles per frame) */
 };
@@ -681,11 +782,19 @@ void dabo_chain_destroy(dabo_chain *c)
 {
     if (!c) return;
     dabo_resampler_destroy(c->rs);
-    free(c->taps); free(c->phase); free(c->a); free(c->b); free(c->acp);
+    free(c->taps); free(c->phase); free(c->a); free(c->b); free(c->acp); free(c->cfr_stats); free(c->cfr_papr);
     free(c);
 }
 
 size_t dabo_chain_out_samples_per_tf(const dabo_chain *c) { return c->out_per_tf; }
+
+const dabo_cfr_stats *dabo_chain_cfr_stats(const dabo_chain *c, size_t f, double *papr)
+{
+    if (!c->cfg.cfr_enable || !c->cfr_stats || f >= c->cfr_frames) return NULL;
+    const size_t nsym = (size_t)c->m.nb_symbols + 1;
+    if (papr) memcpy(papr, c->cfr_papr + f * nsym * 4, nsym * 4 * sizeof(double));
+    return &c->cfr_stats[f];
+}
 
 int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float *out)
 {
@@ -693,6 +802,12 @@ int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float
     const size_t K = (size_t)m->carriers, N = (size_t)m->spacing;
     const size_t ndata = (size_t)(m->nb_symbols - 1) * K, nsym = (size_t)m->nb_symbols + 1;
     const size_t tf = dabo_tf_samples(m), inb = dabo_tf_input_bytes(m);
+    if (c->cfg.cfr_enable) {
+        free(c->cfr_stats); free(c->cfr_papr);
+        c->cfr_stats = (dabo_cfr_stats *)calloc(nframes ? nframes : 1, sizeof(dabo_cfr_stats));
+        c->cfr_papr = (double *)calloc((nframes ? nframes : 1) * nsym * 4, sizeof(double));
+        c->cfr_frames = nframes;
+    }
     for (size_t f = 0; f < nframes; ++f) {
         float *a = c->a, *b = c->b, *t;
         int rc = 0;
@@ -706,7 +821,14 @@ int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float
             c->tii_insert = !c->tii_insert;
         }
         rc |= dabo_diff_mod(c->phase, b, ndata, m->carriers, a + 2 * K);
-        rc |= dabo_ofdm_generate(a, (int)nsym, m->carriers, m->spacing, b);
+        if (c->cfg.cfr_enable) {
+            c->mer_index = (c->mer_index + 1) % (int)nsym;           /* src/OfdmGenerator.cpp:198 */
+            rc |= dabo_ofdm_generate_cfr(a, (int)nsym, m->carriers, m->spacing, c->cfg.cfr_clip,
+                                         c->cfg.cfr_error_clip, c->mer_index, b, &c->cfr_stats[f],
+                                         c->cfr_papr + f * nsym * 4);
+        } else {
+            rc |= dabo_ofdm_generate(a, (int)nsym, m->carriers, m->spacing, b);
+        }
         t = a; a = b; b = t;                       /* a = ofdm out */
         if (c->cfg.stages & DABO_STAGE_GAIN) {
             rc |= dabo_gain_control(a, nsym * N, m->spacing, c->cfg.gain_mode, c->cfg.dig_gain,

@@ -122,6 +122,25 @@ enum {
     DABO_STAGE_POLY     = 1 << 3
 };
 
+/* f-3 crest-factor reduction inside OfdmGenerator (reference src/OfdmGenerator.cpp:157-308,
+ * cfr_one_iteration :310-373) and its side statistics.  FFTW calls are the exact DFT evaluated
+ * in float64 and rounded once to float32 (PARITY UNPINNED against a reference run: FFTW3f is
+ * not installed here); everything around them follows the reference line by line in fp32.
+ *   mer_index : the value of myMERCalcIndex for this call (:198), i.e. the symbol whose MER is taken
+ *   papr      : nsym x 4 doubles per call: {peak, mean} of |x|^2 before CFR (PAPRStats::process_block,
+ *               src/PAPRStats.cpp:41-72) and after CFR (symbol 0: {0,0}, the reference skips it :246-248)
+ *   mer_db    : MER of symbol mer_index, or NAN when the reference pushes none (mer_index == 0) */
+typedef struct {
+    size_t num_clip, num_error_clip;       /* :275-276 */
+    double mer_sum_iq, mer_sum_delta, mer_db;
+} dabo_cfr_stats;
+int dabo_ofdm_generate_cfr(const float *in, int nsym, int carriers, int spacing, float clip,
+                           float error_clip, int mer_index, float *out, dabo_cfr_stats *st,
+                           double *papr);
+/* PAPRStats::calculate_papr over (peak, mean) pairs of equally long blocks, src/PAPRStats.cpp:74-103
+ * (the caller implements the "fewer than num_blocks_to_accumulate blocks -> 0" rule) */
+double dabo_papr_db(const double *peak_mean_pairs, size_t nblocks);
+
 /* f-4 TII (reference src/TII.cpp:172-263,265-337).
  * dabo_tii_pattern: acp[carriers] <- 1 where A_{c,p} is set, in the reference's own index
  * convention (ix = K/2 + k - (k >= 0), :251-262).  Returns 0, or -1 for a mode other than I/II,
@@ -151,6 +170,9 @@ typedef struct {
     /* f-4 TII (src/DabModulator.cpp:178-190,392-395): replaces the null symbol on every other
      * frame of the stream, starting with the first */
     int tii_enable, tii_comb, tii_pattern, tii_old_variant;
+    /* f-3 CFR inside OfdmGenerator; the MER symbol index advances per frame like myMERCalcIndex */
+    int cfr_enable;
+    float cfr_clip, cfr_error_clip;
 } dabo_chain_cfg;
 
 typedef struct dabo_chain dabo_chain;
@@ -162,6 +184,9 @@ size_t dabo_chain_out_samples_per_tf(const dabo_chain *c);
  * Pipeline latency of PipelinedModCodec (src/ModPlugin.cpp:90-115) is NOT
  * modelled: frame i's output is the fully processed frame i. */
 int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float *out);
+/* CFR statistics of frame f of the most recent dabo_chain_process call (NULL if CFR is off / f out of range);
+ * papr (may be NULL) receives (nb_symbols+1) x 4 doubles */
+const dabo_cfr_stats *dabo_chain_cfr_stats(const dabo_chain *c, size_t f, double *papr);
 
 /* float64 unnormalised DFT used by a6/a10, exposed for tests: sign=+1 backward. */
 void dabo_dft_f64(const double *in_ri, double *out_ri, size_t n, int sign);

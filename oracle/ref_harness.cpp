@@ -24,6 +24,7 @@
 #include "MemlessPoly.h"
 #include "FormatConverter.h"
 #include "TII.h"
+#include "PAPRStats.h"
 
 #include <cstring>
 #include <string>
@@ -170,6 +171,16 @@ int ref_memless_poly(const float *in, size_t nsamples, const char *coef_file,
         st.process(&b2, &bo);
         return copy_out(bo, out, nsamples * sizeof(complexf));
     } catch (const std::exception &) { return -1; }
+}
+
+// f-3: PAPRStats fed nblocks blocks of blocklen samples; returns calculate_papr() (0 when fewer
+// than `accumulate` blocks have been seen)
+double ref_papr(const float *x, size_t nblocks, size_t blocklen, size_t accumulate)
+{
+    PAPRStats st(accumulate);
+    for (size_t b = 0; b < nblocks; ++b)
+        st.process_block(reinterpret_cast<const complexf *>(x) + b * blocklen, blocklen);
+    return st.calculate_papr();
 }
 
 // f-4: TII fed by a PhaseReference, called ncalls times (the insert flag toggles per call).

@@ -99,6 +99,8 @@ def main():
             g["format_%s" % fmt] = {"sha256": sha(yo), "clipped": clipped}
             ye, ce = O.ref_format_convert(format_edges(fmt), fmt)
             g["format_edges_%s" % fmt] = {"out": [int(v) for v in ye], "clipped": ce}
+        # f-3: PAPRStats (the part of the CFR statistics that compiles without FFTW) on the synthetic signal
+        g["papr_synth_signal"] = {"db": O.ref_papr(x, N, nsym), "db_too_few_blocks": O.ref_papr(x, N, nsym + 1)}
         # f-4 TII (modes I and II only): every comb x pattern, both variants, inserting and idle call
         if mode in (1, 2):
             for ov, name in ((0, "new"), (1, "old")):

@@ -364,6 +364,86 @@ def test_chain_cfg4_resample_x4_and_poly(pkg):
     assert y.shape[1] == 4 * 196608
 
 
+# --------------------------------------------------------------------------- f-3 CFR
+def _check_cfr_stats(got, want, want_papr, N):
+    """Clip decisions next to a threshold may differ between two fp32 FFTs: counts within 0.2 %."""
+    assert abs(got["num_clip"] - want["num_clip"]) <= max(4, 2e-3 * want["num_clip"])
+    assert abs(got["num_error_clip"] - want["num_error_clip"]) <= max(4, 2e-3 * want["num_error_clip"])
+    assert got["num_samples"] == want_papr.shape[0] * N
+    assert np.allclose(got["papr_before"], want_papr[:, :2], rtol=2e-5, atol=1e-12)
+    assert np.allclose(got["papr_after"], want_papr[:, 2:], rtol=2e-5, atol=1e-12)
+    if np.isnan(want["mer_db"]):
+        assert got["mer_symbol"] == 0 or got["mer_sum_delta"] == 0.0
+    else:
+        mer = 10 * np.log10(got["mer_sum_iq"] / got["mer_sum_delta"])
+        assert abs(mer - want["mer_db"]) < 1e-2
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_ofdm_generator_with_cfr(pkg, mode):
+    """OfdmGeneratorCF32 with cfr on (src/OfdmGenerator.cpp:222-277,310-373): samples and statistics."""
+    md = pkg.Modulator(mode=mode, max_frames=1)
+    try:
+        geo = md.geometry
+        K, N, nsym = geo["carriers"], geo["spacing"], geo["nb_symbols"] + 1
+        pr, _ = O.phase_reference(mode)
+        z = O.signal_mux(np.zeros(K, np.complex64),
+                         O.diff_mod(pr, O.freq_interleave(O.qpsk_map(golden_bits(mode), K), mode), K))
+        clip, eclip = float(np.float32(50.0 * np.sqrt(K / 1536.0))), 0.1
+        md.set_cfr(True, clip, eclip)
+        for call in (1, 2, 3):                          # the MER symbol index advances per call
+            y = md.ofdm(z)
+            ref, st, papr = O.ofdm_generate_cfr(z, nsym, K, N, clip, eclip, call % nsym)
+            assert rel_rms(y, ref) < REL_RMS
+            got = md.cfr_stats(0)
+            assert got["mer_symbol"] == call % nsym
+            _check_cfr_stats(got, st, papr, N)
+            assert st["num_clip"] > 0.05 * nsym * N
+        md.set_cfr(False)
+        assert rel_rms(md.ofdm(z), O.ofdm_generate(z, nsym, K, N)) < REL_RMS
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("mode,chunks", [(1, 1), (1, 5), (3, 1)])
+def test_chain_cfg3_with_cfr(pkg, mode, chunks):
+    """Full chain from coded bits with CFR: 3 frames in calls of 2 + 1, statistics per frame."""
+    md = pkg.Modulator(mode=mode, max_frames=2, chunks_per_frame=chunks)
+    try:
+        K, N = md.geometry["carriers"], md.geometry["spacing"]
+        clip, eclip = float(np.float32(50.0 * np.sqrt(K / 1536.0))), 0.1
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_cfr(True, clip, eclip)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=1300 + i) for i in range(3)])
+        ch = O.Chain(mode=mode, stages=3, gain_mode=2, normalise=1.0 / 50000.0, cfr=(clip, eclip))
+        ref = ch.process(bits)
+        want = [ch.cfr_stats(f) for f in range(3)]
+        y01 = md.chain(bits[:2], 3)
+        got = [md.cfr_stats(0), md.cfr_stats(1)]
+        y2 = md.chain(bits[2:], 3)
+        got.append(md.cfr_stats(0))
+        y = np.concatenate([y01, y2])
+        for f in range(3):
+            assert rel_rms(y[f], ref[f]) < REL_RMS, (f, rel_rms(y[f], ref[f]))
+            assert got[f]["mer_symbol"] == f + 1
+            _check_cfr_stats(got[f], want[f][0], want[f][1], N)
+        with pytest.raises(pkg.DabGpuError, match="no CFR statistics"):
+            md.cfr_stats(1)
+    finally:
+        md.close()
+
+
+def test_chain_cfr_with_tii_and_resampler(pkg):
+    """CFR acts per symbol, so the cached TII null-symbol response simply goes through it as well."""
+    def setup(md):
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_cfr(True, 50.0, 0.1)
+        md.set_resampler(2048000, 4096000)
+    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE,
+                    dict(gain_mode=2, normalise=1.0 / 50000.0, out_rate=4096000, cfr=(50.0, 0.1)), setup)
+
+
 # --------------------------------------------------------------------------- f-4 TII
 @pytest.mark.parametrize("mode", [1, 2])
 def test_tii_stage_bit_exact_vs_reference_golden(pkg, mode):

@@ -106,3 +106,40 @@ def test_flowgraph_with_tii_matches_oracle(tmp_path):
                 assert np.linalg.norm(got[:L] - ref[f][:L]) / np.linalg.norm(ref[f][:L]) < 2e-6
             else:
                 assert not got[:L - 44].any()
+
+
+@pytest.mark.gpu
+def test_flowgraph_with_cfr_matches_oracle(tmp_path):
+    """f-3: OfdmGeneratorCF32 with enableCfr in the stage graph, Settings::enableCfr in the fused plugin,
+    and the RC statistics strings of the reference."""
+    import re
+    import oracle as O
+    from tests.golden.synth import synth_bits
+    build_host()
+    n, mode = 5, 1
+    per = O.tf_input_bytes(mode)
+    bits = np.stack([synth_bits(per, seed=500 + i) for i in range(n)])
+    fbits, fgraph, fchain, fs16 = (str(tmp_path / x) for x in ("bits.bin", "graph.iq", "chain.iq", "chain.s16"))
+    bits.tofile(fbits)
+    r = subprocess.run([BIN, "gpu", str(mode), fbits, str(n), fgraph, fchain, repr(1.0 / 50000.0), fs16, "-",
+                        "50.0,0.1"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    ch = O.Chain(mode=mode, stages=3, gain_mode=2, normalise=1.0 / 50000.0, cfr=(50.0, 0.1))
+    ref = ch.process(bits)
+    tf = O.tf_samples(mode)
+    graph = np.fromfile(fgraph, dtype=np.complex64).reshape(-1, tf)
+    chain = np.fromfile(fchain, dtype=np.complex64).reshape(-1, tf)
+    assert graph.shape[0] == n - 2 and chain.shape[0] == n
+    for f in range(n):
+        for got in ([graph[f]] if f < n - 2 else []) + [chain[f]]:
+            assert np.linalg.norm(got - ref[f]) / np.linalg.norm(ref[f]) < 1e-6
+    # "Statistics : 19.4% samples clipped, 68.8% errors clipped. MER after CFR: 19.8 dB"
+    m = re.search(r"Statistics : ([0-9.]+)% samples clipped, ([0-9.]+)% errors clipped. MER after CFR: ([0-9.]+) dB",
+                  r.stdout)
+    assert m, r.stdout
+    st = [ch.cfr_stats(f)[0] for f in range(n)]
+    ns = 77 * 2048
+    assert abs(float(m.group(1)) - 100 * np.mean([s["num_clip"] / ns for s in st])) < 0.05
+    assert abs(float(m.group(2)) - 100 * np.mean([s["num_error_clip"] / ns for s in st])) < 0.05
+    assert abs(float(m.group(3)) - np.mean([s["mer_db"] for s in st])) < 0.01
+    assert "ofdm papr: PAPR [dB]: N/A, N/A" in r.stdout        # fewer than nbSymbols * 50 blocks so far

@@ -88,6 +88,67 @@ def test_format_converter_bit_exact_vs_reference(mode, fmt):
     assert ce == g["format_edges_%s" % fmt]["clipped"]
 
 
+def _mux_symbols(mode, seed=None):
+    m = O.mode_params(mode)
+    K = m["carriers"]
+    bits = bits_for(mode) if seed is None else synth_bits(O.tf_input_bytes(mode), seed=seed)
+    pr, _ = O.phase_reference(mode)
+    return O.signal_mux(np.zeros(K, np.complex64), O.diff_mod(pr, O.freq_interleave(O.qpsk_map(bits, K), mode), K))
+
+
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_papr_stats_vs_reference_class(mode):
+    """f-3: PAPRStats::process_block / calculate_papr (src/PAPRStats.cpp) -- the oracle's per-symbol
+    (peak, mean) pairs reduce to the reference's figure."""
+    g = GOLD[str(mode)]["papr_synth_signal"]
+    m = O.mode_params(mode)
+    N, nsym = m["spacing"], m["nb_symbols"] + 1
+    x = synth_signal(nsym * N, seed=100 + mode).reshape(nsym, N)
+    p2 = (x.real.astype(np.float32) ** 2 + x.imag.astype(np.float32) ** 2).astype(np.float64)
+    pairs = np.stack([p2.max(axis=1), p2.sum(axis=1) / N], axis=1)
+    assert abs(O.papr_db(pairs) - g["db"]) < 1e-9
+    assert g["db_too_few_blocks"] == 0.0
+
+
+@pytest.mark.parametrize("mode", [1, 3])
+def test_cfr_matches_float64_model(mode):
+    """f-3: clip -> FFT -> error clip -> IFFT (src/OfdmGenerator.cpp:310-373) against an independent
+    numpy model (pocketfft in float64, rounded to float32 where FFTW's output would be)."""
+    m = O.mode_params(mode)
+    K, N, nsym = m["carriers"], m["spacing"], m["nb_symbols"] + 1
+    z = _mux_symbols(mode)
+    clip, eclip, mer_index = np.float32(50.0 * np.sqrt(K / 1536.0)), np.float32(0.1), 7
+    y, st, papr = O.ofdm_generate_cfr(z, nsym, K, N, clip, eclip, mer_index)
+    X = np.zeros((nsym, N), np.complex64)
+    zs = z.reshape(nsym, K)
+    X[:, 1:K // 2 + 1] = zs[:, :K // 2]
+    X[:, N - K // 2:] = zs[:, K // 2:]
+    t = (np.fft.ifft(X.astype(np.complex128), axis=1) * N).astype(np.complex64)
+    mag2 = t.real ** 2 + t.imag ** 2
+    over = mag2 > clip * clip
+    tc = np.where(over, t * np.sqrt(clip * clip / np.where(over, mag2, 1)).astype(np.float32), t).astype(np.complex64)
+    c = (np.fft.fft(tc.astype(np.complex128), axis=1).astype(np.complex64) / np.float32(N)).astype(np.complex64)
+    e = (X - c).astype(np.complex64)
+    e2 = e.real ** 2 + e.imag ** 2
+    eover = e2 > eclip * eclip
+    e = np.where(eover, e * np.sqrt(eclip * eclip / np.where(eover, e2, 1)).astype(np.float32), e).astype(np.complex64)
+    want = (np.fft.ifft((c + e).astype(np.complex64).astype(np.complex128), axis=1) * N).astype(np.complex64)
+    assert np.linalg.norm(y - want.ravel()) / np.linalg.norm(want) < 1e-6
+    # decisions next to a threshold may fall on either side
+    assert abs(st["num_clip"] - int(over.sum())) <= 3 and abs(st["num_error_clip"] - int(eover.sum())) <= 3
+    assert st["num_clip"] > 0.05 * nsym * N and st["num_error_clip"] > 0.3 * nsym * N   # CFR is really active
+    d = want[mer_index] - t[mer_index]
+    mer = 10 * np.log10((np.abs(t[mer_index].astype(np.complex128)) ** 2).sum() / (np.abs(d.astype(np.complex128)) ** 2).sum())
+    assert abs(st["mer_db"] - mer) < 1e-3
+    assert np.allclose(papr[1:, 0], (np.abs(t[1:].astype(np.complex128)) ** 2).max(axis=1), rtol=1e-5)
+    assert np.allclose(papr[1:, 3], (np.abs(want[1:].astype(np.complex128)) ** 2).mean(axis=1), rtol=1e-5)
+    assert not papr[0].any()                                    # blank null symbol
+    # thresholds out of reach: CFR is the identity and nothing is counted
+    y2, st2, _ = O.ofdm_generate_cfr(z, nsym, K, N, 1e9, 1e9, 0)
+    assert np.linalg.norm(y2 - O.ofdm_generate(z, nsym, K, N)) / np.linalg.norm(y2) < 2e-7
+    assert st2["num_clip"] == 0 and st2["num_error_clip"] == 0 and np.isnan(st2["mer_db"])
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_tii_bit_exact_vs_reference(mode):
     """f-4: every comb x pattern, old and new variant, inserting call and idle call."""
