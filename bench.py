@@ -15,6 +15,8 @@ Workloads (BASELINE.json configs):
                   -> guard interval -> FIRFilter(45 default taps), native 2.048 Msps
   cfg2            SignalMultiplexer output (cf32) -> OfdmGenerator + GuardIntervalInserter
   cfg4            cfg3 + Resampler 2.048->8.192 Msps + MemlessPoly
+  ifft_fir_stage  SignalMultiplexer output (cf32) -> OfdmGenerator + GainControl(var) + guard + FIRFilter: the
+                  "IFFT+FIR stage" of the north-star target, SURVEY 8(d) (2 519 040 algorithmic B/TF)
 
 One JSON line on stdout (rank 0).
 """
@@ -34,6 +36,7 @@ HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s meas
 ALGO_BYTES = {
     "cfg2": 946176 + 1572864,        # 77x1536 cf32 read + 196608 cf32 written
     "cfg3": 28800 + 1572864,         # coded bits read + native-rate IQ written
+    "ifft_fir_stage": 946176 + 1572864,  # SURVEY 8(d) "IFFT+Gain+Guard+FIR (IFFT+FIR stage)": carriers in, IQ out
     "cfg4": 28800 + 6291456,         # coded bits read + 8.192 Msps IQ written
 }
 
@@ -53,7 +56,7 @@ def cpu_baseline(workload, seconds_budget=12.0):
     kw = dict(mode=1, fast=True)
     if workload == "cfg2":
         kw.update(stages=0)
-    elif workload == "cfg3":
+    elif workload in ("cfg3", "ifft_fir_stage"):
         kw.update(stages=3, gain_mode=2, normalise=1.0 / 50000.0)
     else:
         kw.update(stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000,
@@ -103,6 +106,8 @@ def main():
         md.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
         if workload == "cfg2":
             stages, from_bits = 0, False
+        elif workload == "ifft_fir_stage":
+            stages, from_bits = P.STAGE_GAIN | P.STAGE_FIR, False
         elif workload == "cfg3":
             stages, from_bits = P.STAGE_GAIN | P.STAGE_FIR, True
         else:
@@ -185,6 +190,8 @@ def main():
         "dtype": "f32",
         "data": "synthetic",
         "config": {"workload": {"cfg2": "Mode I OfdmGenerator+GuardIntervalInserter (BASELINE config 2)",
+                                "ifft_fir_stage": "Mode I OfdmGenerator + GainControl(var) + GuardIntervalInserter + "
+                                                  "FIRFilter(45 default taps) from SignalMultiplexer output",
                                 "cfg3": "Mode I full chain from coded bits + GainControl(var) + "
                                         "FIRFilter(45 default taps), native 2.048 Msps (BASELINE config 3)",
                                 "cfg4": "Mode I cfg3 + Resampler 2.048->8.192 Msps + MemlessPoly "
@@ -202,15 +209,16 @@ def main():
             extra = {}
             # the other BASELINE configs, and the headline workload one frame at a time (B = 1:
             # what a single real-time stream sees; the frame is split over 11 workgroups)
-            for wl, b2 in (("cfg2", B), ("cfg4", max(64, B // 4)), (args.workload + "_B1", 1)):
+            for wl, b2 in (("cfg2", B), ("ifft_fir_stage", B), ("cfg4", max(64, B // 4)),
+                           (args.workload + "_B1", 1)):
                 if wl == args.workload:
                     continue
                 try:
                     k = max(3, args.steps // 4) if b2 > 1 else 200
                     w2, k2 = run_workload(wl.replace("_B1", ""), b2, k, 1)
-                    extra[wl] = {"frames_per_s": round(b2 * k / w2, 2),
-                                 "frames_per_step": b2,
-                                 "achieved_GBps": round(ALGO_BYTES[wl.replace("_B1", "")] * b2 / (k2 * 1e-3) / 1e9, 2)}
+                    gbps = ALGO_BYTES[wl.replace("_B1", "")] * b2 / (k2 * 1e-3) / 1e9
+                    extra[wl] = {"frames_per_s": round(b2 * k / w2, 2), "frames_per_step": b2,
+                                 "achieved_GBps": round(gbps, 2), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4)}
                 except Exception as ex:  # secondary numbers must never break the contract line
                     extra[wl] = {"error": str(ex)[:200]}
             line["other_workloads"] = extra

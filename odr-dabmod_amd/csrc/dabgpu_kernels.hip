@@ -29,6 +29,9 @@
 #ifndef DABGPU_TF_WAVES
 #define DABGPU_TF_WAVES 3      // __launch_bounds__ waves per SIMD for the FIR variants of tf_kernel (<= 168 VGPRs)
 #endif
+#ifndef DABGPU_TF_WAVES_CARRIERS_GAIN
+#define DABGPU_TF_WAVES_CARRIERS_GAIN 1   // 1: the carriers-input FIR variants WITH gain (time-domain statistics keep both
+#endif                                    //    transforms of a symbol live) get 2 waves/SIMD (256 VGPRs) instead of spilling at 168
 #ifndef DABGPU_FIR_SCHED
 #define DABGPU_FIR_SCHED 1
 #endif
@@ -578,7 +581,8 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // kernels): crest-factor reduction of every symbol right after its IFFT, in registers -- clip, forward
 // FFT, error clip against the lane's own input bins, IFFT again -- plus the reference's statistics.
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false>
-__global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8, FIR ? DABGPU_TF_WAVES : 2)
+__global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
+                             (FIR && !(GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN)) ? DABGPU_TF_WAVES : 2)
 void tf_kernel(const TfArgs a)
 {
     static_assert(!CFR || (!GUARD && !FIR), "CFR variants stop after OfdmGenerator(+GainControl)");
