@@ -60,7 +60,7 @@ struct TfArgs {
     double *cfr_papr;         // [frame][nb_symbols+1][4]: peak, mean of |x|^2 before / after CFR (pre-zeroed)
 };
 
-enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16 };
+enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */ };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags);

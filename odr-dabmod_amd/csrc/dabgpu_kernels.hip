@@ -32,6 +32,12 @@
 #ifndef DABGPU_TF_WAVES_CARRIERS_GAIN
 #define DABGPU_TF_WAVES_CARRIERS_GAIN 1   // 1: the carriers-input FIR variants WITH gain (time-domain statistics keep both
 #endif                                    //    transforms of a symbol live) get 2 waves/SIMD (256 VGPRs) instead of spilling at 168
+#ifndef DABGPU_GVAR_WAVES
+#define DABGPU_GVAR_WAVES 2               // waves/SIMD of the carriers-input FIR variant specialised for gain mode var
+#endif
+#ifndef DABGPU_GVAR_TW64
+#define DABGPU_GVAR_TW64 0                // that variant reads the stride-64 twiddles from LDS (14 VGPRs fewer)
+#endif
 #ifndef DABGPU_FIR_SCHED
 #define DABGPU_FIR_SCHED 1
 #endif
@@ -281,7 +287,7 @@ template <int LOGN> struct Fft {
             if (NR8 > 2 || RF > 1) exchange<8, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
-            if (DABGPU_TW64_LDS && TWM == 0 && tw64) {
+            if (TWM == 0 && tw64) {
 #pragma unroll
                 for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw64[r * 64 + (t & 63)]);
                 n += 7;
@@ -580,11 +586,16 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // CFR (f-3, only without GUARD/FIR: the chain then continues with the stand-alone guard and FIR
 // kernels): crest-factor reduction of every symbol right after its IFFT, in registers -- clip, forward
 // FFT, error clip against the lane's own input bins, IFFT again -- plus the reference's statistics.
-template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false>
+// GVAR (carriers path with GAIN only): the gain mode is known to be "var" -- the statistics come from
+// the spectrum and the time-domain reduction (which keeps both transforms of a symbol live and costs
+// the third workgroup per CU) is compiled out.
+template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             (FIR && !(GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN)) ? DABGPU_TF_WAVES : 2)
+                             !FIR ? 2 : (GVAR ? DABGPU_GVAR_WAVES
+                                                  : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2 : DABGPU_TF_WAVES)))
 void tf_kernel(const TfArgs a)
 {
+    static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
     static_assert(!CFR || (!GUARD && !FIR), "CFR variants stop after OfdmGenerator(+GainControl)");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
@@ -602,7 +613,8 @@ void tf_kernel(const TfArgs a)
     // that the boundary outputs read in[i + j] without a tail/head case split
     // frequency-domain gain statistics (coded-bits path): one packed word of phases per lane
     uint32_t *phw = reinterpret_cast<uint32_t *>(red + 16);          // [T]
-    cf *bnd = reinterpret_cast<cf *>(phw + (GAIN && FROM_BITS ? T : 0));
+    // (carriers path: three complex bins per lane instead -- the general form of the same statistic)
+    cf *bnd = reinterpret_cast<cf *>(phw + (GAIN ? (FROM_BITS ? T : 6 * T) : 0));
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * kBnd : 0));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
@@ -617,7 +629,7 @@ void tf_kernel(const TfArgs a)
     cf *tw8_l = hk_l + ((FIR && DABGPU_HK_LDS) ? 6 * T : 0);   // DABGPU_TW8_LDS: 7 x 8 twiddles
     if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
     cf *tw64_l = tw8_l + 56;                            // DABGPU_TW64_LDS: 7 x 64 twiddles (FIR variants)
-    constexpr bool TW64 = DABGPU_TW64_LDS && FIR && F::NR8 >= 3;
+    constexpr bool TW64 = (DABGPU_TW64_LDS || (GVAR && DABGPU_GVAR_TW64)) && FIR && F::NR8 >= 3;
     if (TW64) F::fill_tw64(a.t.twiddle, tw64_l, t, (int)blockDim.x);
     if (t < 8) {
         const float cx = (float)((int)((kCX >> (2u * t)) & 3u) - 1);
@@ -643,7 +655,7 @@ void tf_kernel(const TfArgs a)
 
     // ---- per-lane constants ------------------------------------------------
     cf tw[F::NTW > 0 ? F::NTW : 1];
-    F::template load_twiddles<DABGPU_TW8_LDS != 0, DABGPU_TW64_LDS && FIR && F::NR8 >= 3>(a.t.twiddle, tt, tw);
+    F::template load_twiddles<DABGPU_TW8_LDS != 0, TW64>(a.t.twiddle, tt, tw);
 
     // the lane's 6 active first-stage inputs: r = {0|3,1,2,5,6,7}; bin = t + T*r
     // interleaved position k: bins 1..K/2 -> k = bin-1 ; bins N-K/2.. -> k = bin-N+K
@@ -713,9 +725,15 @@ void tf_kernel(const TfArgs a)
                 val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
             }
         } else {
-            const cf *sym = fcar + (size_t)min(s, nsym - 1) * (size_t)K;
-#pragma unroll
-            for (int c = 0; c < 6; ++c) val[c] = sym[kpos[c]];
+            // position of bin tt + T r: r <= 3 -> bin - 1 (positive carriers first), r >= 5 -> bin - N + K.
+            // Spelled out as lane + constant so that the six loads share one address register.
+            const cf *sym = fcar + (size_t)min(s, nsym - 1) * (size_t)K + tt;
+            val[0] = sym[(tt == 0 ? 3 * T : 0) - 1];
+            val[1] = sym[T - 1];
+            val[2] = sym[2 * T - 1];
+            val[3] = sym[5 * T - N + K];
+            val[4] = sym[6 * T - N + K];
+            val[5] = sym[7 * T - N + K];
         }
     };
     // scatter them into the first-stage register layout
@@ -824,10 +842,50 @@ void tf_kernel(const TfArgs a)
         }
     };
 
+    // Carriers path, gain mode var: the statistic of the coded-bits path for arbitrary carriers
+    // (zero DC bin, so zero mean):
+    //   var(re) = (P + Re Q) / 2,  var(im) = (P - Re Q) / 2,
+    //   P = sum_k |X[k]|^2,  Q = sum_k X[k] X[-k] = 2 sum over pairs {k, -k}.
+    // Bin -k of the lane's three positive bins lives in lane T - t: exchange three values, leave the
+    // per-wave partial sums in redf (combined by spectral_gain after at least one more barrier).
+    auto spectral_partial = [&](const cf *val, float *redf) __attribute__((always_inline)) {
+        cf *pw = reinterpret_cast<cf *>(phw);
+        lds_barrier();                         // the previous symbol's partner reads are done
+        pw[tt] = (tt == 0) ? val[3] : val[5];
+        pw[T + tt] = (tt == 0) ? val[5] : val[4];
+        pw[2 * T + tt] = (tt == 0) ? val[4] : val[3];
+        lds_barrier();
+        const int o = (T - tt) & (T - 1);
+        const cf oa = pw[o], ob = pw[T + o], oc = pw[2 * T + o];
+        float q = (val[0].x * oa.x - val[0].y * oa.y) + (val[1].x * ob.x - val[1].y * ob.y) +
+                  (val[2].x * oc.x - val[2].y * oc.y);
+        float pwr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pwr += val[c].x * val[c].x + val[c].y * val[c].y;
+        q = wave_sum_dpp(lane_on ? 2.0f * q : 0.f);
+        pwr = wave_sum_dpp(lane_on ? pwr : 0.f);
+        if ((t & 63) == 0) { redf[2 * (t >> 6)] = pwr; redf[2 * (t >> 6) + 1] = q; }
+    };
+    auto spectral_gain = [&](const float *redf) __attribute__((always_inline)) -> float {
+        float P = 0.f, Q = 0.f;
+#pragma unroll
+        for (int w = 0; w < (T + 63) / 64; ++w) { P += redf[2 * w]; Q += redf[2 * w + 1]; }
+        const float vr = sqrtf(fmaxf(0.5f * (P + Q), 0.f)) * a.gain.var_variance;
+        const float vi = sqrtf(fmaxf(0.5f * (P - Q), 0.f)) * a.gain.var_variance;
+        return ((int)vr == 0) ? 1.0f : 32767.0f / fmaxf(vr, vi);
+    };
+
     // gain of the NULL symbol = gain computed on symbol 1 (reference
     // src/GainControl.cpp:139-144); only matters when symbol 0 is not blank.
     float g_null = 1.0f;
-    if (GAIN && !FROM_BITS && s_begin == 0) {
+    if (GVAR && s_begin == 0) {
+        cf val[6];
+        load_active(1, val);
+        float *redf = reinterpret_cast<float *>(red + 8);
+        spectral_partial(val, redf);
+        lds_barrier();
+        g_null = spectral_gain(redf);
+    } else if (GAIN && !FROM_BITS && s_begin == 0) {
         cf val[6], v[8];
         load_active(1, val);
         place(val, v);
@@ -925,6 +983,8 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
             for (int c = 0; c < 6; ++c) val[c] = nval[c];
             if (s + 1 < s_stop) load_active(s + 1, nval);
+            if (GAIN && !CFR && (GVAR || a.gain.mode == 2) && s > 0)
+                spectral_partial(val, reinterpret_cast<float *>(red + 8 * (s & 1)));   // combined after the transform
         }
         constexpr bool DUAL = FIR && DABGPU_DUAL_FFT;
         cf z[8];                                  // DUAL: the filtered symbol
@@ -969,6 +1029,10 @@ void tf_kernel(const TfArgs a)
                 const float vr = sqrtf(m2 * fmaxf((float)(K / 2) + S, 0.f)) * a.gain.var_variance;
                 const float vi = sqrtf(m2 * fmaxf((float)(K / 2) - S, 0.f)) * a.gain.var_variance;
                 g = ((int)vr == 0) ? 1.0f : 32767.0f / fmaxf(vr, vi);
+            } else if (!FROM_BITS && !CFR && (GVAR || a.gain.mode == 2) && s > 0) {
+                g = spectral_gain(reinterpret_cast<const float *>(red + 8 * (s & 1)));
+            } else if (GVAR) {
+                g = g_null;                                   // s == 0
             } else {
                 g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
             }
@@ -1062,7 +1126,8 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         return hipErrorInvalidValue;
     const dim3 block(T < 64 ? 64 : T);
     const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
-    const size_t lds = tf_lds_bytes(LOGN, flags);
+    const bool gvar = !(flags & TF_FROM_BITS) && (flags & TF_GAIN) && !(flags & TF_CFR) && a.gain.mode == 2;
+    const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0));
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
 #define TF_LAUNCH_CFR(FB, GN)                                                                  \
@@ -1076,6 +1141,13 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         else    { if (gn) TF_LAUNCH_CFR(false, true); else TF_LAUNCH_CFR(false, false); }
         return hipGetLastError();
     }
+#define TF_LAUNCH_GVAR(GD, FR)                                                                 \
+    hipLaunchKernelGGL((tf_kernel<LOGN, false, true, GD, FR, (FR ? NT : 0), false, true>), grid, block, lds, s, a)
+    if (gvar) {
+        if (fr) TF_LAUNCH_GVAR(true, true); else if (gd) TF_LAUNCH_GVAR(true, false); else TF_LAUNCH_GVAR(false, false);
+        return hipGetLastError();
+    }
+#undef TF_LAUNCH_GVAR
     if (fb) {
         if (gn) { if (fr) TF_LAUNCH(true, true, true, true); else if (gd) TF_LAUNCH(true, true, true, false); else TF_LAUNCH(true, true, false, false); }
         else    { if (fr) TF_LAUNCH(true, false, true, true); else if (gd) TF_LAUNCH(true, false, true, false); else TF_LAUNCH(true, false, false, false); }
@@ -1096,7 +1168,7 @@ size_t tf_lds_bytes(int logN, unsigned flags)
     const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
     const size_t elem = ((flags & TF_FIR) && DABGPU_DUAL_FFT) ? 2 * sizeof(float2) : sizeof(float2);
     size_t b = (dbuf ? 2 : 1) * (N + N / 8) * elem + 16 * sizeof(double);
-    if ((flags & TF_GAIN) && (flags & TF_FROM_BITS)) b += (N / 8) * sizeof(uint32_t);   // phase words
+    if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
     if (flags & TF_FIR) b += 4 * DABGPU_KBND * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
@@ -1106,9 +1178,7 @@ size_t tf_lds_bytes(int logN, unsigned flags)
 #if DABGPU_TW8_LDS
     b += 56 * sizeof(float2);
 #endif
-#if DABGPU_TW64_LDS
-    if (flags & TF_FIR) b += 448 * sizeof(float2);
-#endif
+    if ((flags & TF_FIR) && (DABGPU_TW64_LDS || ((flags & TF_GVAR) && DABGPU_GVAR_TW64))) b += 448 * sizeof(float2);
     return b;
 }
 
