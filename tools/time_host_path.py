@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""PCIe-inclusive rate of the drop-in entry point dabgpu_chain_process (host buffers in, host buffers out).
+usage (GPU box): python tools/time_host_path.py"""
+import importlib, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+P = importlib.import_module("odr-dabmod_amd")
+for B in (1, 8, 64):
+    md = P.Modulator(mode=1, max_frames=B)
+    md.set_gain(2, 1.0, 1 / 50000., 4.0)
+    bits = np.frombuffer(np.random.RandomState(1).bytes(B * 28800), np.uint8).reshape(B, 28800)
+    for _ in range(3): md.chain(bits, 3)
+    n = max(3, 256 // B)
+    t0 = time.perf_counter()
+    for _ in range(n): md.chain(bits, 3)
+    dt = time.perf_counter() - t0
+    print("B=%3d  %8.0f frames/s  (%.2f ms per call, %.2f GB/s of IQ to the host)"
+          % (B, B * n / dt, dt / n * 1e3, B * n * 1572864 / dt / 1e9), flush=True)
+    md.close()
