@@ -96,7 +96,7 @@ struct dabgpu_ctx {
     // constant tables
     DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_firh, d_window, d_coef;
     // resampler
-    DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo, d_rs_spec;
+    DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo;
     int rs_nin = 0, rs_nout = 0;
     size_t rs_L = 1, rs_M = 1;
     float rs_factor = 1.f;
@@ -725,7 +725,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
-                      &c->d_rs_halo, &c->d_rs_spec, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
+                      &c->d_rs_halo, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
                       &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1,
                       &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();

@@ -38,9 +38,6 @@
 #ifndef DABGPU_GVAR_TW64
 #define DABGPU_GVAR_TW64 0                // that variant reads the stride-64 twiddles from LDS (14 VGPRs fewer)
 #endif
-#ifndef DABGPU_FIR_SCHED
-#define DABGPU_FIR_SCHED 1
-#endif
 #ifndef DABGPU_TW8_LDS
 #define DABGPU_TW8_LDS 1       // 1: the stride-8 stage's twiddles (they depend on lane%8 only) are read from a
 #endif                         //    56-entry LDS table instead of living in 14 VGPRs
@@ -54,14 +51,6 @@
 #define DABGPU_FFT_DBUF 0      // FIR variants: 1 = two LDS exchange buffers (one barrier per exchange), 0 = one buffer,
                                // two barriers (36 KB of LDS per workgroup -> three workgroups per CU); the
                                // variants without FIR always double-buffer
-#endif
-#ifndef DABGPU_HK_LDS
-#define DABGPU_HK_LDS 0        // 1: the lane's 6 filter-response values live in LDS (6 x T float2) instead of 12 VGPRs
-#endif
-#ifndef DABGPU_TW_POWERS
-// twiddles resident in registers per FFT stage: 0 = all seven W^r; 1 = W, W^2, W^4 (the
-// rest are products of two of them); 2 = W only (powers by repeated multiplication)
-#define DABGPU_TW_POWERS 0
 #endif
 
 namespace dabgpu {
@@ -149,9 +138,8 @@ template <int LOGN> struct Fft {
     static constexpr int NR8 = LOGN / 3;          // radix-8 stages
     static constexpr int RF = N >> (3 * NR8);     // final radix 1/2/4
     static constexpr int NB = RF > 1 ? 8 / RF : 0;  // final-stage butterflies per lane
-    static constexpr int TWM = DABGPU_TW_POWERS;
-    static constexpr int TW_PER_STAGE = TWM == 0 ? 7 : (TWM == 1 ? 3 : 1);
-    static constexpr int TW_FINAL = RF > 1 ? (TWM == 0 ? RF - 1 : 1) : 0;
+    static constexpr int TW_PER_STAGE = 7;                    // W^1..W^7 of every radix-8 stage stay resident
+    static constexpr int TW_FINAL = RF > 1 ? RF - 1 : 0;
     static constexpr int NTW = TW_PER_STAGE * (NR8 - 1) + NB * TW_FINAL;
 
     // LDS image of the exchange buffer: element i lives at i + (i >> 3) for the
@@ -205,12 +193,8 @@ template <int LOGN> struct Fft {
             const int base = (t % ns) * (N / (ns * 8));
 #pragma unroll
             for (int r = 1; r < 8; ++r) {
-                const bool keep = TWM == 0 || (TWM == 1 && (r == 1 || r == 2 || r == 4)) || (TWM == 2 && r == 1);
-                if (keep) {
-                    if (!(SKIP8 && TWM == 0 && st == 1) && !(SKIP64 && TWM == 0 && st == 2))
-                        tw[n] = wtab[(r * base) & (N - 1)];
-                    ++n;
-                }
+                if (!(SKIP8 && st == 1) && !(SKIP64 && st == 2)) tw[n] = wtab[(r * base) & (N - 1)];
+                ++n;
             }
             ns *= 8;
         }
@@ -219,7 +203,7 @@ template <int LOGN> struct Fft {
             for (int b = 0; b < NB; ++b)
 #pragma unroll
                 for (int r = 1; r < RF; ++r)
-                    if (TWM == 0 || r == 1) tw[n++] = wtab[(r * (t + T * b)) & (N - 1)];
+                    tw[n++] = wtab[(r * (t + T * b)) & (N - 1)];
         }
     }
 
@@ -235,30 +219,12 @@ template <int LOGN> struct Fft {
         for (int i = t; i < 448; i += nthreads) tw64[i] = wtab[(((i >> 6) + 1) * (i & 63) * (N / 512)) & (N - 1)];
     }
 
-    // the seven twiddles W^1..W^7 of a radix-8 stage from the resident subset
+    // the seven twiddles W^1..W^7 of a radix-8 stage
     template <int S> static DEV void stage_twiddles(const cf *tw, int &n, cf *w)
     {
-        if (TWM == 0) {
 #pragma unroll
-            for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw[n + r]);
-            n += 7;
-        } else if (TWM == 1) {
-            w[0] = twid<S>(tw[n]); w[1] = twid<S>(tw[n + 1]); w[3] = twid<S>(tw[n + 2]);
-            n += 3;
-            w[2] = cmul(w[0], w[1]);
-            w[4] = cmul(w[3], w[0]);
-            w[5] = cmul(w[3], w[1]);
-            w[6] = cmul(w[3], w[2]);
-        } else {
-            w[0] = twid<S>(tw[n]);
-            n += 1;
-            w[1] = cmul(w[0], w[0]);
-            w[2] = cmul(w[1], w[0]);
-            w[3] = cmul(w[1], w[1]);
-            w[4] = cmul(w[3], w[0]);
-            w[5] = cmul(w[2], w[2]);
-            w[6] = cmul(w[3], w[2]);
-        }
+        for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw[n + r]);
+        n += 7;
     }
 
     // conjugate twiddles when S < 0 (table holds exp(+2 pi i m/N))
@@ -274,7 +240,7 @@ template <int LOGN> struct Fft {
         int n = 0;
         cf w[7];
         if (NR8 >= 2) {
-            if (DABGPU_TW8_LDS && TWM == 0 && tw8) {
+            if (DABGPU_TW8_LDS && tw8) {
 #pragma unroll
                 for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw8[r * 8 + (t & 7)]);
                 n += 7;
@@ -287,7 +253,7 @@ template <int LOGN> struct Fft {
             if (NR8 > 2 || RF > 1) exchange<8, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
-            if (TWM == 0 && tw64) {
+            if (tw64) {
 #pragma unroll
                 for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw64[r * 64 + (t & 63)]);
                 n += 7;
@@ -309,16 +275,8 @@ template <int LOGN> struct Fft {
         if (RF == 4) {
 #pragma unroll
             for (int b = 0; b < 2; ++b) {
-                cf w1, w2, w3;
-                if (TWM == 0) {
-                    w1 = twid<S>(tw[n]); w2 = twid<S>(tw[n + 1]); w3 = twid<S>(tw[n + 2]);
-                    n += 3;
-                } else {
-                    w1 = twid<S>(tw[n]);
-                    n += 1;
-                    w2 = cmul(w1, w1);
-                    w3 = cmul(w2, w1);
-                }
+                const cf w1 = twid<S>(tw[n]), w2 = twid<S>(tw[n + 1]), w3 = twid<S>(tw[n + 2]);
+                n += 3;
                 V x0 = v[b], x1 = cmul(v[b + 2], w1), x2 = cmul(v[b + 4], w2), x3 = cmul(v[b + 6], w3);
                 dft4<S>(x0, x1, x2, x3);
                 v[b] = x0; v[b + 2] = x1; v[b + 4] = x2; v[b + 6] = x3;
@@ -547,11 +505,9 @@ template <int NTP, int R> DEV void fir_block(const cf *__restrict__ sb, int j0,
 #pragma unroll
             for (int i = R - 1; i < R + G - 1; ++i) w[i] = sb[j0 + (g + 1) * G + i];
         }
-#if DABGPU_FIR_SCHED
         // keep the scheduler from hoisting every group's LDS loads to the top of the
         // unrolled block (that is what drove the kernel past 128 VGPRs into scratch)
         __builtin_amdgcn_sched_barrier(0);
-#endif
     }
 }
 
@@ -625,8 +581,7 @@ void tf_kernel(const TfArgs a)
     float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
     float *mag_l = taps_l + kMaxTaps;
     cf *unit8 = reinterpret_cast<cf *>(mag_l + 160);   // exp(i p pi/4) with exact 0 / +-1 entries
-    cf *hk_l = unit8 + 8;                               // DABGPU_HK_LDS: [6][T] filter response per lane
-    cf *tw8_l = hk_l + ((FIR && DABGPU_HK_LDS) ? 6 * T : 0);   // DABGPU_TW8_LDS: 7 x 8 twiddles
+    cf *tw8_l = unit8 + 8;                              // DABGPU_TW8_LDS: 7 x 8 twiddles
     if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
     cf *tw64_l = tw8_l + 56;                            // DABGPU_TW64_LDS: 7 x 64 twiddles (FIR variants)
     constexpr bool TW64 = (DABGPU_TW64_LDS || (GVAR && DABGPU_GVAR_TW64)) && FIR && F::NR8 >= 3;
@@ -669,7 +624,6 @@ void tf_kernel(const TfArgs a)
             const int bin = tt + T * rr[c];
             kpos[c] = (bin <= K / 2) ? bin - 1 : bin - N + K;
             if (FIR) hk[c] = a.t.fir_h[bin];
-            if (FIR && DABGPU_HK_LDS) hk_l[c * T + tt] = hk[c];
         }
     }
     int bitpos[6];
@@ -992,7 +946,7 @@ void tf_kernel(const TfArgs a)
             // unfiltered and filtered transform of the symbol in lockstep (see struct c2)
             cf valf[6];
 #pragma unroll
-            for (int c = 0; c < 6; ++c) valf[c] = cmul(val[c], DABGPU_HK_LDS ? hk_l[c * T + tt] : hk[c]);
+            for (int c = 0; c < 6; ++c) valf[c] = cmul(val[c], hk[c]);
             place(val, v);
             place(valf, z);
             c2 v2[8];
@@ -1083,7 +1037,7 @@ void tf_kernel(const TfArgs a)
                 // ---- second IFFT: carriers times the filter's frequency response ------
                 if (FROM_BITS) load_active(s, val);        // cheaper to rebuild than to keep 12 registers live
 #pragma unroll
-                for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], DABGPU_HK_LDS ? hk_l[c * T + tt] : hk[c]);
+                for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
                 place(val, v);
                 F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
             }
@@ -1172,9 +1126,6 @@ size_t tf_lds_bytes(int logN, unsigned flags)
     if (flags & TF_FIR) b += 4 * DABGPU_KBND * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
-#if DABGPU_HK_LDS
-    if (flags & TF_FIR) b += 6 * (N / 8) * sizeof(float2);
-#endif
 #if DABGPU_TW8_LDS
     b += 56 * sizeof(float2);
 #endif
