@@ -10,6 +10,7 @@
 //       <nframes> blocks of hot-path input, and writes what reaches the sink; then
 //       runs the same frames through the single DabGpuChain plugin.
 #include "Flowgraph.h"
+#include "Frontend.h"
 #include "GpuStages.h"
 
 #include <cstdio>
@@ -218,6 +219,42 @@ int run_cpu()
         CHECK(pd.process_metadata({m0}).empty());
         meta_vec_t r = pd.process_metadata({m1});
         CHECK(r.size() == 1 && r[0].ts.fct == 10);
+    }
+    // EtiReader: the byte stream may be cut anywhere (reference src/EtiReader.cpp:93-270 returns the
+    // number of bytes it could use); two frames fed in pieces of 7 bytes parse like two whole frames
+    {
+        std::vector<uint8_t> eti(2 * 6144, 0x55);
+        for (int f = 0; f < 2; ++f) {
+            uint8_t *p = eti.data() + f * 6144;
+            const uint8_t head[] = {0xFF, 0x07, 0x3A, 0xB6, static_cast<uint8_t>(8 + f), 0x81,
+                                    static_cast<uint8_t>((f << 5) | (1 << 3)), 0x40,
+                                    0x00, 0x00, static_cast<uint8_t>(0x22 << 2), 48,     // SAD 0, TPL 0x22, STL 48
+                                    0, 0, 0, 0};
+            std::memcpy(p, head, sizeof head);
+            for (int i = 0; i < 96 + 384; ++i) p[16 + i] = static_cast<uint8_t>(i * 7 + f);
+        }
+        double off = 0;
+        EtiReader whole(off), pieces(off);
+        Buffer a(6144, eti.data());
+        CHECK(whole.loadEtiData(a) == 6144 && whole.getFct() == 8 && whole.getFp() == 0 && whole.getMode() == 1);
+        CHECK(whole.getSubchannels().size() == 1 && whole.getSubchannels()[0]->framesize() == 384 &&
+              whole.getSubchannels()[0]->framesizeCu() == 96);
+        size_t fed = 0;
+        std::vector<uint8_t> pending;
+        while (fed < eti.size()) {
+            const size_t n = std::min<size_t>(7, eti.size() - fed);
+            pending.insert(pending.end(), eti.begin() + fed, eti.begin() + fed + n);
+            fed += n;
+            Buffer b(pending.size(), pending.data());
+            const int used = pieces.loadEtiData(b);
+            pending.erase(pending.begin(), pending.begin() + used);
+        }
+        Buffer f0, f1;
+        CHECK(pieces.getFct() == 9 && pieces.getFp() == 1 && pending.empty());
+        pieces.getFic()->process(&f0);
+        CHECK(f0.getLength() == 96 && f0[0] == 1 && f0[95] == static_cast<uint8_t>(95 * 7 + 1));
+        pieces.getSubchannels()[0]->process(&f1);
+        CHECK(f1.getLength() == 384 && f1[0] == static_cast<uint8_t>(96 * 7 + 1));
     }
     // pipelined stage inside a graph: N rounds in, N-1 frames out
     {

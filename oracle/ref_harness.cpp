@@ -25,6 +25,16 @@
 #include "FormatConverter.h"
 #include "TII.h"
 #include "PAPRStats.h"
+#include "EtiReader.h"
+#include "FicSource.h"
+#include "SubchannelSource.h"
+#include "PrbsGenerator.h"
+#include "ConvEncoder.h"
+#include "PuncturingEncoder.h"
+#include "TimeInterleaver.h"
+#include "FrameMultiplexer.h"
+#include "BlockPartitioner.h"
+#include <memory>
 
 #include <cstring>
 #include <string>
@@ -170,6 +180,177 @@ int ref_memless_poly(const float *in, size_t nsamples, const char *coef_file,
         st.process(&b1, &bo);
         st.process(&b2, &bo);
         return copy_out(bo, out, nsamples * sizeof(complexf));
+    } catch (const std::exception &) { return -1; }
+}
+
+// f-1: the ETI -> coded-bits front-end built from the reference's own classes and run in the order
+// DabModulator wires them (src/DabModulator.cpp:131-139,281-385); frames before the first FP == 0 are
+// parsed but not modulated (src/DabMod.cpp:684-693).  out receives one BlockPartitioner block per
+// completed transmission frame; returns the number of blocks, or -1 on exception.
+int ref_eti_frontend(const uint8_t *eti, size_t nframes, unsigned mode, uint8_t *out, size_t out_cap)
+{
+    try {
+        double tist_offset = 0.0;
+        EtiReader reader(tist_offset);
+        std::shared_ptr<FicSource> fic;
+        std::unique_ptr<PrbsGenerator> cifPrbs, ficPrbs;
+        std::unique_ptr<ConvEncoder> ficConv;
+        std::unique_ptr<PuncturingEncoder> ficPunc;
+        std::unique_ptr<FrameMultiplexer> cifMux;
+        std::unique_ptr<BlockPartitioner> cifPart;
+        struct Sub {
+            std::shared_ptr<SubchannelSource> src;
+            std::unique_ptr<PrbsGenerator> prbs;
+            std::unique_ptr<ConvEncoder> conv;
+            std::unique_ptr<PuncturingEncoder> punc;
+            std::unique_ptr<TimeInterleaver> ti;
+            Buffer b0, b1, b2, b3, b4;
+        };
+        std::vector<std::unique_ptr<Sub>> subs;
+        bool started = false;
+        int nblocks = 0;
+        size_t pos = 0;
+        Buffer part;      // BlockPartitioner fills ONE output buffer over the frames of a transmission frame
+        for (size_t f = 0; f < nframes; ++f) {
+            Buffer frame(6144, eti + f * 6144);
+            reader.loadEtiData(frame);
+            if (!started) {
+                if (reader.getFp() != 0) continue;
+                started = true;
+                cifPrbs.reset(new PrbsGenerator(864 * 8, 0x110));
+                cifMux.reset(new FrameMultiplexer(reader));
+                cifPart.reset(new BlockPartitioner(mode));
+                fic = reader.getFic();
+                const size_t n = fic->getFramesize();
+                ficPrbs.reset(new PrbsGenerator(n, 0x110));
+                ficConv.reset(new ConvEncoder(n));
+                ficPunc.reset(new PuncturingEncoder());
+                for (const auto &r : fic->get_rules()) ficPunc->append_rule(r);
+                ficPunc->append_tail_rule(PuncturingRule(3, 0xcccccc));
+                for (const auto &sc : reader.getSubchannels()) {
+                    std::unique_ptr<Sub> s(new Sub);
+                    s->src = sc;
+                    s->prbs.reset(new PrbsGenerator(sc->framesize(), 0x110));
+                    s->conv.reset(new ConvEncoder(sc->framesize()));
+                    s->punc.reset(new PuncturingEncoder(sc->framesizeCu()));
+                    for (const auto &r : sc->get_rules()) s->punc->append_rule(r);
+                    s->punc->append_tail_rule(PuncturingRule(3, 0xcccccc));
+                    s->ti.reset(new TimeInterleaver(sc->framesizeCu() * 8));
+                    subs.push_back(std::move(s));
+                }
+            }
+            Buffer prbs, f0, f1, f2, f3, cif;
+            cifPrbs->process({}, {&prbs});
+            fic->process(&f0);
+            ficPrbs->process({&f0}, {&f1});
+            ficConv->process(&f1, &f2);
+            ficPunc->process(&f2, &f3);
+            std::vector<Buffer *> muxin{&prbs};
+            // the subchannel sources are re-created by the reader only when the STC changes
+            const auto cur = reader.getSubchannels();
+            if (cur.size() != subs.size()) return -3;
+            for (size_t i = 0; i < subs.size(); ++i) {
+                Sub &s = *subs[i];
+                if (cur[i] != s.src) return -3;
+                s.src->process(&s.b0);
+                s.prbs->process({&s.b0}, {&s.b1});
+                s.conv->process(&s.b1, &s.b2);
+                s.punc->process(&s.b2, &s.b3);
+                s.ti->process(&s.b3, &s.b4);
+                muxin.push_back(&s.b4);
+            }
+            cifMux->process(muxin, &cif);
+            if (cifPart->process({&f3, &cif}, &part)) {
+                if (pos + part.getLength() > out_cap) return -2;
+                memcpy(out + pos, part.getData(), part.getLength());
+                pos += part.getLength();
+                ++nblocks;
+            }
+        }
+        return nblocks;
+    } catch (const std::exception &) { return -1; }
+}
+
+// f-1 piece by piece (each against one reference class)
+int ref_prbs(size_t framesize, const uint8_t *in /* may be NULL */, uint8_t *out)
+{
+    try {
+        PrbsGenerator g(framesize, 0x110);
+        Buffer bi, bo;
+        if (in) { fill(bi, in, framesize); g.process({&bi}, {&bo}); } else g.process({}, {&bo});
+        memcpy(out, bo.getData(), bo.getLength());
+        return (int)bo.getLength();
+    } catch (const std::exception &) { return -1; }
+}
+
+int ref_conv_encode(const uint8_t *in, size_t framesize, uint8_t *out)
+{
+    try {
+        ConvEncoder e(framesize);
+        Buffer bi, bo;
+        fill(bi, in, framesize);
+        e.process(&bi, &bo);
+        memcpy(out, bo.getData(), bo.getLength());
+        return (int)bo.getLength();
+    } catch (const std::exception &) { return -1; }
+}
+
+// sub-channel protection: the puncturing rules and CU count the reference derives from (STL, TPL);
+// rules: up to 8 (length, pattern) pairs.  Returns the number of rules, -1 when the reference throws.
+int ref_subchannel_profile(unsigned stl, unsigned tpl, uint32_t *rules, size_t *framesize_cu,
+                           size_t *bitrate)
+{
+    try {
+        SubchannelSource s(0, (uint16_t)stl, (uint8_t)tpl);
+        int n = 0;
+        for (const auto &r : s.get_rules()) {
+            if (n >= 8) return -2;
+            rules[2 * n] = (uint32_t)r.length();
+            rules[2 * n + 1] = r.pattern();
+            ++n;
+        }
+        *framesize_cu = s.framesizeCu();
+        *bitrate = s.bitrate();
+        return n;
+    } catch (const std::exception &) { return -1; }
+}
+
+// puncture `in` with the rules of (stl, tpl) plus the tail rule, as DabModulator configures it
+int ref_puncture(const uint8_t *in, size_t in_len, unsigned stl, unsigned tpl, int is_fic, unsigned mid,
+                 uint8_t *out)
+{
+    try {
+        std::unique_ptr<PuncturingEncoder> p;
+        if (is_fic) {
+            FicSource f(1, mid);
+            p.reset(new PuncturingEncoder());
+            for (const auto &r : f.get_rules()) p->append_rule(r);
+        } else {
+            SubchannelSource s(0, (uint16_t)stl, (uint8_t)tpl);
+            p.reset(new PuncturingEncoder(s.framesizeCu()));
+            for (const auto &r : s.get_rules()) p->append_rule(r);
+        }
+        p->append_tail_rule(PuncturingRule(3, 0xcccccc));
+        Buffer bi, bo;
+        fill(bi, in, in_len);
+        p->process(&bi, &bo);
+        memcpy(out, bo.getData(), bo.getLength());
+        return (int)bo.getLength();
+    } catch (const std::exception &) { return -1; }
+}
+
+// nframes frames of `framesize` bytes through ONE TimeInterleaver
+int ref_time_interleave(const uint8_t *in, size_t framesize, size_t nframes, uint8_t *out)
+{
+    try {
+        TimeInterleaver ti(framesize);
+        for (size_t f = 0; f < nframes; ++f) {
+            Buffer bi, bo;
+            fill(bi, in + f * framesize, framesize);
+            ti.process(&bi, &bo);
+            memcpy(out + f * framesize, bo.getData(), framesize);
+        }
+        return 0;
     } catch (const std::exception &) { return -1; }
 }
 

@@ -113,6 +113,11 @@ def main():
                               bool(np.array_equal(one[0], one[2]))}
             g["tii_disabled"] = {"all_zero": bool(not O.ref_tii(mode, 3, 5, 0, False, 2).any())}
         gold["modes"][str(mode)] = g
+    # f-1: the CPU front-end, every case of tests/golden/frontend_cases.py through the reference's classes
+    import importlib
+    from tests.golden.frontend_cases import run_cases
+    fe_mod = importlib.import_module("odr-dabmod_amd.frontend")
+    gold["frontend"] = run_cases(fe_mod.Frontend(fe_mod.bind(O.ref(), "ref_"), "ref_"))
     with open(os.path.join(HERE, "golden.json"), "w") as fo:
         json.dump(gold, fo, indent=1, sort_keys=True)
     print("wrote", os.path.join(HERE, "golden.json"))

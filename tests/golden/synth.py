@@ -58,3 +58,37 @@ def format_edges(fmt):
         e = [-200.0, -129.0, -128.5, -128.0, -127.99, -1.5, -0.99, -0.0, 0.0, 0.99, 1.5, 126.99, 127.0,
              127.5, 128.0, 200.0]
     return np.asarray(e, np.float32)
+
+
+def synth_eti(nframes, subchannels=((0, 48, 0x22),), mid=1, seed=1234, first_fct=0):
+    """Raw ETI(NI) frames (src/Eti.h:50-97): nframes x 6144 bytes.
+    subchannels: (SAD, STL in 64-bit words, TPL); FIC and MST payloads are pseudo-random bytes.
+    Default = BASELINE config 1: one 128 kbit/s sub-channel, EEP 3-A (96 CU)."""
+    fic_len = 128 if mid == 3 else 96
+    out = np.full((nframes, 6144), 0x55, np.uint8)
+    for n in range(nframes):
+        f = out[n]
+        fct = (first_fct + n) % 250
+        f[0] = 0xFF
+        f[1:4] = (0x07, 0x3A, 0xB6) if fct % 2 == 0 else (0xF8, 0xC5, 0x49)
+        mst = sum(stl * 8 for _, stl, _ in subchannels)
+        fl = (len(subchannels) * 4 + 4 + fic_len + mst) // 4          # words after FC up to EOF (not checked)
+        f[4] = fct
+        f[5] = 0x80 | len(subchannels)                                # FICF | NST
+        f[6] = ((fct % 8) << 5) | ((mid & 3) << 3) | ((fl >> 8) & 7)  # FP | MID | FL[10:8]
+        f[7] = fl & 0xFF
+        p = 8
+        for i, (sad, stl, tpl) in enumerate(subchannels):
+            f[p] = (i << 2) | ((sad >> 8) & 3)
+            f[p + 1] = sad & 0xFF
+            f[p + 2] = ((tpl & 0x3F) << 2) | ((stl >> 8) & 3)
+            f[p + 3] = stl & 0xFF
+            p += 4
+        f[p:p + 4] = (0, 0, 0, 0)                                      # EOH: MNSC, CRC (not checked)
+        p += 4
+        payload = synth_bits(fic_len + mst, seed=seed * 1000003 + n)
+        f[p:p + fic_len + mst] = payload
+        p += fic_len + mst
+        f[p:p + 4] = (0, 0, 0xFF, 0xFF)                                # EOF: CRC, RFU
+        f[p + 4:p + 8] = 0xFF                                          # TIST: not set
+    return out

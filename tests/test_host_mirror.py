@@ -143,3 +143,34 @@ def test_flowgraph_with_cfr_matches_oracle(tmp_path):
     assert abs(float(m.group(2)) - 100 * np.mean([s["num_error_clip"] / ns for s in st])) < 0.05
     assert abs(float(m.group(3)) - np.mean([s["mer_db"] for s in st])) < 0.01
     assert "ofdm papr: PAPR [dB]: N/A, N/A" in r.stdout        # fewer than nbSymbols * 50 blocks so far
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["complexf", "s16"])
+def test_config1_eti_file_to_iq_file(tmp_path, fmt):
+    """BASELINE config 1: Mode I, native 2.048 Msps, ETI file -> IQ file, no FIR / resampler, through
+    dabmod_file (CPU front-end + fused MI355X chain).  The front-end is bit-exact (tests/test_frontend.py),
+    so the expectation is the oracle chain run on the front-end's own blocks."""
+    import importlib
+    import oracle as O
+    from tests.golden.synth import synth_eti
+    build_host()
+    fe_mod = importlib.import_module("odr-dabmod_amd.frontend")
+    eti = synth_eti(24)
+    fin, fout = str(tmp_path / "in.eti"), str(tmp_path / "out.iq")
+    eti.tofile(fin)
+    tool = os.path.join(HOST, "dabmod_file")
+    r = subprocess.run([tool, fin, fout, "--format", fmt], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert r.stdout.split() == ["24", "6"]
+    bits = fe_mod.Frontend().eti_to_bits(eti, 1)
+    ref = O.Chain(mode=1, stages=O.STAGE_GAIN, gain_mode=2, normalise=1.0).process(bits)
+    if fmt == "complexf":
+        got = np.fromfile(fout, dtype=np.complex64).reshape(6, -1)
+        for f in range(6):
+            assert np.linalg.norm(got[f] - ref[f]) / np.linalg.norm(ref[f]) < 1e-6
+    else:
+        want, _ = O.format_convert(ref, "s16")
+        got = np.fromfile(fout, dtype=np.int16)
+        d = np.abs(got.astype(np.int32) - want.astype(np.int32))
+        assert got.size == want.size and d.max() <= 1 and (d != 0).mean() < 1e-2
