@@ -20,8 +20,8 @@ def build():
 
 
 def bind(lib, prefix):
-    """argtypes of the six entry points (the reference harness of oracle/_ref exports the same
-    signatures under the prefix ref_)."""
+    """argtypes of the six entry points, for any library exporting them under `prefix` (the tests
+    bind a harness over the reference's classes the same way)."""
     g = lambda n: getattr(lib, prefix + n)  # noqa: E731
     g("prbs").argtypes = [C.c_size_t, _U8P, _U8P]
     g("conv_encode").argtypes = [_U8P, C.c_size_t, _U8P]

@@ -5,8 +5,8 @@
 // Serial, bit-level, ~60 kB per transmission frame: it stays on the CPU (there is nothing for a
 // GPU to win), written from scratch with the reference's class names and constructor signatures
 // (file:line at each class) so that src/DabModulator.cpp:131-139,281-385 wires it unchanged.
-// Pure integer work: bit-exact against the reference's classes (tests/test_frontend.py, goldens
-// generated from oracle/_ref).  Not restated: timestamp decoding (MNSC/TIST -> metadata), EDI
+// Pure integer work: bit-exact against the reference's classes (tests/test_frontend.py and the
+// goldens it reads).  Not restated: timestamp decoding (MNSC/TIST -> metadata), EDI
 // input, FIC decoding for the remote control -- metadata and I/O, SURVEY 2 rows 19-20.
 #pragma once
 
