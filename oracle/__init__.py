@@ -378,12 +378,15 @@ class Chain:
         self.out_samples_per_tf = self._l.dabo_chain_out_samples_per_tf(self._h)
         self.in_bytes_per_tf = tf_input_bytes(mode)
 
-    def process(self, bits):
+    def process(self, bits, out=None):
         bits = _u8(bits).reshape(-1)
         if bits.size % self.in_bytes_per_tf:
             raise ValueError("oracle: chain input size not valid")
         n = bits.size // self.in_bytes_per_tf
-        out = np.empty(n * self.out_samples_per_tf, np.complex64)
+        if out is None:
+            out = np.empty(n * self.out_samples_per_tf, np.complex64)
+        out = out.reshape(-1)
+        assert out.dtype == np.complex64 and out.size == n * self.out_samples_per_tf and out.flags.c_contiguous
         _chk(self._l.dabo_chain_process(self._h, bits.ctypes.data_as(_U8P), n, _fp(out)), "chain")
         return out.reshape(n, self.out_samples_per_tf)
 
