@@ -65,6 +65,12 @@ def cpu_baseline(workload, seconds_budget=12.0):
                   am=(1.0, 0.05, -0.01, 0.002, 0.0), pm=(0.0, 0.02, 0.003, 0.0, 0.0))
     bits = np.stack([synth_bits(28800, seed=500 + i) for i in range(4)])
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
+    try:                                   # a container's CPU quota, when there is one (cgroup v2)
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            cores = max(1, min(cores, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        pass
 
     def timed_run(nthreads, seconds):
         """nthreads independent streams, each looping 4-frame calls until the deadline; frames / elapsed."""
