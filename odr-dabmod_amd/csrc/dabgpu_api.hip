@@ -342,7 +342,11 @@ int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
     const int nsym = c->g.nb_symbols + 1;
     if (n_frames >= 1024) return 1;
     int want = (int)((1024 + n_frames - 1) / n_frames);
-    want = std::min(want, (nsym + 6) / 7);  // at least 7 symbols per workgroup
+    want = std::min(want, (nsym + 6) / 7);  // at least 7 symbols per workgroup (each run pays a prologue and,
+                                            // with FIR, one look-ahead transform)
+    // a handful of frames cannot fill 256 CUs even so: latency counts, not efficiency -- one workgroup per
+    // CU, down to single symbols (B = 1: 55 -> 38 us per Mode-I frame)
+    if (n_frames * (size_t)want <= 128) want = std::min<int>(nsym, (int)((256 + n_frames - 1) / n_frames));
     return std::max(1, want);
 }
 
