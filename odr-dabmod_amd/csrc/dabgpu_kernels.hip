@@ -1842,10 +1842,10 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
 {
     constexpr int NIN = 1 << LOGNIN;
     const int Q = a.nout / a.nin;
-    // runs of hops: one extra (warm-up) hop per run; keep >= 2048 workgroups when the
-    // stream is long enough, never shorter than 12 hops per run.
-    // (long runs amortise the warm-up hop: 96 hops = one Mode-I frame when the stream has >= 1024 of them)
-    int hpr = (int)std::max<size_t>(12, std::min<size_t>(96, a.nhops / 1024));
+    // runs of hops: every run starts with one dual forward transform (half a hop's work).  Long streams
+    // get runs of 96 hops (one Mode-I frame); short ones are cut finer so that the launch still covers the
+    // chip (>= 512 workgroups when there are that many pairs of hops) -- latency, not efficiency, counts there
+    int hpr = (int)std::max<size_t>(2, std::min<size_t>(96, a.nhops / 512));
     const dim3 grid((unsigned)((a.nhops + hpr - 1) / hpr)), block(NIN / 8);
     const size_t lds = 2 * (size_t)(NIN + NIN / 8) * 16 + (2 + 56) * sizeof(float2) + (size_t)(NIN / 2) * sizeof(float);
     const bool poly = a.poly != nullptr;
