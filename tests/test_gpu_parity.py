@@ -661,3 +661,42 @@ def test_symbols_entry_point_matches_bits_entry_point(pkg):
         assert rel_rms(ya.reshape(-1), yb.reshape(-1).astype(np.complex128)) < 2e-7
     finally:
         md.close()
+
+
+def test_setters_from_another_thread_take_effect_between_frames(pkg):
+    """The remote-control contract: setters may come from any thread at any time; every
+    processed frame sees ONE consistent snapshot of the settings (here: digital gain 1.0 or 0.5, taps
+    default or halved -- never a mixture inside a frame)."""
+    import threading
+    md = pkg.Modulator(mode=2, max_frames=1)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        bits = golden_bits(2)
+        taps = O.fir_default_taps()
+        base = O.Chain(mode=2, stages=3, gain_mode=2, normalise=1.0 / 50000.0).process(bits)[0]
+        stop = threading.Event()
+
+        def rc_thread():
+            i = 0
+            while not stop.is_set():
+                md.set_gain(2, 1.0 if i & 1 else 0.5, 1.0 / 50000.0, 4.0)
+                md.set_fir_taps(taps if i & 2 else taps * np.float32(0.5))
+                md.set_tii(False, i % 24, i % 70)
+                i += 1
+
+        t = threading.Thread(target=rc_thread)
+        t.start()
+        seen = set()
+        try:
+            for _ in range(300):
+                y = md.chain(bits, 3)[0]
+                k = float(np.vdot(base, y).real / np.vdot(base, base).real)     # least-squares scale vs the base frame
+                scale = min((1.0, 0.5, 0.25), key=lambda c: abs(c - k))
+                assert rel_rms(y, base * np.float32(scale)) < 2e-6, k
+                seen.add(scale)
+        finally:
+            stop.set()
+            t.join()
+        assert len(seen) >= 2          # the settings really changed under the processing thread
+    finally:
+        md.close()
