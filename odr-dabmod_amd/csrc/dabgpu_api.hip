@@ -475,19 +475,15 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         a.out = (float2 *)c->d_b.p;
         a.out_stride = nsymN;
         HIPCHK(c, launch_tf(a, flags, s));
-        float2 *gout = native_out;
-        if (mask & DABGPU_STAGE_FIR) {
-            HIPCHK(c, c->d_c.reserve(n_frames * native * sizeof(float2)));
-            gout = (float2 *)c->d_c.p;
-        }
-        if (c->cur.overlap > 0)
-            HIPCHK(c, launch_guard_window((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
-                                          (const float *)c->d_window.p, gout, s));
-        else
-            HIPCHK(c, launch_guard_copy((const float2 *)c->d_b.p, n_frames, c->g, gout, s));
         if (mask & DABGPU_STAGE_FIR)
-            HIPCHK(c, launch_fir(gout, native, n_frames, (const float *)c->d_taps.p,
-                                 (int)c->cur.taps.size(), native_out, s));
+            HIPCHK(c, launch_guard_fir((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
+                                       (const float *)c->d_window.p, c->cur.taps.data(),
+                                       (int)c->cur.taps.size(), native_out, s));
+        else if (c->cur.overlap > 0)
+            HIPCHK(c, launch_guard_window((const float2 *)c->d_b.p, n_frames, c->g, (int)c->cur.overlap,
+                                          (const float *)c->d_window.p, native_out, s));
+        else
+            HIPCHK(c, launch_guard_copy((const float2 *)c->d_b.p, n_frames, c->g, native_out, s));
     }
 
     return DABGPU_OK;
@@ -1070,7 +1066,7 @@ int dabgpu_fir_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out
     if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
     HIPCHK(c, c->d_b.reserve(std::max<size_t>(in_bytes, 16)));
     HIPCHK(c, launch_fir((const float2 *)c->d_a.p, in_bytes / sizeof(float2), 1,
-                         (const float *)c->d_taps.p, (int)c->cur.taps.size(), (float2 *)c->d_b.p, c->stream));
+                         c->cur.taps.data(), (int)c->cur.taps.size(), (float2 *)c->d_b.p, c->stream));
     return io.out(out, c->d_b.p, in_bytes);
 }
 

@@ -79,6 +79,10 @@ hipError_t launch_guard_copy(const float2 *in, size_t n_frames, Geometry g, floa
                              hipStream_t s);
 hipError_t launch_guard_window(const float2 *in, size_t n_frames, Geometry g, int overlap,
                                const float *window, float2 *out, hipStream_t s);
+// guard interval (copy or windowed) + FIR in one pass over the IFFT output ((nb_symbols+1) x N per frame).
+// For this and launch_fir, `taps` is a HOST pointer to ntaps floats: they travel as a kernel argument.
+hipError_t launch_guard_fir(const float2 *in, size_t n_frames, Geometry g, int overlap, const float *window,
+                            const float *taps, int ntaps, float2 *out, hipStream_t s);
 hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, const float *taps,
                       int ntaps, float2 *out, hipStream_t s);
 hipError_t launch_poly(const float2 *in, size_t nsamples, const float *am, const float *pm,

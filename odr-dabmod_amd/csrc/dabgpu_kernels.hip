@@ -479,31 +479,36 @@ template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, 
 // at j0; taps are wave-uniform (SGPR operands).  out[j] = sum_k taps[k]*sb[j+k]
 // accumulated in tap order (reference src/FIRFilter.cpp:168-184; fused
 // multiply-add instead of mul+add: float tolerance class).
-template <int NTP, int R> DEV void fir_block(const cf *__restrict__ sb, int j0,
-                                             const float *__restrict__ taps, cf *acc)
+// The stream buffer is padded one slot per 8 samples (fir_pad): lane l starts at sample 8 l, and a lane
+// stride of 64 bytes would put the 64 lanes of a wave on four banks (16-way conflicts); 72 bytes spreads
+// them over all 64.
+DEV constexpr int fir_pad(int j) { return j + (j >> 3); }
+// taps as a kernel argument by value: they arrive in SGPRs through scalar loads (read through a pointer
+// they come as vector loads + v_readlane, with a hazard nop in front of every multiply)
+template <int NTP> struct FirTaps { float t[NTP]; };
+// lane = &sb[fir_pad(8 l)] = sb + 9 l: every access below is lane + a compile-time offset
+template <int NTP, int R> DEV void fir_block(const cf *__restrict__ lane, const FirTaps<NTP> &taps, cf *acc)
 {
+    static_assert(R == 8, "the padded addressing assumes 8 outputs per lane");
     constexpr int G = 8;  // taps per window refill
     cf w[R + G - 1];
 #pragma unroll
-    for (int i = 0; i < R + G - 1; ++i) w[i] = sb[j0 + i];
+    for (int i = 0; i < R + G - 1; ++i) w[i] = lane[fir_pad(i)];
 #pragma unroll
     for (int i = 0; i < R; ++i) acc[i] = mk(0.f, 0.f);
 #pragma unroll
     for (int g = 0; g < NTP / G; ++g) {
 #pragma unroll
         for (int jj = 0; jj < G; ++jj) {
-            const float tp = taps[g * G + jj];
+            const float tp = taps.t[g * G + jj];
 #pragma unroll
-            for (int i = 0; i < R; ++i) {
-                acc[i].x = fmaf(w[i + jj].x, tp, acc[i].x);
-                acc[i].y = fmaf(w[i + jj].y, tp, acc[i].y);
-            }
+            for (int i = 0; i < R; ++i) acc[i] = w[i + jj] * tp + acc[i];   // one v_pk_fma_f32 (re, im) per tap
         }
         if (g + 1 < NTP / G) {
 #pragma unroll
             for (int i = 0; i < R - 1; ++i) w[i] = w[i + G];
 #pragma unroll
-            for (int i = R - 1; i < R + G - 1; ++i) w[i] = sb[j0 + (g + 1) * G + i];
+            for (int i = R - 1; i < R + G - 1; ++i) w[i] = lane[fir_pad((g + 1) * G + i)];
         }
         // keep the scheduler from hoisting every group's LDS loads to the top of the
         // unrolled block (that is what drove the kernel past 128 VGPRs into scratch)
@@ -1247,8 +1252,61 @@ template <int LOGN> __global__ void gain_kernel(const cf *__restrict__ in, size_
     }
 }
 
-// a8 GuardIntervalInserter, overlap 0 (src/GuardIntervalInserter.cpp:301-319):
-// pure gather, one lane per output sample.
+// a8 GuardIntervalInserter as a gather: sample p of a frame's output stream from the frame's
+// (nb_symbols+1) x N IFFT output x0.
+// Overlap 0 (src/GuardIntervalInserter.cpp:301-319): a pure copy.
+// (segment s, offset o inside it) of stream position p
+DEV void guard_locate(const Geometry &g, int p, int &s, int &o)
+{
+    if (p < g.null_size) { s = 0; o = p; }
+    else { s = 1 + (p - g.null_size) / g.sym_size; o = (p - g.null_size) % g.sym_size; }
+}
+
+DEV cf guard_copy_at(const cf *__restrict__ x0, const Geometry &g, int s, int o)
+{
+    const int cpl = (s == 0 ? g.null_size : g.sym_size) - g.N;
+    const int n = o < cpl ? g.N - cpl + o : o - cpl;
+    return x0[(size_t)s * (size_t)g.N + (size_t)n];
+}
+
+// Raised-cosine overlap W > 0 (src/GuardIntervalInserter.cpp:149-300): every output sample is its
+// own symbol's sample times a window factor, plus (inside 2W-wide seams) one neighbour term.
+// Products and the sum are rounded separately, as in the reference.
+DEV cf guard_window_at(const cf *__restrict__ x0, const Geometry &g, int W, const float *__restrict__ win, int s,
+                       int o)
+{
+#pragma clang fp contract(off)  // products and sums rounded separately, like the reference
+    const int N = g.N, nsym = g.nb_symbols + 1;
+    const int seg = s == 0 ? g.null_size : g.sym_size;
+    const int cpl = seg - N;
+    const cf *x = x0 + (size_t)s * (size_t)N;
+    const bool last = (s == nsym - 1);
+    if (s >= 1 && o < W) {
+        // overwritten first by the previous symbol's suffix (1/2 -> 0), then += own rising edge
+        const cf *xp = x - N;
+        const float fs = win[W - 1 - o];
+        cf r = mk(xp[o].x * fs, xp[o].y * fs);
+        const float fr = win[W + o];
+        const cf xr = x[N - cpl + o];
+        const float pr_ = xr.x * fr, pi_ = xr.y * fr;
+        return mk(r.x + pr_, r.y + pi_);
+    }
+    const int n = o < cpl ? N - cpl + o : o - cpl;
+    if (!last && o >= seg - W) {
+        // falling half window 1 -> 1/2, then the next symbol's rising edge is added
+        const int i2 = o - (seg - W);
+        const float ff = win[2 * W - 1 - i2];
+        const cf r = mk(x[n].x * ff, x[n].y * ff);
+        const cf *xn = x + N;
+        const int cpn = g.sym_size - N;
+        const cf xr = xn[N - cpn - W + i2];
+        const float fr = win[i2];
+        const float pr_ = xr.x * fr, pi_ = xr.y * fr;
+        return mk(r.x + pr_, r.y + pi_);
+    }
+    return x[n];
+}
+
 __global__ void guard_copy_kernel(const cf *__restrict__ in, size_t n_frames, Geometry g,
                                   cf *__restrict__ out)
 {
@@ -1256,89 +1314,107 @@ __global__ void guard_copy_kernel(const cf *__restrict__ in, size_t n_frames, Ge
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_frames * tf) return;
     const size_t f = i / tf;
-    const int p = (int)(i - f * tf);
-    int s, o, cpl;
-    if (p < g.null_size) { s = 0; o = p; cpl = g.null_size - g.N; }
-    else { s = 1 + (p - g.null_size) / g.sym_size; o = (p - g.null_size) % g.sym_size; cpl = g.sym_size - g.N; }
-    const int n = o < cpl ? g.N - cpl + o : o - cpl;
-    out[i] = in[(f * (size_t)(g.nb_symbols + 1) + (size_t)s) * (size_t)g.N + (size_t)n];
+    int s, o;
+    guard_locate(g, (int)(i - f * tf), s, o);
+    out[i] = guard_copy_at(in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N, g, s, o);
 }
 
-// a8 with raised-cosine overlap W > 0 (src/GuardIntervalInserter.cpp:149-300),
-// reformulated as a gather: every output sample is its own symbol's sample
-// times a window factor, plus (inside 2W-wide seams) one neighbour term.
-// Products and the sum are rounded separately, as in the reference.
 __global__ void guard_window_kernel(const cf *__restrict__ in, size_t n_frames, Geometry g, int W,
                                     const float *__restrict__ win, cf *__restrict__ out)
 {
-#pragma clang fp contract(off)  // products and sums rounded separately, like the reference
     const size_t tf = (size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n_frames * tf) return;
     const size_t f = i / tf;
-    const int p = (int)(i - f * tf);
-    const int N = g.N, nsym = g.nb_symbols + 1;
-    int s, o, seg;
-    if (p < g.null_size) { s = 0; o = p; seg = g.null_size; }
-    else { s = 1 + (p - g.null_size) / g.sym_size; o = (p - g.null_size) % g.sym_size; seg = g.sym_size; }
-    const int cpl = seg - N;
-    const cf *x = in + (f * (size_t)nsym + (size_t)s) * (size_t)N;
-    const bool last = (s == nsym - 1);
-    cf r;
-    bool have = false;
-    // own contribution, written with '=' by the reference
-    if (s >= 1 && o < W) {
-        // overwritten first by the previous symbol's suffix (1/2 -> 0), then += own rising edge
-        const cf *xp = x - N;
-        const float fs = win[W - 1 - o];
-        r = mk(xp[o].x * fs, xp[o].y * fs);
-        const float fr = win[W + o];
-        const cf xr = x[N - cpl + o];
-        { const float pr_ = xr.x * fr, pi_ = xr.y * fr; r = mk(r.x + pr_, r.y + pi_); }
-        have = true;
-    }
-    if (!have) {
-        const int n = o < cpl ? N - cpl + o : o - cpl;
-        if (!last && o >= seg - W) {
-            // falling half window 1 -> 1/2, then the next symbol's rising edge is added
-            const int i2 = o - (seg - W);
-            const float ff = win[2 * W - 1 - i2];
-            r = mk(x[n].x * ff, x[n].y * ff);
-            const cf *xn = x + N;
-            const int cpn = g.sym_size - N;
-            const cf xr = xn[N - cpn - W + i2];
-            const float fr = win[i2];
-            { const float pr_ = xr.x * fr, pi_ = xr.y * fr; r = mk(r.x + pr_, r.y + pi_); }
-        } else {
-            r = x[n];
-        }
-    }
-    out[i] = r;
+    int s, o;
+    guard_locate(g, (int)(i - f * tf), s, o);
+    out[i] = guard_window_at(in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N, g, W, win, s, o);
 }
 
 // a9 FIRFilter stand-alone (src/FIRFilter.cpp:162-192): LDS-tiled look-ahead FIR,
 // truncated at the end of each frame.
 template <int NTP> __global__ __launch_bounds__(256)
-void fir_kernel(const cf *__restrict__ in, size_t frame_samples, const float *__restrict__ taps,
+void fir_kernel(const cf *__restrict__ in, size_t frame_samples, const FirTaps<NTP> taps,
                 cf *__restrict__ out)
 {
     constexpr int R = 8, TILE = 256 * R;
-    __shared__ cf sb[TILE + NTP + R + 8];
+    __shared__ cf sb[fir_pad(TILE + NTP + R + 8) + 1];
     const size_t f = blockIdx.y;
     const size_t base = (size_t)blockIdx.x * TILE;
     const cf *fin = in + f * frame_samples;
-    for (int i = threadIdx.x; i < TILE + NTP + R + 8; i += 256) {
-        const size_t p = base + (size_t)i;
-        sb[i] = p < frame_samples ? fin[p] : mk(0.f, 0.f);
+    constexpr int LIMIT = TILE + NTP + R + 8, KMAX = (LIMIT + 255) / 256;
+    cf fetched[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const size_t p = base + threadIdx.x + 256 * (size_t)k;
+        fetched[k] = (p < frame_samples && (int)threadIdx.x + 256 * k < LIMIT) ? fin[p] : mk(0.f, 0.f);
     }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if ((int)threadIdx.x + 256 * k < LIMIT) sb[fir_pad((int)threadIdx.x + 256 * k)] = fetched[k];
     lds_barrier();
     cf acc[R];
     const int j0 = threadIdx.x * R;
-    fir_block<NTP, R>(sb, j0, taps, acc);
+    fir_block<NTP, R>(sb + 9 * threadIdx.x, taps, acc);
+    // a lane holds 8 consecutive outputs (64 bytes apart from its neighbour's): back through LDS so that
+    // every store instruction writes 512 contiguous bytes
+    lds_barrier();
 #pragma unroll
-    for (int i = 0; i < R; ++i) {
-        const size_t p = base + (size_t)(j0 + i);
-        if (p < frame_samples) out[f * frame_samples + p] = acc[i];
+    for (int i = 0; i < R; ++i) sb[fir_pad(j0 + i)] = acc[i];
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const size_t p = base + threadIdx.x + 256 * (size_t)k;
+        if (p < frame_samples) out[f * frame_samples + p] = sb[fir_pad((int)threadIdx.x + 256 * k)];
+    }
+}
+
+// a8 + a9 in one pass for the chains that cannot use the frame kernel's fused epilogue (windowed guard
+// interval, crest-factor reduction, filters longer than the cyclic prefix): the FIR's LDS tile is filled
+// straight from the IFFT output through the guard-interval gather, so the guard-extended stream never
+// goes to HBM (1.57 MB written + 1.57 MB read per Mode-I frame less).
+template <int NTP> __global__ __launch_bounds__(256)
+void guard_fir_kernel(const cf *__restrict__ in, Geometry g, int W, const float *__restrict__ win,
+                      const FirTaps<NTP> taps, cf *__restrict__ out)
+{
+    constexpr int R = 8, TILE = 256 * R;
+    __shared__ cf sb[fir_pad(TILE + NTP + R + 8) + 1];
+    const size_t f = blockIdx.y;
+    const int tf = g.null_size + g.nb_symbols * g.sym_size;
+    const int base = (int)blockIdx.x * TILE;
+    const cf *x0 = in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N;
+    // The lane's samples are 256 apart: locate the first one, then step (no division per sample).
+    // All gathers are issued before the first LDS store, so the lane waits for memory once, not per sample.
+    constexpr int LIMIT = TILE + NTP + R + 8, KMAX = (LIMIT + 255) / 256;
+    int sg, og;
+    guard_locate(g, min(base + (int)threadIdx.x, tf - 1), sg, og);
+    cf fetched[KMAX];
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k) {
+        const int p = base + (int)threadIdx.x + 256 * k;
+        fetched[k] = mk(0.f, 0.f);
+        if (p < tf && (int)threadIdx.x + 256 * k < LIMIT)
+            fetched[k] = W > 0 ? guard_window_at(x0, g, W, win, sg, og) : guard_copy_at(x0, g, sg, og);
+        og += 256;
+        for (int len = sg == 0 ? g.null_size : g.sym_size; og >= len; len = g.sym_size) { og -= len; ++sg; }
+    }
+#pragma unroll
+    for (int k = 0; k < KMAX; ++k)
+        if ((int)threadIdx.x + 256 * k < LIMIT) sb[fir_pad((int)threadIdx.x + 256 * k)] = fetched[k];
+    lds_barrier();
+    cf acc[R];
+    const int j0 = threadIdx.x * R;
+    fir_block<NTP, R>(sb + 9 * threadIdx.x, taps, acc);
+    // a lane holds 8 consecutive outputs (64 bytes apart from its neighbour's): back through LDS so that
+    // every store instruction writes 512 contiguous bytes
+    lds_barrier();
+#pragma unroll
+    for (int i = 0; i < R; ++i) sb[fir_pad(j0 + i)] = acc[i];
+    lds_barrier();
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+        const int p = base + (int)threadIdx.x + 256 * k;
+        if (p < tf) out[f * (size_t)tf + (size_t)p] = sb[fir_pad((int)threadIdx.x + 256 * k)];
     }
 }
 
@@ -1459,10 +1535,34 @@ hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, c
     if (frame_samples == 0 || n_frames == 0) return hipSuccess;
     if (ntaps < 1 || ntaps > kMaxTaps) return hipErrorInvalidValue;
     const dim3 grid(blocks_for(frame_samples, 256 * 8), (unsigned)n_frames);
-    if (ntaps <= 48)
-        hipLaunchKernelGGL(fir_kernel<48>, grid, dim3(256), 0, s, in, frame_samples, taps, out);
-    else
-        hipLaunchKernelGGL(fir_kernel<128>, grid, dim3(256), 0, s, in, frame_samples, taps, out);
+    if (ntaps <= 48) {
+        FirTaps<48> t{};
+        std::copy(taps, taps + ntaps, t.t);
+        hipLaunchKernelGGL(fir_kernel<48>, grid, dim3(256), 0, s, in, frame_samples, t, out);
+    } else {
+        FirTaps<128> t{};
+        std::copy(taps, taps + ntaps, t.t);
+        hipLaunchKernelGGL(fir_kernel<128>, grid, dim3(256), 0, s, in, frame_samples, t, out);
+    }
+    return hipGetLastError();
+}
+
+hipError_t launch_guard_fir(const float2 *in, size_t n_frames, Geometry g, int overlap, const float *window,
+                            const float *taps, int ntaps, float2 *out, hipStream_t s)
+{
+    if (n_frames == 0) return hipSuccess;
+    if (ntaps < 1 || ntaps > kMaxTaps) return hipErrorInvalidValue;
+    const size_t tf = (size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size;
+    const dim3 grid(blocks_for(tf, 256 * 8), (unsigned)n_frames);
+    if (ntaps <= 48) {
+        FirTaps<48> t{};
+        std::copy(taps, taps + ntaps, t.t);
+        hipLaunchKernelGGL(guard_fir_kernel<48>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+    } else {
+        FirTaps<128> t{};
+        std::copy(taps, taps + ntaps, t.t);
+        hipLaunchKernelGGL(guard_fir_kernel<128>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+    }
     return hipGetLastError();
 }
 

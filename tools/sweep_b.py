@@ -10,6 +10,12 @@ st = torch.cuda.Stream()
 def run(B, chunks, mask, iters=8):
     md = P.Modulator(mode=1, max_frames=B, chunks_per_frame=chunks)
     md.set_gain(2, 1.0, 1 / 50000., 4.0)
+    if os.environ.get("CFR"):
+        md.set_cfr(True, 50.0, 0.1)
+    if os.environ.get("WIN"):
+        md.set_window_overlap(int(os.environ["WIN"]))
+    if os.environ.get("TII"):
+        md.set_tii(True, 3, 5)
     if mask & 4:
         md.set_resampler(2048000, 8192000)
         md.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0])
