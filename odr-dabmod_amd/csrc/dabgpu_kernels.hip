@@ -589,6 +589,8 @@ void tf_kernel(const TfArgs a)
     cf *tw8_l = unit8 + 8;                              // DABGPU_TW8_LDS: 7 x 8 twiddles
     if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
     cf *tw64_l = tw8_l + 56;                            // DABGPU_TW64_LDS: 7 x 64 twiddles (FIR variants)
+    // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
+    float *cfr_red = reinterpret_cast<float *>(tw64_l + 448);
     constexpr bool TW64 = (DABGPU_TW64_LDS || (GVAR && DABGPU_GVAR_TW64)) && FIR && F::NR8 >= 3;
     if (TW64) F::fill_tw64(a.t.twiddle, tw64_l, t, (int)blockDim.x);
     if (t < 8) {
@@ -718,15 +720,15 @@ void tf_kernel(const TfArgs a)
     auto cfr_symbol = [&](cf *v, const cf *refv, int s, bool stats) __attribute__((always_inline)) {
         const float clip2 = a.cfr_clip * a.cfr_clip, eclip2 = a.cfr_errclip * a.cfr_errclip;   // :315, :339
         const bool mer_sym = stats && s > 0 && s == (a.cfr_mer_base + frame) % nsym;             // :198, :250
+        constexpr int NW = (T + 63) / 64;
         cf before[8];
-        float pk = 0.f;
-        double sm = 0.;
+        float pk = 0.f, sm = 0.f;
         unsigned nclip = 0, neclip = 0;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
             pk = fmaxf(pk, mag2);
-            sm += (double)mag2;
+            sm += mag2;
             before[m] = v[m];
             if (mag2 > clip2) {                                   // :320-330
                 const float f = sqrtf(clip2 / mag2);
@@ -735,18 +737,22 @@ void tf_kernel(const TfArgs a)
             }
         }
         if (stats) {
-            // PAPRStats::process_block before CFR (src/PAPRStats.cpp:41-60)
-            double dummy = 0.;
-            sm = lane_on ? sm : 0.;
-            pk = block_max<T>(lane_on ? pk : 0.f, red, t);
-            block_sum2<T>(sm, dummy, red, t);
-            if (t == 0) {
-                double *pp = a.cfr_papr + ((size_t)frame * nsym + s) * 4;
-                pp[0] = (double)pk;
-                pp[1] = sm / (double)N;
-            }
+            // PAPRStats::process_block before CFR (src/PAPRStats.cpp:41-60): per-wave partials now,
+            // combined by lane 0 behind the forward transform's barriers
+            pk = wave_max_dpp(lane_on ? pk : 0.f);
+            sm = wave_sum_dpp(lane_on ? sm : 0.f);
+            if ((t & 63) == 0) { cfr_red[2 * (t >> 6)] = pk; cfr_red[2 * (t >> 6) + 1] = sm; }
         }
         F::template run<-1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+        if (stats && t == 0) {
+            float p = 0.f;
+            double q = 0.;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { p = fmaxf(p, cfr_red[2 * w]); q += (double)cfr_red[2 * w + 1]; }
+            double *pp = a.cfr_papr + ((size_t)frame * nsym + s) * 4;
+            pp[0] = (double)p;
+            pp[1] = q / (double)N;
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const cf c = cscale(v[m], 1.0f / (float)N);         // :349-350 (a power of two: exact)
@@ -768,33 +774,42 @@ void tf_kernel(const TfArgs a)
                 if (n2) atomicAdd(a.cfr_counts + 2 * (size_t)frame + 1, n2);
             }
             if (s > 0) {                                          // :246-248: symbol 0 is skipped
-                float pk2 = 0.f;
-                double sm2 = 0., siq = 0., sdl = 0.;
+                float pk2 = 0.f, sm2 = 0.f, siq = 0.f, sdl = 0.f;
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
                     pk2 = fmaxf(pk2, mag2);
-                    sm2 += (double)mag2;
+                    sm2 += mag2;
                     const cf d = csub(v[m], before[m]);
-                    siq += (double)(before[m].x * before[m].x + before[m].y * before[m].y);
-                    sdl += (double)(d.x * d.x + d.y * d.y);
+                    siq += before[m].x * before[m].x + before[m].y * before[m].y;
+                    sdl += d.x * d.x + d.y * d.y;
                 }
-                double dummy = 0.;
-                sm2 = lane_on ? sm2 : 0.;
-                pk2 = block_max<T>(lane_on ? pk2 : 0.f, red, t);
-                block_sum2<T>(sm2, dummy, red, t);
+                pk2 = wave_max_dpp(lane_on ? pk2 : 0.f);
+                sm2 = wave_sum_dpp(lane_on ? sm2 : 0.f);
+                siq = wave_sum_dpp(lane_on ? siq : 0.f);
+                sdl = wave_sum_dpp(lane_on ? sdl : 0.f);
+                float *r2 = cfr_red + 2 * NW;
+                if ((t & 63) == 0) {
+                    r2[4 * (t >> 6)] = pk2; r2[4 * (t >> 6) + 1] = sm2;
+                    r2[4 * (t >> 6) + 2] = siq; r2[4 * (t >> 6) + 3] = sdl;
+                }
+                lds_barrier();
                 if (t == 0) {
+                    float p = 0.f;
+                    double q = 0., iq = 0., dl = 0.;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        p = fmaxf(p, r2[4 * w]);
+                        q += (double)r2[4 * w + 1];
+                        iq += (double)r2[4 * w + 2];
+                        dl += (double)r2[4 * w + 3];
+                    }
                     double *pp = a.cfr_papr + ((size_t)frame * nsym + s) * 4;
-                    pp[2] = (double)pk2;
-                    pp[3] = sm2 / (double)N;
-                }
-                if (mer_sym) {                                    // :250-273 (wave-uniform branch)
-                    siq = lane_on ? siq : 0.;
-                    sdl = lane_on ? sdl : 0.;
-                    block_sum2<T>(siq, sdl, red, t);
-                    if (t == 0) {
-                        a.cfr_mer[2 * (size_t)frame] = siq;
-                        a.cfr_mer[2 * (size_t)frame + 1] = sdl;
+                    pp[2] = (double)p;
+                    pp[3] = q / (double)N;
+                    if (mer_sym) {                                // :250-273
+                        a.cfr_mer[2 * (size_t)frame] = iq;
+                        a.cfr_mer[2 * (size_t)frame + 1] = dl;
                     }
                 }
             }
@@ -1135,6 +1150,7 @@ size_t tf_lds_bytes(int logN, unsigned flags)
     b += 56 * sizeof(float2);
 #endif
     if ((flags & TF_FIR) && (DABGPU_TW64_LDS || ((flags & TF_GVAR) && DABGPU_GVAR_TW64))) b += 448 * sizeof(float2);
+    if (flags & TF_CFR) b += (448 * sizeof(float2)) + 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red sits behind the tw64 slot
     return b;
 }
 
