@@ -17,7 +17,10 @@ class StreamGroup:
         self._dist = dist
         self._torch = torch
         self.backend = backend
-        if self.world > 1 and not dist.is_initialized():
+        # DABGPU_FORCE_DIST=1 initialises the process group for a single rank too (exercises the RCCL path
+        # on a one-GPU box)
+        self._collective = self.world > 1 or os.environ.get("DABGPU_FORCE_DIST") == "1"
+        if self._collective and not dist.is_initialized():
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             self.backend = backend
@@ -27,12 +30,12 @@ class StreamGroup:
             dist.init_process_group(backend, **kw)
 
     def barrier(self):
-        if self.world > 1:
+        if self._collective:
             self._dist.barrier()
 
     def max_over_ranks(self, seconds):
         """The job's elapsed time is the slowest rank's."""
-        if self.world == 1:
+        if not self._collective:
             return float(seconds)
         dev = "cuda:%d" % self.local_rank if self.backend == "nccl" else "cpu"
         t = self._torch.tensor([float(seconds)], dtype=self._torch.float64, device=dev)
@@ -59,5 +62,5 @@ class StreamGroup:
         return self.world * frames_per_step_per_gpu * steps / seconds
 
     def close(self):
-        if self.world > 1 and self._dist.is_initialized():
+        if self._collective and self._dist.is_initialized():
             self._dist.destroy_process_group()
