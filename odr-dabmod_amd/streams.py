@@ -3,8 +3,25 @@ stream of transmission frames (frames are independent units, so the
 path shards with NO data-path collective).  torch.distributed (backend "nccl" =
 RCCL on ROCm, "gloo" in CPU tests) is used only to bracket the timed region and
 to combine the ranks' clocks."""
+import contextlib
 import os
+import sys
 import time
+
+
+@contextlib.contextmanager
+def _stdout_to_stderr():
+    """RCCL prints a version banner on the C-level stdout when a communicator is created; the bench's
+    stdout carries exactly one JSON line, so the banner is sent to stderr."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 class StreamGroup:
@@ -27,7 +44,9 @@ class StreamGroup:
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", self.local_rank)
-            dist.init_process_group(backend, **kw)
+            with _stdout_to_stderr():
+                dist.init_process_group(backend, **kw)
+                dist.barrier()                    # communicator creation (and its banner) happens here at the latest
 
     def barrier(self):
         if self._collective:
