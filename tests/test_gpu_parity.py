@@ -700,3 +700,57 @@ def test_setters_from_another_thread_take_effect_between_frames(pkg):
         assert len(seen) >= 2          # the settings really changed under the processing thread
     finally:
         md.close()
+
+
+def test_two_contexts_run_concurrently_on_their_own_streams(pkg):
+    """One context per stream, no shared mutable state in the library: two host threads drive two
+    contexts with different settings at the same time (what a multi-multiplex head-end does)."""
+    import threading
+    import torch
+    per = O.tf_input_bytes(1)
+    bits = [np.stack([synth_bits(per, seed=1400 + 10 * k + i) for i in range(6)]) for k in range(2)]
+    kw = [dict(gain_mode=2, normalise=1.0 / 50000.0), dict(gain_mode=1, normalise=1.0)]
+    refs = [O.Chain(mode=1, stages=3, **kw[k]).process(bits[k]) for k in range(2)]
+    results, errors = [None, None], []
+
+    def run(k):
+        try:
+            md = pkg.Modulator(mode=1, max_frames=6)
+            md.set_gain(kw[k]["gain_mode"], 1.0, kw[k]["normalise"], 4.0)
+            st = torch.cuda.Stream()
+            with torch.cuda.stream(st):
+                d_bits = torch.from_numpy(bits[k]).cuda()
+                d_out = torch.empty((6, 196608), dtype=torch.complex64, device="cuda")
+                for _ in range(20):
+                    md.chain_dev(d_bits, 6, 3, d_out, stream=st.cuda_stream)
+                st.synchronize()
+                results[k] = d_out.cpu().numpy()
+            md.close()
+        except Exception as e:          # surfaced in the main thread below
+            errors.append(e)
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(2)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(2):
+        for f in range(6):
+            assert rel_rms(results[k][f], refs[k][f]) < REL_RMS
+
+
+def test_capacity_and_empty_batches(pkg):
+    import torch
+    md = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        d_bits = torch.zeros((4, 28800), dtype=torch.uint8, device="cuda")
+        d_out = torch.empty((4, 196608), dtype=torch.complex64, device="cuda")
+        assert md.chain_dev(d_bits, 0, 3, d_out) == 0                      # nothing to do is not an error
+        with pytest.raises(pkg.DabGpuError, match="too small"):
+            md.chain_dev(d_bits, 2, 3, d_out[:1])
+        # more frames than the context was sized for still work (scratch grows on demand)
+        assert md.chain_dev(d_bits, 4, 3, d_out) == 4 * 196608 * 8
+        assert not torch.isnan(torch.view_as_real(d_out)).any()
+    finally:
+        md.close()
