@@ -219,6 +219,17 @@ DABGPU_API int dabgpu_symbols_process_dev(dabgpu_ctx *ctx, const void *d_carrier
                                           size_t n_frames, unsigned stage_mask, void *d_iq,
                                           size_t out_cap, size_t *out_bytes, void *stream);
 
+/* Asynchronous host path: the streaming shape of dabgpu_chain_process.  submit() stages the coded
+ * bits in pinned memory and queues upload, kernels and -- on a second HIP stream -- the copy back
+ * into a pinned buffer owned by the context; up to TWO batches may be in flight, so the copy of
+ * batch i overlaps the kernels of batch i+1 (a third submit is DABGPU_E_CAPACITY).  collect() waits
+ * for the OLDEST batch and hands out its buffer: *iq stays valid until the second next submit.
+ * Same settings snapshot, stream state (resampler halo, TII parity) and ordering as the synchronous
+ * call; do not mix the two on one context while batches are in flight. */
+DABGPU_API int dabgpu_chain_submit(dabgpu_ctx *ctx, const uint8_t *bits, size_t n_frames,
+                                   unsigned stage_mask);
+DABGPU_API int dabgpu_chain_collect(dabgpu_ctx *ctx, const void **iq, size_t *out_bytes);
+
 /* wait for everything queued on the context's own stream */
 DABGPU_API int dabgpu_synchronize(dabgpu_ctx *ctx);
 

@@ -29,7 +29,7 @@ EXPORTS = [
     "dabgpu_resampler_process", "dabgpu_poly_process", "dabgpu_chain_out_bytes_per_frame",
     "dabgpu_chain_process", "dabgpu_chain_process_dev", "dabgpu_symbols_process_dev",
     "dabgpu_synchronize", "dabgpu_time_chain_dev",
-    "dabgpu_set_cfr", "dabgpu_get_cfr_stats", "dabgpu_set_tii", "dabgpu_tii_process", "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
+    "dabgpu_chain_submit", "dabgpu_chain_collect", "dabgpu_set_cfr", "dabgpu_get_cfr_stats", "dabgpu_set_tii", "dabgpu_tii_process", "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -108,6 +108,8 @@ def load_library():
     lib.dabgpu_chain_process.argtypes = [vp, vp, sz, u, vp, sz, szp]
     lib.dabgpu_chain_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_symbols_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
+    lib.dabgpu_chain_submit.argtypes = [vp, vp, sz, u]
+    lib.dabgpu_chain_collect.argtypes = [vp, C.POINTER(vp), szp]
     lib.dabgpu_synchronize.argtypes = [vp]
     lib.dabgpu_set_cfr.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     lib.dabgpu_get_cfr_stats.argtypes = [vp, sz, C.POINTER(_CfrStats)]
@@ -329,6 +331,22 @@ class Modulator:
         self._chk(self._lib.dabgpu_chain_process(self._h, bits.ctypes.data, n, stages,
                                                  out.ctypes.data, out.nbytes, C.byref(ob)))
         return out.reshape(n, ns)
+
+    def submit(self, bits, stages):
+        """Asynchronous host path: queue a batch (at most two in flight)."""
+        bits = np.ascontiguousarray(bits, np.uint8).reshape(-1)
+        per = self.geometry["tf_input_bytes"]
+        if bits.size % per:
+            raise DabGpuError("chain: input size not valid")
+        self._chk(self._lib.dabgpu_chain_submit(self._h, bits.ctypes.data, bits.size // per, stages))
+
+    def collect(self, copy=True):
+        """Wait for the oldest batch: complex64 samples (a view of the context's pinned buffer when
+        copy=False: valid until the second next submit)."""
+        p, n = C.c_void_p(), C.c_size_t()
+        self._chk(self._lib.dabgpu_chain_collect(self._h, C.byref(p), C.byref(n)))
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value // 4,)).view(np.complex64)
+        return a.copy() if copy else a
 
     def _stream_handle(self, tensor, stream):
         """HIP stream handle to launch on.  A real torch stream is used as is

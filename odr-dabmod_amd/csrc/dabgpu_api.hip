@@ -121,6 +121,18 @@ struct dabgpu_ctx {
     unsigned long long applied_epoch = 0;
 
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+
+    // asynchronous host path (dabgpu_chain_submit / dabgpu_chain_collect): two batches in flight,
+    // pinned staging on both sides, device->host copies on their own stream
+    struct Slot {
+        void *h_in = nullptr, *h_out = nullptr;        // pinned (hipHostMalloc)
+        size_t h_in_cap = 0, h_out_cap = 0, out_bytes = 0;
+        DevBuf d_in, d_out;
+        hipEvent_t computed = nullptr, copied = nullptr;
+        bool busy = false;
+    } slot[2];
+    hipStream_t copy_stream = nullptr;
+    int slot_head = 0, slot_count = 0;                 // oldest batch in flight, number in flight
 };
 
 namespace {
@@ -729,6 +741,15 @@ void dabgpu_destroy(dabgpu_ctx *c)
                       &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1,
                       &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();
+    for (auto &sl : c->slot) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        sl.d_in.release();
+        sl.d_out.release();
+        if (sl.computed) (void)hipEventDestroy(sl.computed);
+        if (sl.copied) (void)hipEventDestroy(sl.copied);
+    }
+    if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1207,6 +1228,73 @@ int dabgpu_chain_process(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, un
     rc = run_chain(c, c->d_in.p, true, n_frames, mask, (float2 *)c->d_out.p, need, &ob, c->stream);
     if (rc) return rc;
     return io.out(iq_out, c->d_out.p, need);
+}
+
+// ---- asynchronous host path ------------------------------------------------------
+
+int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, unsigned mask)
+{
+    CTXCHK(c);
+    if (c->slot_count == 2) return fail(c, DABGPU_E_CAPACITY, "two batches are already in flight: collect one first");
+    if (n_frames > (size_t)c->max_frames)
+        return fail(c, DABGPU_E_CAPACITY, "n_frames exceeds max_frames of the context");
+    int rc = apply_settings(c);
+    if (rc) return rc;
+    unsigned m2 = mask;
+    if ((m2 & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) m2 &= ~DABGPU_STAGE_RESAMPLE;
+    const size_t in_bytes = n_frames * tf_in_bytes(c->g);
+    const size_t need = n_frames * out_samples_per_frame(c, m2, c->rs_L, c->rs_M) * sizeof(float2);
+    dabgpu_ctx::Slot &sl = c->slot[(c->slot_head + c->slot_count) & 1];
+    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!sl.computed) {
+        HIPCHK(c, hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
+        HIPCHK(c, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
+    }
+    if (sl.h_in_cap < in_bytes) {
+        if (sl.h_in) (void)hipHostFree(sl.h_in);
+        sl.h_in = nullptr;
+        sl.h_in_cap = 0;
+        HIPCHK(c, hipHostMalloc(&sl.h_in, std::max<size_t>(in_bytes, 16), hipHostMallocDefault));
+        sl.h_in_cap = in_bytes;
+    }
+    if (sl.h_out_cap < need) {
+        if (sl.h_out) (void)hipHostFree(sl.h_out);
+        sl.h_out = nullptr;
+        sl.h_out_cap = 0;
+        HIPCHK(c, hipHostMalloc(&sl.h_out, std::max<size_t>(need, 16), hipHostMallocDefault));
+        sl.h_out_cap = need;
+    }
+    HIPCHK(c, sl.d_in.reserve(std::max<size_t>(in_bytes, 16)));
+    HIPCHK(c, sl.d_out.reserve(std::max<size_t>(need, 16)));
+    std::memcpy(sl.h_in, bits, in_bytes);                       // 28.8 kB per frame
+    if (in_bytes) HIPCHK(c, hipMemcpyAsync(sl.d_in.p, sl.h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    size_t ob = 0;
+    rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, c->stream);
+    if (rc) return rc;
+    HIPCHK(c, hipEventRecord(sl.computed, c->stream));
+    // the copy back runs on its own stream: the next batch's kernels overlap it
+    HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.computed, 0));
+    if (need) HIPCHK(c, hipMemcpyAsync(sl.h_out, sl.d_out.p, need, hipMemcpyDeviceToHost, c->copy_stream));
+    HIPCHK(c, hipEventRecord(sl.copied, c->copy_stream));
+    sl.out_bytes = need;
+    sl.busy = true;
+    ++c->slot_count;
+    return DABGPU_OK;
+}
+
+int dabgpu_chain_collect(dabgpu_ctx *c, const void **iq, size_t *out_bytes)
+{
+    CTXCHK(c);
+    if (!iq) return fail(c, DABGPU_E_INVALID, "null argument");
+    if (c->slot_count == 0) return fail(c, DABGPU_E_INVALID, "no batch in flight");
+    dabgpu_ctx::Slot &sl = c->slot[c->slot_head];
+    HIPCHK(c, hipEventSynchronize(sl.copied));
+    *iq = sl.h_out;
+    if (out_bytes) *out_bytes = sl.out_bytes;
+    sl.busy = false;
+    c->slot_head ^= 1;
+    --c->slot_count;
+    return DABGPU_OK;
 }
 
 int dabgpu_synchronize(dabgpu_ctx *c)

@@ -754,3 +754,38 @@ def test_capacity_and_empty_batches(pkg):
         assert not torch.isnan(torch.view_as_real(d_out)).any()
     finally:
         md.close()
+
+
+def test_async_host_path_submit_collect(pkg):
+    """dabgpu_chain_submit / _collect: two batches in flight, results and stream state (resampler halo)
+    identical to the synchronous entry point, in order."""
+    per = O.tf_input_bytes(1)
+    batches = [np.stack([synth_bits(per, seed=1500 + 4 * b + i) for i in range(2)]) for b in range(5)]
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE
+    sync = pkg.Modulator(mode=1, max_frames=2)
+    asyn = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        for md in (sync, asyn):
+            md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_resampler(2048000, 4096000)
+        want = [sync.chain(b, stages) for b in batches]
+        out = []
+        for i, b in enumerate(batches):
+            asyn.submit(b, stages)
+            if i >= 1:
+                out.append(asyn.collect())                 # batch i-1 while batch i is in flight
+        out.append(asyn.collect())
+        assert len(out) == len(want)
+        for y, w in zip(out, want):
+            assert np.array_equal(y.view(np.uint32), np.ascontiguousarray(w).reshape(-1).view(np.uint32))
+        with pytest.raises(pkg.DabGpuError, match="no batch in flight"):
+            asyn.collect()
+        asyn.submit(batches[0], stages)
+        asyn.submit(batches[1], stages)
+        with pytest.raises(pkg.DabGpuError, match="already in flight"):
+            asyn.submit(batches[2], stages)
+        asyn.collect()
+        asyn.collect()
+    finally:
+        sync.close()
+        asyn.close()

@@ -18,3 +18,21 @@ for B in (1, 8, 64):
     print("B=%3d  %8.0f frames/s  (%.2f ms per call, %.2f GB/s of IQ to the host)"
           % (B, B * n / dt, dt / n * 1e3, B * n * 1572864 / dt / 1e9), flush=True)
     md.close()
+print("asynchronous (submit / collect, two batches in flight, pinned output handed out without a copy):")
+for B in (1, 8):
+    md = P.Modulator(mode=1, max_frames=B)
+    md.set_gain(2, 1.0, 1 / 50000., 4.0)
+    bits = np.frombuffer(np.random.RandomState(1).bytes(B * 28800), np.uint8).reshape(B, 28800)
+    md.submit(bits, 3)
+    for _ in range(4):
+        md.submit(bits, 3); md.collect(copy=False)
+    n = max(8, 512 // B)
+    t0 = time.perf_counter()
+    for _ in range(n):
+        md.submit(bits, 3)
+        md.collect(copy=False)
+    dt = time.perf_counter() - t0
+    md.collect(copy=False)
+    print("B=%3d  %8.0f frames/s  (%.2f ms per batch, %.2f GB/s of IQ to the host)"
+          % (B, B * n / dt, dt / n * 1e3, B * n * 1572864 / dt / 1e9), flush=True)
+    md.close()
