@@ -176,6 +176,14 @@ DABGPU_API int dabgpu_set_tii(dabgpu_ctx *ctx, int enable, int comb, int pattern
 DABGPU_API int dabgpu_tii_process(dabgpu_ctx *ctx, const void *in, size_t in_bytes, void *out,
                                   size_t out_cap, size_t *out_bytes);
 
+/* CicEqualizer(nbCarriers, spacing, R)::process, src/CicEqualizer.cpp:29-91: every
+ * symbol of `carriers` samples times the per-carrier compensation gain of an R-fold, 4-stage CIC
+ * interpolator.  Stage drop-in only: the fused chain does not apply it (the reference wires it in only
+ * when an FPGA clockRate is configured, src/DabModulator.cpp:154-176). */
+DABGPU_API int dabgpu_cic_equalizer_process(dabgpu_ctx *ctx, size_t spacing, int R, const void *in,
+                                            size_t in_bytes, void *out, size_t out_cap,
+                                            size_t *out_bytes);
+
 /* FormatConverter::process, float input path, src/FormatConverter.cpp:111-178:
  * cf32 -> interleaved s16 / u8 / s8 with the reference's range test, truncation toward zero and
  * count of clipped components (FormatConverter::get_num_clipped_samples, :186-189).

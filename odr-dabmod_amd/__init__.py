@@ -29,7 +29,9 @@ EXPORTS = [
     "dabgpu_resampler_process", "dabgpu_poly_process", "dabgpu_chain_out_bytes_per_frame",
     "dabgpu_chain_process", "dabgpu_chain_process_dev", "dabgpu_symbols_process_dev",
     "dabgpu_synchronize", "dabgpu_time_chain_dev",
-    "dabgpu_chain_submit", "dabgpu_chain_collect", "dabgpu_set_cfr", "dabgpu_get_cfr_stats", "dabgpu_set_tii", "dabgpu_tii_process", "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
+    "dabgpu_chain_submit", "dabgpu_chain_collect", "dabgpu_set_cfr", "dabgpu_get_cfr_stats",
+    "dabgpu_cic_equalizer_process", "dabgpu_set_tii", "dabgpu_tii_process",
+    "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -113,6 +115,7 @@ def load_library():
     lib.dabgpu_synchronize.argtypes = [vp]
     lib.dabgpu_set_cfr.argtypes = [vp, C.c_int, C.c_float, C.c_float]
     lib.dabgpu_get_cfr_stats.argtypes = [vp, sz, C.POINTER(_CfrStats)]
+    lib.dabgpu_cic_equalizer_process.argtypes = [vp, sz, C.c_int, vp, sz, vp, sz, szp]
     lib.dabgpu_set_tii.argtypes = [vp, C.c_int, C.c_int, C.c_int, C.c_int]
     lib.dabgpu_tii_process.argtypes = [vp, vp, sz, vp, sz, szp]
     lib.dabgpu_format_size.argtypes = [C.c_int]
@@ -280,6 +283,15 @@ class Modulator:
         d["papr_before"] = np.array([[st.papr_before[i][0], st.papr_before[i][1]] for i in range(n)])
         d["papr_after"] = np.array([[st.papr_after[i][0], st.papr_after[i][1]] for i in range(n)])
         return d
+
+    def cic_equalizer(self, x, spacing, R):
+        """CicEqualizer(carriers, spacing, R)::process."""
+        x = np.ascontiguousarray(x, np.complex64)
+        out = np.empty_like(x)
+        n = C.c_size_t()
+        self._chk(self._lib.dabgpu_cic_equalizer_process(self._h, spacing, R, x.ctypes.data, x.nbytes,
+                                                         out.ctypes.data, out.nbytes, C.byref(n)))
+        return out
 
     def set_tii(self, enable, comb=0, pattern=0, old_variant=False):
         self._chk(self._lib.dabgpu_set_tii(self._h, int(enable), comb, pattern, int(old_variant)))

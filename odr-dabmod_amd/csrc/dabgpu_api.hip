@@ -103,7 +103,9 @@ struct dabgpu_ctx {
     // scratch
     DevBuf d_a, d_b, d_c, d_in, d_out, d_count;
     // TII (f-4): carrier set, the one-frame carrier image and its native-rate response, gain of symbol 1
-    DevBuf d_acp, d_tii_car, d_tii_frame, d_gain1;
+    DevBuf d_acp, d_tii_car, d_tii_frame, d_gain1, d_cic;
+    size_t cic_spacing = 0;               // what d_cic was built for (CicEqualizer, a12)
+    int cic_R = 0;
     // CFR statistics (f-3) of the most recent chain / OfdmGenerator call, and a scratch set for internal runs
     DevBuf d_cfr_counts, d_cfr_mer, d_cfr_papr, d_cfr_tmp;
     int cfr_mer_index = 0;                // myMERCalcIndex (src/OfdmGenerator.h:109): advances once per frame
@@ -738,7 +740,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
                       &c->d_rs_halo, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
-                      &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1,
+                      &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1, &c->d_cic,
                       &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();
     for (auto &sl : c->slot) {
@@ -971,6 +973,43 @@ int dabgpu_null_symbol_process(dabgpu_ctx *c, void *out, size_t out_cap, size_t 
     HIPCHK(c, c->d_b.reserve(need));
     HIPCHK(c, hipMemsetAsync(c->d_b.p, 0, need, c->stream));
     return io.out(out, c->d_b.p, need);
+}
+
+int dabgpu_cic_equalizer_process(dabgpu_ctx *c, size_t spacing, int R, const void *in, size_t in_bytes, void *out,
+                                 size_t out_cap, size_t *out_bytes)
+{
+    CTXCHK(c);
+    const size_t K = (size_t)c->g.K;
+    if (in_bytes % (K * sizeof(float2))) return fail(c, DABGPU_E_INVALID, "CicEqualizer::process input size not valid!");
+    if (!spacing || R <= 0) return fail(c, DABGPU_E_INVALID, "CicEqualizer: spacing and R must be positive");
+    int rc = check_out(c, in_bytes, out_cap, out_bytes);
+    if (rc) return rc;
+    if (c->cic_spacing != spacing || c->cic_R != R) {
+        // the reference's constructor, src/CicEqualizer.cpp:38-55, in float with the libm float functions
+        std::vector<float> filter(K);
+        const int M = 1, N = 4;
+        const float pi = 4.0f * atanf(1.0f);
+        for (size_t i = 0; i < K; ++i) {
+            const int k = i < (K + 1) / 2 ? (int)i + (int)((K & 1) ^ 1) : (int)i - (int)K;
+            const float angle = pi * k / spacing;
+            if (k == 0) {
+                filter[i] = 1.0f;
+            } else {
+                float f = sinf(angle / R) / sinf(angle * M);
+                f = fabsf(f) * R * M;
+                filter[i] = powf(f, N);
+            }
+        }
+        HIPCHK(c, upload(c->d_cic, filter, c->stream));
+        c->cic_spacing = spacing;
+        c->cic_R = R;
+    }
+    HostIO io(c);
+    if ((rc = io.in(c->d_a, in, in_bytes))) return rc;
+    HIPCHK(c, c->d_b.reserve(std::max<size_t>(in_bytes, 16)));
+    HIPCHK(c, launch_cic((const float2 *)c->d_a.p, in_bytes / sizeof(float2), c->g.K, (const float *)c->d_cic.p,
+                         (float2 *)c->d_b.p, c->stream));
+    return io.out(out, c->d_b.p, in_bytes);
 }
 
 int dabgpu_tii_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *out, size_t out_cap,

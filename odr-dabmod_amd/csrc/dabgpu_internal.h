@@ -87,6 +87,8 @@ hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, c
                       int ntaps, float2 *out, hipStream_t s);
 hipError_t launch_poly(const float2 *in, size_t nsamples, const float *am, const float *pm,
                        float2 *out, hipStream_t s);
+// a12 CicEqualizer: out[i] = in[i] * filter[i % K]
+hipError_t launch_cic(const float2 *in, size_t nsamples, int K, const float *filter, float2 *out, hipStream_t s);
 // f-4 TII: the sparse symbol (stand-alone stage), and its addition to a stream whose null symbol is blank
 hipError_t launch_tii(const float2 *in, const uint8_t *acp, int K, int old_variant, int insert, float2 *out,
                       hipStream_t s);

@@ -1611,6 +1611,18 @@ hipError_t launch_lut(const float2 *in, size_t nsamples, float scale, const floa
 namespace {
 
 // ===========================================================================
+// a12 CicEqualizer (reference src/CicEqualizer.cpp:66-91): every carrier times its real gain.
+__global__ void cic_kernel(const cf *__restrict__ in, size_t n, int K, const float *__restrict__ filter,
+                           cf *__restrict__ out)
+{
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float f = filter[i % (size_t)K];
+    const cf x = in[i];
+    out[i] = mk(x.x * f, x.y * f);
+}
+
+// ===========================================================================
 // f-4 TII (reference src/TII.cpp:172-211): the sparse TII symbol from the phase reference symbol.
 // Gather form of the reference's loop "if (Acp[i]) { out[i] = in[i]; out[i+1] = old ? in[i+1] : in[i]; }".
 __global__ void tii_kernel(const cf *__restrict__ in, const uint8_t *__restrict__ acp, int K, int old_variant,
@@ -1700,6 +1712,13 @@ void format_kernel(const float *__restrict__ in, size_t n, void *__restrict__ ou
 }
 
 }  // namespace
+
+hipError_t launch_cic(const float2 *in, size_t nsamples, int K, const float *filter, float2 *out, hipStream_t s)
+{
+    if (nsamples == 0) return hipSuccess;
+    hipLaunchKernelGGL(cic_kernel, dim3(blocks_for(nsamples, 256)), dim3(256), 0, s, in, nsamples, K, filter, out);
+    return hipGetLastError();
+}
 
 hipError_t launch_tii(const float2 *in, const uint8_t *acp, int K, int old_variant, int insert, float2 *out,
                       hipStream_t s)

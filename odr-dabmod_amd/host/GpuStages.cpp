@@ -508,6 +508,21 @@ int Resampler::process(Buffer *const dataIn, Buffer *dataOut)
     return 1;
 }
 
+// ---------------------------------------------------------------- CicEqualizer
+CicEqualizer::CicEqualizer(size_t nbCarriers, size_t spacing, int R)
+    : m_ctx(dabgpu_host::mode_from_carriers(nbCarriers)), m_spacing(spacing), m_R(R)
+{
+}
+
+int CicEqualizer::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    dataOut->setLength(dataIn->getLength());
+    size_t n = 0;
+    m_ctx.check(dabgpu_cic_equalizer_process(m_ctx.get(), m_spacing, m_R, dataIn->getData(), dataIn->getLength(),
+                                             dataOut->getData(), dataOut->getLength(), &n));
+    return static_cast<int>(n / sizeof(complexf));
+}
+
 // ---------------------------------------------------------------- TII
 namespace {
 // the TIIError the reference constructor throws for a mode without TII (src/TII.cpp:144-149),

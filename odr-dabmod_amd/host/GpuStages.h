@@ -231,6 +231,19 @@ private:
     float m_lut_scale = 0.f;
 };
 
+// reference src/CicEqualizer.h:37-52, .cpp:29-91
+class CicEqualizer : public ModCodec {
+public:
+    CicEqualizer(size_t nbCarriers, size_t spacing, int R);
+    int process(Buffer *const dataIn, Buffer *dataOut) override;
+    const char *name() override { return "CicEqualizer"; }
+
+private:
+    dabgpu_host::Context m_ctx;
+    size_t m_spacing;
+    int m_R;
+};
+
 // reference src/TII.h:42-69 (settings) and :79-130, src/TII.cpp:106-245, RC :339-410
 struct tii_config_t {
     bool enable = false;

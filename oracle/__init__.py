@@ -102,6 +102,9 @@ def _load(name):
                                            C.POINTER(_CfrStats), C.POINTER(C.c_double)]
     lib.dabo_papr_db.argtypes = [C.POINTER(C.c_double), C.c_size_t]
     lib.dabo_papr_db.restype = C.c_double
+    lib.dabo_cic_filter.argtypes = [C.c_int, C.c_size_t, C.c_int, _FP]
+    lib.dabo_cic_filter.restype = None
+    lib.dabo_cic_equalize.argtypes = [_FP, C.c_size_t, C.c_int, _FP, _FP]
     lib.dabo_tii_pattern.argtypes = [C.c_int, C.c_int, C.c_int, _U8P]
     lib.dabo_tii_process.argtypes = [_FP, C.c_int, _U8P, C.c_int, C.c_int, _FP]
     lib.dabo_tii_process.restype = None
@@ -309,6 +312,21 @@ def papr_db(pairs):
     return float(lib().dabo_papr_db(pairs.ctypes.data_as(C.POINTER(C.c_double)), pairs.shape[0]))
 
 
+def cic_filter(carriers, spacing, R):
+    f = np.empty(carriers, np.float32)
+    lib().dabo_cic_filter(carriers, spacing, R, _fp(f))
+    return f
+
+
+def cic_equalize(x, carriers, spacing, R):
+    """a12 CicEqualizer: every symbol of `carriers` samples times the per-carrier gain."""
+    x = _c64(x)
+    out = np.empty_like(x)
+    _chk(lib().dabo_cic_equalize(_fp(x), x.size, carriers, _fp(cic_filter(carriers, spacing, R)), _fp(out)),
+         "cic_equalize")
+    return out
+
+
 def tii_pattern(mode, comb, pattern):
     """f-4: A_{c,p} as a uint8 mask over the carriers (reference index convention)."""
     K = mode_params(mode)["carriers"]
@@ -431,6 +449,7 @@ def ref():
         r.ref_fir_filter.argtypes = [_FP, C.c_size_t, C.c_char_p, _FP]
         r.ref_memless_poly.argtypes = [_FP, C.c_size_t, C.c_char_p, C.c_uint, _FP]
         r.ref_tii.argtypes = [C.c_int] * 6 + [_FP]
+        r.ref_cic_equalizer.argtypes = [_FP, C.c_size_t, C.c_size_t, C.c_size_t, C.c_int, _FP]
         r.ref_papr.argtypes = [_FP, C.c_size_t, C.c_size_t, C.c_size_t]
         r.ref_papr.restype = C.c_double
         r.ref_format_convert.argtypes = [_FP, C.c_size_t, C.c_char_p, C.c_void_p, C.c_size_t,
@@ -531,6 +550,13 @@ def ref_memless_poly(x, coef_file, num_threads=1):
     out = np.empty_like(x)
     _rchk(ref().ref_memless_poly(_fp(x), x.size, coef_file.encode(), num_threads, _fp(out)),
           "memless_poly")
+    return out
+
+
+def ref_cic_equalizer(x, carriers, spacing, R):
+    x = _c64(x)
+    out = np.empty_like(x)
+    _rchk(ref().ref_cic_equalizer(_fp(x), x.size, carriers, spacing, R, _fp(out)), "cic_equalizer")
     return out
 
 

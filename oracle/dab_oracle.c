@@ -284,6 +284,35 @@ int dabo_ofdm_generate(const float *in, int nsym, int carriers, int spacing, flo
     return 0;
 }
 
+/* a12 CicEqualizer, src/CicEqualizer.cpp:29-57 (filter) and :66-91 (process) */
+void dabo_cic_filter(int carriers, size_t spacing, int R, float *filter)
+{
+    const int M = 1, N = 4;
+    const float pi = 4.0f * atanf(1.0f);
+    for (int i = 0; i < carriers; ++i) {
+        const int k = i < (carriers + 1) / 2 ? i + ((carriers & 1) ^ 1) : i - carriers;
+        const float angle = pi * k / spacing;
+        if (k == 0) {
+            filter[i] = 1.0f;
+        } else {
+            float f = sinf(angle / R) / sinf(angle * M);
+            f = fabsf(f) * R * M;
+            filter[i] = powf(f, N);
+        }
+    }
+}
+
+int dabo_cic_equalize(const float *in, size_t nsamples, int carriers, const float *filter, float *out)
+{
+    if (nsamples % (size_t)carriers) return -1;
+    for (size_t i = 0; i < nsamples; ++i) {
+        const float f = filter[i % (size_t)carriers];
+        out[2 * i] = in[2 * i] * f;
+        out[2 * i + 1] = in[2 * i + 1] * f;
+    }
+    return 0;
+}
+
 /* f-3: the same loop with crest-factor reduction enabled (src/OfdmGenerator.cpp:207-283 with
  * myCfr, cfr_one_iteration :310-373). */
 static void papr_block(const float *x, size_t n, double *peak, double *mean)

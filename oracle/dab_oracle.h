@@ -122,6 +122,13 @@ enum {
     DABO_STAGE_POLY     = 1 << 3
 };
 
+/* a12 CicEqualizer (reference src/CicEqualizer.cpp:29-91): per-carrier gain (|sin(a/R) / sin(a M)| R M)^N,
+ * a = pi k / spacing, M = 1, N = 4, in the carrier order OfdmGenerator reads (positive first), all in
+ * float with the libm float functions the reference calls.  filter: carriers floats. */
+void dabo_cic_filter(int carriers, size_t spacing, int R, float *filter);
+/* out[s][j] = in[s][j] * filter[j]; nsamples must be a multiple of carriers (else -1, the reference throws) */
+int dabo_cic_equalize(const float *in, size_t nsamples, int carriers, const float *filter, float *out);
+
 /* f-3 crest-factor reduction inside OfdmGenerator (reference src/OfdmGenerator.cpp:157-308,
  * cfr_one_iteration :310-373) and its side statistics.  FFTW calls are the exact DFT evaluated
  * in float64 and rounded once to float32 (PARITY UNPINNED against a reference run: FFTW3f is

@@ -25,6 +25,7 @@
 #include "FormatConverter.h"
 #include "TII.h"
 #include "PAPRStats.h"
+#include "CicEqualizer.h"
 #include "EtiReader.h"
 #include "FicSource.h"
 #include "SubchannelSource.h"
@@ -351,6 +352,18 @@ int ref_time_interleave(const uint8_t *in, size_t framesize, size_t nframes, uin
             memcpy(out + f * framesize, bo.getData(), framesize);
         }
         return 0;
+    } catch (const std::exception &) { return -1; }
+}
+
+// a12: CicEqualizer(nbCarriers, spacing, R)
+int ref_cic_equalizer(const float *in, size_t nsamples, size_t carriers, size_t spacing, int R, float *out)
+{
+    try {
+        CicEqualizer st(carriers, spacing, R);
+        Buffer bi, bo;
+        fill(bi, in, nsamples * sizeof(complexf));
+        st.process(&bi, &bo);
+        return copy_out(bo, out, nsamples * sizeof(complexf));
     } catch (const std::exception &) { return -1; }
 }
 

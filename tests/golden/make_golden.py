@@ -99,6 +99,9 @@ def main():
             g["format_%s" % fmt] = {"sha256": sha(yo), "clipped": clipped}
             ye, ce = O.ref_format_convert(format_edges(fmt), fmt)
             g["format_edges_%s" % fmt] = {"out": [int(v) for v in ye], "clipped": ce}
+        # a12 CicEqualizer (spacing, R as DabModulator derives them: spacing * rate / 2048000, clock / rate / 4)
+        for sp, R in ((2048, 8), (8192, 25), (512, 4), (256, 3)):
+            g["cic_%d_%d" % (sp, R)] = {"sha256": sha(O.ref_cic_equalizer(synth_signal(5 * K, seed=600 + mode), K, sp, R))}
         # f-3: PAPRStats (the part of the CFR statistics that compiles without FFTW) on the synthetic signal
         g["papr_synth_signal"] = {"db": O.ref_papr(x, N, nsym), "db_too_few_blocks": O.ref_papr(x, N, nsym + 1)}
         # f-4 TII (modes I and II only): every comb x pattern, both variants, inserting and idle call

@@ -364,6 +364,19 @@ def test_chain_cfg4_resample_x4_and_poly(pkg):
     assert y.shape[1] == 4 * 196608
 
 
+# --------------------------------------------------------------------------- a12 CicEqualizer
+@pytest.mark.parametrize("mode,spacing,R", [(1, 2048, 8), (1, 8192, 25), (2, 512, 4), (3, 256, 3)])
+def test_cic_equalizer_bit_exact_vs_reference_golden(mods, mode, spacing, R):
+    md = mods[mode]
+    K = md.geometry["carriers"]
+    x = synth_signal(5 * K, seed=600 + mode)
+    y = md.cic_equalizer(x, spacing, R)
+    assert sha(y) == GOLD[str(mode)]["cic_%d_%d" % (spacing, R)]["sha256"]
+    assert bits_eq(y, O.cic_equalize(x, K, spacing, R))
+    with pytest.raises(RuntimeError, match="CicEqualizer::process input size not valid"):
+        md.cic_equalizer(x[:-1], spacing, R)
+
+
 # --------------------------------------------------------------------------- f-3 CFR
 def _check_cfr_stats(got, want, want_papr, N):
     """Clip decisions next to a threshold may differ between two fp32 FFTs: counts within 0.2 %."""

@@ -88,6 +88,16 @@ def test_format_converter_bit_exact_vs_reference(mode, fmt):
     assert ce == g["format_edges_%s" % fmt]["clipped"]
 
 
+@pytest.mark.parametrize("mode", [1, 2, 3, 4])
+def test_cic_equalizer_bit_exact_vs_reference(mode):
+    K = O.mode_params(mode)["carriers"]
+    x = synth_signal(5 * K, seed=600 + mode)
+    for sp, R in ((2048, 8), (8192, 25), (512, 4), (256, 3)):
+        assert sha(O.cic_equalize(x, K, sp, R)) == GOLD[str(mode)]["cic_%d_%d" % (sp, R)]["sha256"]
+    with pytest.raises(ValueError):
+        O.cic_equalize(x[:-1], K, 2048, 8)
+
+
 def _mux_symbols(mode, seed=None):
     m = O.mode_params(mode)
     K = m["carriers"]
