@@ -256,8 +256,8 @@ int apply_settings(dabgpu_ctx *c)
         c->applied_epoch = c->set.epoch;
     }
     hipStream_t s = c->stream;
-    std::vector<float> taps(kMaxTaps, 0.0f);
-    std::copy(c->cur.taps.begin(), c->cur.taps.end(), taps.begin());
+    std::vector<float> taps(kMaxTaps, 0.0f);   // the fused kernel's copy (longer filters take the unfused kernels)
+    std::copy(c->cur.taps.begin(), c->cur.taps.begin() + std::min<size_t>(c->cur.taps.size(), kMaxTaps), taps.begin());
     HIPCHK(c, upload(c->d_taps, taps, s));
     {
         // frequency response seen by the look-ahead FIR on a cyclically extended symbol:
@@ -785,7 +785,7 @@ int dabgpu_set_fir_taps(dabgpu_ctx *c, const float *taps, size_t n)
 {
     if (!c) return DABGPU_E_INVALID;
     if (!taps || n == 0) return fail(c, DABGPU_E_INVALID, "FIRFilter: taps file has invalid format.");
-    if (n > (size_t)kMaxTaps) return fail(c, DABGPU_E_INVALID, "FIRFilter: more than 128 taps not supported");
+    if (n > (size_t)kMaxTapsUnfused) return fail(c, DABGPU_E_INVALID, "FIRFilter: more than 512 taps not supported");
     std::lock_guard<std::mutex> lk(c->mu);
     c->set.taps.assign(taps, taps + n);
     ++c->set.epoch;

@@ -7,7 +7,8 @@
 
 namespace dabgpu {
 
-constexpr int kMaxTaps = 128;
+constexpr int kMaxTaps = 128;        // fused (spectral) FIR of the frame kernel
+constexpr int kMaxTapsUnfused = 512; // direct FIR kernels (the chain falls back to them for longer filters)
 
 // Transmission-mode geometry (reference src/DabModulator.cpp:84-122).
 struct Geometry {

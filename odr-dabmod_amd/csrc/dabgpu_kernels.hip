@@ -1549,16 +1549,20 @@ hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, c
                       int ntaps, float2 *out, hipStream_t s)
 {
     if (frame_samples == 0 || n_frames == 0) return hipSuccess;
-    if (ntaps < 1 || ntaps > kMaxTaps) return hipErrorInvalidValue;
+    if (ntaps < 1 || ntaps > kMaxTapsUnfused) return hipErrorInvalidValue;
     const dim3 grid(blocks_for(frame_samples, 256 * 8), (unsigned)n_frames);
     if (ntaps <= 48) {
         FirTaps<48> t{};
         std::copy(taps, taps + ntaps, t.t);
         hipLaunchKernelGGL(fir_kernel<48>, grid, dim3(256), 0, s, in, frame_samples, t, out);
-    } else {
+    } else if (ntaps <= 128) {
         FirTaps<128> t{};
         std::copy(taps, taps + ntaps, t.t);
         hipLaunchKernelGGL(fir_kernel<128>, grid, dim3(256), 0, s, in, frame_samples, t, out);
+    } else {
+        FirTaps<512> t{};
+        std::copy(taps, taps + ntaps, t.t);
+        hipLaunchKernelGGL(fir_kernel<512>, grid, dim3(256), 0, s, in, frame_samples, t, out);
     }
     return hipGetLastError();
 }
@@ -1567,17 +1571,21 @@ hipError_t launch_guard_fir(const float2 *in, size_t n_frames, Geometry g, int o
                             const float *taps, int ntaps, float2 *out, hipStream_t s)
 {
     if (n_frames == 0) return hipSuccess;
-    if (ntaps < 1 || ntaps > kMaxTaps) return hipErrorInvalidValue;
+    if (ntaps < 1 || ntaps > kMaxTapsUnfused) return hipErrorInvalidValue;
     const size_t tf = (size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size;
     const dim3 grid(blocks_for(tf, 256 * 8), (unsigned)n_frames);
     if (ntaps <= 48) {
         FirTaps<48> t{};
         std::copy(taps, taps + ntaps, t.t);
         hipLaunchKernelGGL(guard_fir_kernel<48>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
-    } else {
+    } else if (ntaps <= 128) {
         FirTaps<128> t{};
         std::copy(taps, taps + ntaps, t.t);
         hipLaunchKernelGGL(guard_fir_kernel<128>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+    } else {
+        FirTaps<512> t{};
+        std::copy(taps, taps + ntaps, t.t);
+        hipLaunchKernelGGL(guard_fir_kernel<512>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
     }
     return hipGetLastError();
 }

@@ -163,7 +163,7 @@ def test_gain_control_null_detect_and_symbol0_rule(mods):
     md.set_gain()
 
 
-@pytest.mark.parametrize("ntaps", [1, 13, 45, 48, 49, 100])
+@pytest.mark.parametrize("ntaps", [1, 13, 45, 48, 49, 100, 129, 300, 512])
 def test_fir_filter(mods, ntaps):
     md = mods[2]
     x = synth_signal(md.geometry["tf_samples"], seed=31) * np.float32(1 / 160)
@@ -317,7 +317,7 @@ def test_chain_other_gain_modes_file_normalisation(pkg, gain_mode):
     _chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, 1, 2, dict(gain_mode=gain_mode), setup)
 
 
-@pytest.mark.parametrize("ntaps", [13, 100])
+@pytest.mark.parametrize("ntaps", [13, 100, 300])
 def test_chain_custom_taps(pkg, ntaps):
     taps = (synth_signal(ntaps, seed=ntaps).real * np.float32(1 / 200)).astype(np.float32)
 
@@ -751,6 +751,11 @@ def test_two_contexts_run_concurrently_on_their_own_streams(pkg):
     for k in range(2):
         for f in range(6):
             assert rel_rms(results[k][f], refs[k][f]) < REL_RMS
+
+
+def test_fir_tap_count_limit(mods, pkg):
+    with pytest.raises(pkg.DabGpuError, match="more than 512 taps"):
+        mods[1].set_fir_taps(np.zeros(513, np.float32))
 
 
 def test_capacity_and_empty_batches(pkg):
