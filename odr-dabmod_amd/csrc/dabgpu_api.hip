@@ -322,6 +322,8 @@ int apply_settings(dabgpu_ctx *c)
             HIPCHK(c, hipMemsetAsync(c->d_rs_halo.p, 0, nin * sizeof(float2), s));
         }
     }
+    // everything above went through the context's own stream; the caller may launch on another one
+    HIPCHK(c, hipStreamSynchronize(s));
     return DABGPU_OK;
 }
 
