@@ -88,14 +88,17 @@ DABGPU_API int dabgpu_get_geometry(const dabgpu_ctx *ctx, dabgpu_geometry *g);
  * constructor argument derived from the sink, src/DabMod.cpp:259-347 */
 DABGPU_API int dabgpu_set_gain(dabgpu_ctx *ctx, int gain_mode, float digital, float normalise,
                                float var_variance);
-/* FIRFilter::load_filter_taps, src/FIRFilter.cpp:95-141 (n <= 128) */
+/* FIRFilter::load_filter_taps, src/FIRFilter.cpp:95-141 (n <= 512; up to 128 taps run fused) */
 DABGPU_API int dabgpu_set_fir_taps(dabgpu_ctx *ctx, const float *taps, size_t n);
 /* FIRFilter("default"): the built-in 45 taps, src/FIRFilter.cpp:59-71 */
 DABGPU_API int dabgpu_set_fir_default_taps(dabgpu_ctx *ctx);
 /* GuardIntervalInserter::update_window, src/GuardIntervalInserter.cpp:96-113 */
 DABGPU_API int dabgpu_set_window_overlap(dabgpu_ctx *ctx, size_t overlap);
 /* Resampler(inputRate, outputRate, resolution = spacing), src/Resampler.cpp:51-112;
- * resets the stream state (prev-input halo and overlap tail) */
+ * resets the stream state (prev-input halo and overlap tail).  Built: up-sampling by L / M
+ * (the rates reduced by their gcd) with M a power of two <= 128 in Mode I (2.4, 3.072, 4, 6.144,
+ * 8, 10 ... Msps; x2 and x4 have their own faster kernel).  Other ratios -- down-sampling, M not
+ * a power of two -- are refused by the next *_process call with DABGPU_E_INVALID. */
 DABGPU_API int dabgpu_set_resampler(dabgpu_ctx *ctx, size_t in_rate, size_t out_rate);
 /* MemlessPoly::load_coefficients format 1, src/MemlessPoly.cpp:154-202 */
 DABGPU_API int dabgpu_set_poly(dabgpu_ctx *ctx, const float am[5], const float pm[5]);

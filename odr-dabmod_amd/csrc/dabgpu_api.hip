@@ -96,7 +96,7 @@ struct dabgpu_ctx {
     // constant tables
     DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_firh, d_window, d_coef;
     // resampler
-    DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo;
+    DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo, d_rs_tw_s, d_rs_tw_l;
     int rs_nin = 0, rs_nout = 0;
     size_t rs_L = 1, rs_M = 1;
     float rs_factor = 1.f;
@@ -318,6 +318,19 @@ int apply_settings(dabgpu_ctx *c)
             }
             HIPCHK(c, upload(c->d_rs_tw_in, ti, s));
             HIPCHK(c, upload(c->d_rs_tw_out, to, s));
+            // the general (rational) kernel: S = nin / M point transforms, and the L-th roots of unity
+            const size_t S = nin / M;
+            std::vector<float2> tsv(std::max<size_t>(S, 1)), tlv(L);
+            for (size_t m = 0; m < tsv.size(); ++m) {
+                const double x = 2.0 * M_PI * (double)m / (double)tsv.size();
+                tsv[m] = make_float2((float)std::cos(x), (float)std::sin(x));
+            }
+            for (size_t m = 0; m < L; ++m) {
+                const double x = 2.0 * M_PI * (double)m / (double)L;
+                tlv[m] = make_float2((float)std::cos(x), (float)std::sin(x));
+            }
+            HIPCHK(c, upload(c->d_rs_tw_s, tsv, s));
+            HIPCHK(c, upload(c->d_rs_tw_l, tlv, s));
             HIPCHK(c, c->d_rs_halo.reserve(nin * sizeof(float2)));
             HIPCHK(c, hipMemsetAsync(c->d_rs_halo.p, 0, nin * sizeof(float2), s));
         }
@@ -368,12 +381,25 @@ int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
 
 bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 
+// ratios with a dedicated kernel (integer 2 and 4: packed dual transforms, fused predistorter)
+bool resampler_fast_ratio(const dabgpu_ctx *c)
+{
+    return c->rs_nout % c->rs_nin == 0 && (c->rs_nout / c->rs_nin == 2 || c->rs_nout / c->rs_nin == 4);
+}
+
 int check_resampler(dabgpu_ctx *c)
 {
-    if (!is_pow2((size_t)c->rs_nin) || !is_pow2((size_t)c->rs_nout) || c->rs_nin < 512 ||
-        c->rs_nout < 512 || c->rs_nin > 16384 || c->rs_nout > 16384)
+    // Up-sampling by L / M with M a power of two (output rates that are multiples of 2048000 / M: 2.4, 2.5,
+    // 3.072, 4, 6.144, 8, 10 ... Msps): then nin = 2 N is a power of two and the nout-point transform
+    // factors into L transforms of nin / M points.  Other ratios (M not a power of two, down-sampling) would
+    // need arbitrary-length transforms.
+    const size_t nin = (size_t)c->rs_nin, M = c->rs_M, L = c->rs_L;
+    const size_t S = M ? nin / M : 0;                    // transform size of a branch; instantiated: nin .. nin / 64 (32 in Mode I)
+    const bool ok = is_pow2(nin) && nin >= 512 && nin <= 4096 && is_pow2(M) && nin % M == 0 && L > M && S >= 8 &&
+                    (S * 64 >= nin || (nin == 4096 && S == 32)) && L <= 4096 && (size_t)c->rs_nout == S * L;
+    if (!ok)
         return fail(c, DABGPU_E_INVALID,
-                    "Resampler: only power-of-two rate ratios (FFT sizes 512..16384) are supported");
+                    "Resampler: only up-sampling by L/M with M a power of two (<= 128 in Mode I) is supported");
     return DABGPU_OK;
 }
 
@@ -386,14 +412,18 @@ int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out
     const size_t hin = (size_t)c->rs_nin / 2;
     if (total % hin) return fail(c, DABGPU_E_INVALID, "Resampler::process input size not valid!");
     const size_t nhops = total / hin;
-    ResamplerArgs a;
+    ResamplerArgs a{};
     a.nin = c->rs_nin; a.nout = c->rs_nout; a.factor = c->rs_factor;
     a.window = (const float *)c->d_rs_window.p;
     a.tw_in = (const float2 *)c->d_rs_tw_in.p;
     a.tw_out = (const float2 *)c->d_rs_tw_out.p;
     a.in = d_in; a.halo = (const float2 *)c->d_rs_halo.p;
     a.out = d_out; a.nhops = nhops;
-    a.poly = fuse_poly ? (const float *)c->d_coef.p : nullptr;
+    a.poly = (fuse_poly && resampler_fast_ratio(c)) ? (const float *)c->d_coef.p : nullptr;
+    a.L = (int)c->rs_L;
+    a.M = (int)c->rs_M;
+    a.tw_s = (const float2 *)c->d_rs_tw_s.p;
+    a.tw_l = (const float2 *)c->d_rs_tw_l.p;
     HIPCHK(c, launch_resampler(a, s));
     // new halo = last two hops of the concatenation [halo | in]
     float2 *halo = (float2 *)c->d_rs_halo.p;
@@ -622,7 +652,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
         bool poly_done = false;
         if (mask & DABGPU_STAGE_RESAMPLE) {
             // the polynomial predistorter is an epilogue of the resampler's store (LUT mode is not)
-            const bool fuse = (mask & DABGPU_STAGE_POLY) && !c->cur.poly_is_lut;
+            const bool fuse = (mask & DABGPU_STAGE_POLY) && !c->cur.poly_is_lut && resampler_fast_ratio(c);
             float2 *dst = d_out;
             if ((mask & DABGPU_STAGE_POLY) && !fuse) {
                 HIPCHK(c, c->d_b.reserve(n_frames * per * sizeof(float2)));
@@ -741,7 +771,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
-                      &c->d_rs_halo, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
+                      &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
                       &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1, &c->d_cic,
                       &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();

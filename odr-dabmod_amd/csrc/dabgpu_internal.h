@@ -113,6 +113,10 @@ struct ResamplerArgs {
     float2 *out;            // nhops * nout/2
     const float *poly;      // nullptr, or am[5] at [0..4] and pm[5] at [8..12]: MemlessPoly fused into the store
     size_t nhops;
+    // rational ratios L/M (the general kernel): nout = (nin / M) * L
+    int L, M;
+    const float2 *tw_s;     // nin / M entries exp(+2 pi i m / (nin / M))
+    const float2 *tw_l;     // L entries exp(+2 pi i m / L)
 };
 hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s);
 

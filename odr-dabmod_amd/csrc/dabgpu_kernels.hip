@@ -158,7 +158,8 @@ template <int LOGN> struct Fft {
     // reads 2-way); strides 8 and 64 are conflict-free unpadded.
     template <int NS, bool DBUF, typename V> static DEV void exchange(V *v, V *lds, int t)
     {
-        constexpr bool PAD = sizeof(V) == 8 ? (NS < 64) : (NS == 1);
+        // (the padded read address base + m (T + T/8) needs T to be a multiple of 8: tiny transforms go unpadded)
+        constexpr bool PAD = (T % 8 == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
         if (PAD) {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
             V *wp = lds + (j0 + (j0 >> 3));
@@ -1981,6 +1982,145 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     }
 }
 
+// ---------------------------------------------------------------------------
+// a10 for rational ratios L / M (M a power of two dividing nin, L > M): nout = S L with S = nin / M.
+// Same overlap-add on the spectra as above (G_h = F_h + (-1)^k F_{h-1}, first half of the output only).
+// The zero-stuffed nout-point IDFT factors over n = L j + p and stuffed bin k' + S r:
+//     y_p[j] = IDFT_S over k' of  W_nout^{k' p} * sum_r Gst[k' + S r] e^{2 pi i r p / L},
+// and only M (+1, Nyquist) of the L values of r are occupied: bin k = k' + S rho of the nin-point spectrum
+// sits at r = rho (k < nin/2), r = rho + L - M (k > nin/2), or both (k = nin/2).  So a hop is one nin-point
+// forward transform, then L "branches": an M-term fold per bin and an S-point IFFT.  The nin / 8 lanes of the
+// workgroup split into M groups of S / 8 lanes, one branch per group and round, ceil(L / M) rounds.
+// General, not tuned: the integer ratios 2 and 4 keep the kernel above.
+template <int LOGNIN, int LOGS> __global__ __launch_bounds__((1 << LOGNIN) / 8 < 64 ? 64 : (1 << LOGNIN) / 8)
+void resampler_rational_kernel(const ResamplerArgs a, int hops_per_run)
+{
+    typedef Fft<LOGNIN> F;
+    typedef Fft<LOGS> FS;
+    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, S = FS::N, TS = FS::T, M = NIN / S;
+    static_assert(M >= 1 && TS >= 1, "group geometry");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *xbuf = reinterpret_cast<cf *>(smem);                 // exchange buffers: 2 x LDS_ELEMS of the nin-point
+                                                             // transform = M groups x 2 x LDS_ELEMS of the S-point one
+    cf *gl = xbuf + 2 * F::LDS_ELEMS;                        // G: the nin bins of the hop's spectrum
+    cf *cl = gl + NIN;                                       // exp(2 pi i m / L), m < L
+    float *win = reinterpret_cast<float *>(cl + a.L);        // first half of the symmetric Hann window
+    const int L = a.L, nout = a.nout, HOUT = nout / 2;
+    int fpar = 0, spar = 0;
+    const int t = threadIdx.x;
+    const bool lane_on = t < T;                              // nin = 256 would leave half a wave idle (not used)
+    const int tt = lane_on ? t : 0;
+    const long h0 = (long)blockIdx.x * hops_per_run;
+    const long h1 = min((long)a.nhops, h0 + hops_per_run);
+    if (h0 >= (long)a.nhops) return;
+
+    cf tw[F::NTW > 0 ? F::NTW : 1], tws[FS::NTW > 0 ? FS::NTW : 1];
+    F::template load_twiddles<false>(a.tw_in, tt, tw);
+    const int grp = tt / TS, l = tt % TS;                    // branch group and lane inside it
+    FS::template load_twiddles<false>(a.tw_s, l, tws);
+    for (int i = t; i < L; i += blockDim.x) cl[i] = a.tw_l[i];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) win[tt + T * m] = a.window[tt + T * m];
+    lds_barrier();
+    auto wnd = [&](int m) __attribute__((always_inline)) -> float {
+        return m < 4 ? win[tt + T * m] : win[T * (7 - m) + (T - 1 - tt)];
+    };
+    auto fetch = [&](long h, cf *x) __attribute__((always_inline)) {
+        const long base = (h + 1) * HIN;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const long i = base + tt + T * m;
+            x[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
+        }
+    };
+    // nin-point forward transform of a windowed hop (conjugate trick: DFT(x) = conj(IDFT(conj(x))))
+    auto forward = [&](const cf *x, cf *f) __attribute__((always_inline)) {
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { const float w = wnd(m); v[m] = mk(x[m].x * w, -x[m].y * w); }
+        F::template run<+1, true>(v, xbuf, fpar, tw, tt, nullptr);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = mk(v[m].x * a.factor, -v[m].y * a.factor);
+    };
+    const float sgn = (tt & 1) ? -1.0f : 1.0f;
+    cf xn[8], Fp[8];
+    fetch(h0 - 1, xn);
+    forward(xn, Fp);
+    fetch(h0, xn);
+    cf *gbuf = xbuf + (size_t)grp * 2 * FS::LDS_ELEMS;       // this group's pair of exchange buffers
+    const int rounds = (L + M - 1) / M;
+
+    for (long h = h0; h < h1; ++h) {
+        cf Fc[8];
+        forward(xn, Fc);
+        if (h + 1 < h1) fetch(h + 1, xn);
+        lds_barrier();                                       // the previous hop's folds have read gl
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            if (lane_on) gl[tt + T * m] = mk(fmaf(sgn, Fp[m].x, Fc[m].x), fmaf(sgn, Fp[m].y, Fc[m].y));
+            Fp[m] = Fc[m];
+        }
+        lds_barrier();
+        cf *dst = a.out + (size_t)h * HOUT;
+        for (int q = 0; q < rounds; ++q) {
+            const int p = q * M + grp;                       // this group's branch (may run past L: computed, not stored)
+            const int pe = p < L ? p : 0;
+            const int off = (int)(((long)M * pe) % L);       // (r p) mod L for r = rho + L - M is (rho p - M p) mod L
+            cf v[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int kp = l + TS * i;                   // bin k' of the S-point transform
+                cf acc = mk(0.f, 0.f);
+                int idx = 0;                                 // (rho p) mod L
+                for (int rho = 0; rho < M; ++rho) {
+                    const int k = kp + S * rho;
+                    const cf g = gl[k];
+                    int in2 = idx - off;
+                    in2 += in2 < 0 ? L : 0;
+                    const cf cpos = cl[idx], cneg = cl[in2];
+                    cf c = k < HIN ? cpos : cneg;
+                    if (k == HIN) c = cadd(cpos, cneg);      // the Nyquist bin sits at both +nin/2 and -nin/2
+                    acc = cadd(acc, cmul(g, c));
+                    idx += pe;
+                    idx -= idx >= L ? L : 0;
+                }
+                v[i] = cmul(acc, a.tw_out[(int)(((long)kp * pe) % nout)]);
+            }
+            FS::template run<+1, true>(v, gbuf, spar, tws, l, nullptr);
+            if (p < L && lane_on) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) dst[(size_t)L * (l + TS * m) + p] = v[m];   // j = l + TS m < S / 2
+            }
+        }
+    }
+}
+
+template <int LOGNIN, int LOGS> hipError_t launch_resampler_rational(const ResamplerArgs &a, hipStream_t s)
+{
+    constexpr int NIN = 1 << LOGNIN;
+    const int hpr = (int)std::max<size_t>(2, std::min<size_t>(96, a.nhops / 512));
+    const dim3 grid((unsigned)((a.nhops + hpr - 1) / hpr)), block(NIN / 8 < 64 ? 64 : NIN / 8);
+    const size_t lds = (2 * (size_t)(NIN + NIN / 8) + NIN + (size_t)a.L) * sizeof(float2) + (size_t)(NIN / 2) * sizeof(float);
+    hipLaunchKernelGGL((resampler_rational_kernel<LOGNIN, LOGS>), grid, block, lds, s, a, hpr);
+    return hipGetLastError();
+}
+
+template <int LOGNIN> hipError_t launch_resampler_rational_n(const ResamplerArgs &a, hipStream_t s)
+{
+    // S = nin / M; groups of S / 8 lanes, at least one lane
+    switch (a.nin / a.M) {
+        case 1 << LOGNIN: return launch_resampler_rational<LOGNIN, LOGNIN>(a, s);
+        case (1 << LOGNIN) / 2: return launch_resampler_rational<LOGNIN, LOGNIN - 1>(a, s);
+        case (1 << LOGNIN) / 4: return launch_resampler_rational<LOGNIN, LOGNIN - 2>(a, s);
+        case (1 << LOGNIN) / 8: return launch_resampler_rational<LOGNIN, LOGNIN - 3>(a, s);
+        case (1 << LOGNIN) / 16: return launch_resampler_rational<LOGNIN, LOGNIN - 4>(a, s);
+        case (1 << LOGNIN) / 32: return launch_resampler_rational<LOGNIN, LOGNIN - 5>(a, s);
+        case (1 << LOGNIN) / 64: return launch_resampler_rational<LOGNIN, LOGNIN - 6>(a, s);
+    }
+    if (LOGNIN == 12 && a.nin / a.M == 32) return launch_resampler_rational<12, 5>(a, s);     // M = 128 (e.g. 2.4 Msps)
+    return hipErrorInvalidValue;
+}
+
 template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipStream_t s)
 {
     constexpr int NIN = 1 << LOGNIN;
@@ -2011,12 +2151,14 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
 hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s)
 {
     if (a.nhops == 0) return hipSuccess;
-    if (a.nout <= a.nin || a.nout % a.nin) return hipErrorInvalidValue;
+    if (a.nout <= a.nin) return hipErrorInvalidValue;
+    const bool fast = a.nout % a.nin == 0 && (a.nout / a.nin == 2 || a.nout / a.nin == 4);
+    if (!fast && a.poly) return hipErrorInvalidValue;        // the general kernel has no fused predistorter
     switch (a.nin) {
-        case 512: return launch_resampler_n<9>(a, s);
-        case 1024: return launch_resampler_n<10>(a, s);
-        case 2048: return launch_resampler_n<11>(a, s);
-        case 4096: return launch_resampler_n<12>(a, s);
+        case 512: return fast ? launch_resampler_n<9>(a, s) : launch_resampler_rational_n<9>(a, s);
+        case 1024: return fast ? launch_resampler_n<10>(a, s) : launch_resampler_rational_n<10>(a, s);
+        case 2048: return fast ? launch_resampler_n<11>(a, s) : launch_resampler_rational_n<11>(a, s);
+        case 4096: return fast ? launch_resampler_n<12>(a, s) : launch_resampler_rational_n<12>(a, s);
     }
     return hipErrorInvalidValue;
 }

@@ -195,13 +195,13 @@ typedef struct {
     uint32_t *rev;
 } dft_plan;
 
-static dft_plan g_plans[8];
+static dft_plan g_plans[16];
 
 static const dft_plan *dft_get_plan(size_t n)
 {
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < 16; ++i)
         if (g_plans[i].n == n) return &g_plans[i];
-    for (int i = 0; i < 8; ++i) {
+    for (int i = 0; i < 16; ++i) {
         if (g_plans[i].n != 0) continue;
         dft_plan *p = &g_plans[i];
         p->tw = (double *)malloc(sizeof(double) * n);
@@ -224,7 +224,53 @@ static const dft_plan *dft_get_plan(size_t n)
     return NULL;
 }
 
+static void dft_pow2_f64(const double *in, double *out, size_t n, int sign);
+
+/* Any other length: Bluestein's chirp-z identity, nk = (n^2 + k^2 - (k-n)^2) / 2, turns the DFT into a
+ * circular convolution evaluated with the power-of-two transform above -- still float64 throughout, the
+ * chirp angles reduced mod 2N as integers (the resampler's output FFT has sizes such as 4800 or 6144). */
+static void dft_bluestein_f64(const double *in, double *out, size_t n, int sign)
+{
+    size_t m = 1;
+    while (m < 2 * n - 1) m <<= 1;
+    double *c = (double *)malloc(sizeof(double) * 2 * n);      /* chirp exp(sign * pi i j^2 / n) */
+    double *a = (double *)calloc(2 * m, sizeof(double)), *b = (double *)calloc(2 * m, sizeof(double));
+    double *fa = (double *)malloc(sizeof(double) * 2 * m), *fb = (double *)malloc(sizeof(double) * 2 * m);
+    for (size_t j = 0; j < n; ++j) {
+        const size_t q = (size_t)(((unsigned long long)j * j) % (2 * n));
+        const double ang = (double)sign * M_PI * (double)q / (double)n;
+        c[2 * j] = cos(ang);
+        c[2 * j + 1] = sin(ang);
+        a[2 * j] = in[2 * j] * c[2 * j] - in[2 * j + 1] * c[2 * j + 1];
+        a[2 * j + 1] = in[2 * j] * c[2 * j + 1] + in[2 * j + 1] * c[2 * j];
+        b[2 * j] = c[2 * j];                       /* conj(chirp), also at the mirrored index */
+        b[2 * j + 1] = -c[2 * j + 1];
+        if (j) { b[2 * (m - j)] = c[2 * j]; b[2 * (m - j) + 1] = -c[2 * j + 1]; }
+    }
+    dft_pow2_f64(a, fa, m, -1);
+    dft_pow2_f64(b, fb, m, -1);
+    for (size_t k = 0; k < m; ++k) {
+        const double re = fa[2 * k] * fb[2 * k] - fa[2 * k + 1] * fb[2 * k + 1];
+        const double im = fa[2 * k] * fb[2 * k + 1] + fa[2 * k + 1] * fb[2 * k];
+        a[2 * k] = re;
+        a[2 * k + 1] = im;
+    }
+    dft_pow2_f64(a, fa, m, +1);
+    for (size_t k = 0; k < n; ++k) {
+        const double re = fa[2 * k] / (double)m, im = fa[2 * k + 1] / (double)m;
+        out[2 * k] = re * c[2 * k] - im * c[2 * k + 1];
+        out[2 * k + 1] = re * c[2 * k + 1] + im * c[2 * k];
+    }
+    free(c); free(a); free(b); free(fa); free(fb);
+}
+
 void dabo_dft_f64(const double *in, double *out, size_t n, int sign)
+{
+    if (n & (n - 1)) dft_bluestein_f64(in, out, n, sign);
+    else dft_pow2_f64(in, out, n, sign);
+}
+
+static void dft_pow2_f64(const double *in, double *out, size_t n, int sign)
 {
     const dft_plan *p = dft_get_plan(n);
     if (!p) return;

@@ -258,7 +258,7 @@ def test_format_converter_errors_and_device_path(pkg, mods):
         md.format_convert_dev(d_in, "s16", d_out[:-8], d_cnt, stream=st.cuda_stream)
 
 
-@pytest.mark.parametrize("out_rate", [8192000, 4096000])
+@pytest.mark.parametrize("out_rate", [8192000, 4096000, 3072000, 2304000, 2400000, 6144000, 10000000, 16384000])
 def test_resampler_state_carries_across_calls(pkg, out_rate):
     md = pkg.Modulator(mode=1, max_frames=4)
     try:
@@ -272,6 +272,45 @@ def test_resampler_state_carries_across_calls(pkg, out_rate):
             assert rel_rms(y, ref) < REL_RMS
     finally:
         md.close()
+
+
+@pytest.mark.parametrize("out_rate", [1024000, 2500000, 2048001, 3000000])
+def test_resampler_ratios_without_a_kernel_are_refused(pkg, out_rate):
+    """Down-sampling, and L / M with M not a power of two (or beyond 128 in Mode I), would need
+    arbitrary-length transforms: an error, never a wrong signal."""
+    md = pkg.Modulator(mode=1, max_frames=1)
+    try:
+        md.set_resampler(2048000, out_rate)
+        with pytest.raises(pkg.DabGpuError, match="Resampler: only up-sampling"):
+            md.resample(np.zeros(4096, np.complex64))
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("mode,out_rate", [(2, 3072000), (3, 2304000), (4, 6144000), (2, 8192000)])
+def test_resampler_rational_other_modes(pkg, mode, out_rate):
+    md = pkg.Modulator(mode=mode, max_frames=2)
+    try:
+        N = md.geometry["spacing"]
+        md.set_resampler(2048000, out_rate)
+        r = O.Resampler(2048000, out_rate, N)
+        x = synth_signal(2 * md.geometry["tf_samples"], seed=52) * np.float32(1 / 160)
+        y = md.resample(x)
+        assert rel_rms(y, r.process(x)) < REL_RMS
+    finally:
+        md.close()
+
+
+def test_chain_rational_rate_with_poly(pkg):
+    """cfg 4 at 2.4 Msps (L / M = 150 / 128): general resampler kernel, predistorter as its own kernel."""
+    def setup(md):
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_resampler(2048000, 2400000)
+        md.set_poly(POLY_AM, POLY_PM)
+    y, ref = _chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY,
+                         1, 2, dict(gain_mode=2, normalise=1.0 / 50000.0, out_rate=2400000,
+                                    am=POLY_AM, pm=POLY_PM), setup)
+    assert y.shape[1] == 196608 * 150 // 128
 
 
 # --------------------------------------------------------------------------- the fused chain

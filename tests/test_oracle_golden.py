@@ -277,7 +277,7 @@ def _resampler_model(x, nin, nout, factor):
     return np.concatenate(out)
 
 
-@pytest.mark.parametrize("out_rate", [8192000, 4096000, 1024000])
+@pytest.mark.parametrize("out_rate", [8192000, 4096000, 1024000, 2400000, 3072000, 6144000, 2304000, 2500000])
 def test_resampler_matches_float64_model_across_two_frames(out_rate):
     """a10: state carries across frames (src/Resampler.cpp:142-192): feed two TFs."""
     r = O.Resampler(2048000, out_rate, 2048)

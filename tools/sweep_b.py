@@ -17,7 +17,7 @@ def run(B, chunks, mask, iters=8):
     if os.environ.get("TII"):
         md.set_tii(True, 3, 5)
     if mask & 4:
-        md.set_resampler(2048000, 8192000)
+        md.set_resampler(2048000, int(os.environ.get("RATE", "8192000")))
         md.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0])
     with torch.cuda.stream(st):
         bits = torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device="cuda")
