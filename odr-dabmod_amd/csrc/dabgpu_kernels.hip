@@ -2066,26 +2066,37 @@ void resampler_rational_kernel(const ResamplerArgs a, int hops_per_run)
             const int p = q * M + grp;                       // this group's branch (may run past L: computed, not stored)
             const int pe = p < L ? p : 0;
             const int off = (int)(((long)M * pe) % L);       // (r p) mod L for r = rho + L - M is (rho p - M p) mod L
+            // the fold: the weights depend on (p, rho) only, so rho is the outer loop and the lane's eight bins
+            // k' = l + TS i share them
             cf v[8];
 #pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int kp = l + TS * i;                   // bin k' of the S-point transform
-                cf acc = mk(0.f, 0.f);
-                int idx = 0;                                 // (rho p) mod L
-                for (int rho = 0; rho < M; ++rho) {
-                    const int k = kp + S * rho;
-                    const cf g = gl[k];
-                    int in2 = idx - off;
-                    in2 += in2 < 0 ? L : 0;
-                    const cf cpos = cl[idx], cneg = cl[in2];
-                    cf c = k < HIN ? cpos : cneg;
-                    if (k == HIN) c = cadd(cpos, cneg);      // the Nyquist bin sits at both +nin/2 and -nin/2
-                    acc = cadd(acc, cmul(g, c));
-                    idx += pe;
-                    idx -= idx >= L ? L : 0;
+            for (int i = 0; i < 8; ++i) v[i] = mk(0.f, 0.f);
+            int idx = 0;                                     // (rho p) mod L
+            for (int rho = 0; rho < M; ++rho) {
+                int in2 = idx - off;
+                in2 += in2 < 0 ? L : 0;
+                const cf cpos = cl[idx], cneg = cl[in2];
+                if (M == 1) {
+                    // one term per bin: the half of the spectrum decides, and the Nyquist bin gets both
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) {
+                        const int k = l + TS * i;
+                        cf c = k < HIN ? cpos : cneg;
+                        if (k == HIN) c = cadd(cpos, cneg);
+                        v[i] = cmul(gl[k], c);
+                    }
+                } else {
+                    const cf c = rho < M / 2 ? cpos : cneg;  // k = k' + S rho < nin/2  <=>  rho < M/2
+#pragma unroll
+                    for (int i = 0; i < 8; ++i) v[i] = cadd(v[i], cmul(gl[l + TS * i + S * rho], c));
+                    // the Nyquist bin (k' = 0, rho = M/2) sits at -nin/2 (above) and at +nin/2 as well
+                    if (rho == M / 2 && l == 0) v[0] = cadd(v[0], cmul(gl[HIN], cpos));
                 }
-                v[i] = cmul(acc, a.tw_out[(int)(((long)kp * pe) % nout)]);
+                idx += pe;
+                idx -= idx >= L ? L : 0;
             }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) v[i] = cmul(v[i], a.tw_out[(int)(((long)(l + TS * i) * pe) % nout)]);
             FS::template run<+1, true>(v, gbuf, spar, tws, l, nullptr);
             if (p < L && lane_on) {
 #pragma unroll
