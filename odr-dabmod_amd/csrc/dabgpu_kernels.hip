@@ -2103,6 +2103,9 @@ void resampler_rational_kernel(const ResamplerArgs a, int hops_per_run)
                 for (int m = 0; m < 4; ++m) dst[(size_t)L * (l + TS * m) + p] = v[m];   // j = l + TS m < S / 2
             }
         }
+        // the groups' exchange buffers and the nin-point transform's share the same memory under different
+        // layouts: nobody may still be reading the former when the next hop starts writing the latter
+        lds_barrier();
     }
 }
 
