@@ -32,8 +32,14 @@
 #ifndef DABGPU_TF_WAVES_CARRIERS_GAIN
 #define DABGPU_TF_WAVES_CARRIERS_GAIN 1   // 1: the carriers-input FIR variants WITH gain (time-domain statistics keep both
 #endif                                    //    transforms of a symbol live) get 2 waves/SIMD (256 VGPRs) instead of spilling at 168
+#ifndef DABGPU_BND_UNROLL
+#define DABGPU_BND_UNROLL 1               // unroll factor of the boundary-FIR tap loop
+#endif
+#ifndef DABGPU_PK_OPSEL
+#define DABGPU_PK_OPSEL 1                 // packed twiddle products through op_sel (hand-written VOP3P), see cmul(c2, cf)
+#endif
 #ifndef DABGPU_GVAR_WAVES
-#define DABGPU_GVAR_WAVES 2               // waves/SIMD of the carriers-input FIR variant specialised for gain mode var
+#define DABGPU_GVAR_WAVES 3               // waves/SIMD of the carriers-input FIR variant specialised for gain mode var
 #endif
 #ifndef DABGPU_GVAR_TW64
 #define DABGPU_GVAR_TW64 0                // that variant reads the stride-64 twiddles from LDS (14 VGPRs fewer)
@@ -84,7 +90,26 @@ struct c2 {
 };
 DEV c2 cadd(c2 a, c2 b) { return c2{a.re + b.re, a.im + b.im}; }
 DEV c2 csub(c2 a, c2 b) { return c2{a.re - b.re, a.im - b.im}; }
+#if DABGPU_PK_OPSEL
+// Twiddle product of the packed pair: four VOP3P instructions that read the twiddle's two halves through
+// op_sel.  Written out by hand because the compiler does not use op_sel here: from the plain expression
+// below it keeps every twiddle duplicated as (x, x) and (y, y) register pairs -- 28 extra VGPRs in the FIR
+// variants of the frame kernel.
+typedef float v2f __attribute__((ext_vector_type(2)));
+DEV c2 cmul(c2 a, cf w)
+{
+    const v2f are = {a.re.x, a.re.y}, aim = {a.im.x, a.im.y}, ww = {w.x, w.y};
+    v2f t0, t1, re, im;
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t0) : "v"(aim), "v"(ww));          // im * w.y
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
+        : "=v"(re) : "v"(are), "v"(ww), "v"(t0));                                                         // re * w.x - t0
+    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t1) : "v"(aim), "v"(ww));          // im * w.x
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(im) : "v"(are), "v"(ww), "v"(t1));   // re * w.y + t1
+    return c2{make_float2(re.x, re.y), make_float2(im.x, im.y)};
+}
+#else
 DEV c2 cmul(c2 a, cf w) { return c2{a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x}; }
+#endif
 
 // multiply by (S * i)
 template <int S> DEV cf mul_i(cf a) { return S > 0 ? mk(-a.y, a.x) : mk(a.y, -a.x); }
@@ -889,8 +914,8 @@ void tf_kernel(const TfArgs a)
             const int i = i0 + (t >> 2), q = t & 3;
             const int ii = i < C ? i : 0;
             cf acc = mk(0.f, 0.f);
-            // (kept rolled on purpose: unrolling its 12 iterations pushes the kernel into spilling)
-#pragma unroll 1
+            // (rolled or lightly unrolled: fully unrolling its 12 iterations pushes the kernel into spilling)
+#pragma unroll DABGPU_BND_UNROLL
             for (int j = q; j < ntaps; j += 4) {
                 const cf x = src[ii + j];
                 const float tp = taps_l[j];
