@@ -1042,6 +1042,21 @@ void tf_kernel(const TfArgs a)
             if (FROM_BITS && a.gain1 != nullptr && s == 1 && t == 0) a.gain1[frame] = g;
         }
 
+        // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the
+        // (unfiltered, filtered) pairs the dual transform left side by side; everything below uses v and z as is
+        constexpr bool PRESCALED = DUAL && GAIN;
+        if (PRESCALED) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float2 re = make_float2(v[m].x, z[m].x) * g, im = make_float2(v[m].y, z[m].y) * g;
+                v[m] = mk(re.x, im.x);
+                z[m] = mk(re.y, im.y);
+            }
+        }
+        auto scaled = [&](cf x) __attribute__((always_inline)) -> cf {
+            return (PRESCALED || !GAIN) ? x : cscale(x, g);
+        };
+
         const int cpl = (!FROM_BITS && s == 0) ? cp0 : cp;
         const int seg = N + cpl;
         // position of this segment in the frame's output stream
@@ -1056,20 +1071,20 @@ void tf_kernel(const TfArgs a)
                 // Slot tests are wave-uniform, only the lane tests are vector work.
                 const int m_h0 = (N - cpl) / T;
                 if (C <= T) {      // the usual case (45 taps, T = 256): one tail slot, at most two head slots
-                    if (t >= T - C) tail_new[t - (T - C)] = cscale(v[7], g);
+                    if (t >= T - C) tail_new[t - (T - C)] = scaled(v[7]);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
                         if (m == m_h0 || m == m_h0 + 1) {
                             const int hn = t + T * m - (N - cpl);
-                            if (hn >= 0 && hn < C) head[hn] = cscale(v[m], g);
+                            if (hn >= 0 && hn < C) head[hn] = scaled(v[m]);
                         }
                     }
                 } else {           // short FFTs (T = 32, 64) or long filters
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
                         const int tn = t + T * m - (N - C), hn = t + T * m - (N - cpl);
-                        if (tn >= 0) tail_new[tn] = cscale(v[m], g);
-                        if (hn >= 0 && hn < C) head[hn] = cscale(v[m], g);
+                        if (tn >= 0) tail_new[tn] = scaled(v[m]);
+                        if (hn >= 0 && hn < C) head[hn] = scaled(v[m]);
                     }
                 }
             }
@@ -1098,7 +1113,7 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
-                const cf y = (GAIN || FIR) ? cscale(v[m], g) : v[m];
+                const cf y = scaled(v[m]);
                 if (!FIR || n < N - C) fout[pos + cpl + n] = y;            // FIR: the last C belong to `boundary`
                 if (m > m_cp || (m == m_cp && n >= N - cpl)) fout[pos + n - (N - cpl)] = y;
             }
