@@ -59,18 +59,23 @@ int PrbsGenerator::process(std::vector<Buffer *> dataIn, std::vector<Buffer *> d
     dataOut[0]->setLength(m_framesize);
     uint8_t *out = static_cast<uint8_t *>(dataOut[0]->getData());
 
-    // the register restarts on every call: all ones up to the polynomial's degree (reference :144-153)
-    uint32_t acc = m_accum_init;
-    if (!acc)
-        while (acc < m_polynomial) acc = (acc << 1) | 1u;
-    size_t i = 0;
-    for (; i < m_init && i < m_framesize; ++i) out[i] = 0xff;
-    for (; i < m_framesize; ++i) {
-        // eight steps of the Fibonacci register; the byte is its low eight bits (reference :58-73,112-123)
-        for (int k = 0; k < 8; ++k) acc = (acc << 1) ^ parity32(acc & m_polynomial);
-        // (the DVB variant of the reference blanks every 188th byte, :163-165)
-        out[i] = (m_accum_init == 0xa9 && i % 188 == 0) ? 0 : static_cast<uint8_t>(acc);
+    // The register restarts on every call (all ones up to the polynomial's degree, reference :144-153), so
+    // the sequence is the same every time: generated once, copied afterwards.
+    if (m_sequence.size() != m_framesize) {
+        m_sequence.resize(m_framesize);
+        uint32_t acc = m_accum_init;
+        if (!acc)
+            while (acc < m_polynomial) acc = (acc << 1) | 1u;
+        size_t i = 0;
+        for (; i < m_init && i < m_framesize; ++i) m_sequence[i] = 0xff;
+        for (; i < m_framesize; ++i) {
+            // eight steps of the Fibonacci register; the byte is its low eight bits (reference :58-73,112-123)
+            for (int k = 0; k < 8; ++k) acc = (acc << 1) ^ parity32(acc & m_polynomial);
+            // (the DVB variant of the reference blanks every 188th byte, :163-165)
+            m_sequence[i] = (m_accum_init == 0xa9 && i % 188 == 0) ? 0 : static_cast<uint8_t>(acc);
+        }
     }
+    std::memcpy(out, m_sequence.data(), m_framesize);
     if (!dataIn.empty()) {
         if (dataIn[0]->getLength() != m_framesize)
             throw std::runtime_error("PrbsGenerator::process input size is not equal to output size!\n");
@@ -89,19 +94,45 @@ int ConvEncoder::process(Buffer *const dataIn, Buffer *dataOut)
         throw std::runtime_error("ConvEncoder::process input size not valid!\n");
     dataOut->setLength(4 * m_framesize + 3);
     const uint8_t *in = static_cast<const uint8_t *>(dataIn->getData());
-    BitWriter w(static_cast<uint8_t *>(dataOut->getData()));
-    // 7-bit register, new bit enters at bit 6; generators 133, 171, 145, 133 (octal) read as the
-    // masks 0x5b, 0x79, 0x65, 0x5b on it (reference :95-113)
-    static const unsigned gen[4] = {0x5b, 0x79, 0x65, 0x5b};
-    unsigned reg = 0;
-    auto step = [&](unsigned bit) {
-        reg = (reg >> 1) | (bit << 6);
-        for (unsigned g : gen) w.put(parity32(reg & g));
+    uint8_t *out = static_cast<uint8_t *>(dataOut->getData());
+    // 7-bit register, new bit enters at bit 6; generators 133, 171, 145, 133 (octal) read as the masks
+    // 0x5b, 0x79, 0x65, 0x5b on it (reference :95-113).  One input byte = 32 code bits that depend on the
+    // byte and on the six bits before it: a 64 x 256 table of code words, built once.
+    struct Table {
+        uint32_t code[64][256];
+        uint8_t next[256];
+        Table()
+        {
+            static const unsigned gen[4] = {0x5b, 0x79, 0x65, 0x5b};
+            for (unsigned st = 0; st < 64; ++st)
+                for (unsigned b = 0; b < 256; ++b) {
+                    unsigned reg = st << 1;
+                    uint32_t w = 0;
+                    for (int i = 7; i >= 0; --i) {
+                        reg = (reg >> 1) | (((b >> i) & 1u) << 6);
+                        for (unsigned g : gen) w = (w << 1) | parity32(reg & g);
+                    }
+                    code[st][b] = w;
+                    next[b] = static_cast<uint8_t>(reg >> 1);      // the six newest bits: a function of the byte alone
+                }
+        }
     };
-    for (size_t i = 0; i < m_framesize; ++i)
-        for (int b = 7; b >= 0; --b) step((in[i] >> b) & 1u);
-    for (int tail = 0; tail < 6; ++tail) step(0);     // flush: 24 code bits (reference :120-139)
-    return static_cast<int>(w.bytes());
+    static const Table tab;
+    unsigned st = 0;
+    for (size_t i = 0; i < m_framesize; ++i) {
+        const uint32_t w = tab.code[st][in[i]];
+        out[4 * i] = static_cast<uint8_t>(w >> 24);
+        out[4 * i + 1] = static_cast<uint8_t>(w >> 16);
+        out[4 * i + 2] = static_cast<uint8_t>(w >> 8);
+        out[4 * i + 3] = static_cast<uint8_t>(w);
+        st = tab.next[in[i]];
+    }
+    // flush: six zero bits = 24 code bits (reference :120-139): the top 24 bits of the word for a zero byte
+    const uint32_t tail = tab.code[st][0];
+    out[4 * m_framesize] = static_cast<uint8_t>(tail >> 24);
+    out[4 * m_framesize + 1] = static_cast<uint8_t>(tail >> 16);
+    out[4 * m_framesize + 2] = static_cast<uint8_t>(tail >> 8);
+    return static_cast<int>(4 * m_framesize + 3);
 }
 
 // ---------------------------------------------------------------- PuncturingEncoder
@@ -200,10 +231,18 @@ int TimeInterleaver::process(Buffer *const dataIn, Buffer *dataOut)
     // bit b (MSB first) of byte j comes from the frame delayed by bitrev4(2b + (j & 1)) ... spelled
     // out: even bytes 0,8,4,12,2,10,6,14, odd bytes 1,9,5,13,3,11,7,15 (reference :66-93)
     static const unsigned delay[2][8] = {{0, 8, 4, 12, 2, 10, 6, 14}, {1, 9, 5, 13, 3, 11, 7, 15}};
-    for (size_t j = 0; j < m_framesize; ++j) {
-        unsigned v = 0;
-        for (int b = 0; b < 8; ++b) v |= m_history[(m_head + delay[j & 1][b]) & 15][j] & (0x80u >> b);
-        out[j] = static_cast<uint8_t>(v);
+    // one pass per bit plane over 16-bit words (even byte | odd byte): plain loops the compiler vectorises
+    const size_t nw = m_framesize / 2;
+    for (int b = 0; b < 8; ++b) {
+        const uint8_t *he = m_history[(m_head + delay[0][b]) & 15].data();
+        const uint8_t *ho = m_history[(m_head + delay[1][b]) & 15].data();
+        const uint8_t mask = static_cast<uint8_t>(0x80u >> b);
+        uint8_t *o = out;
+        if (b == 0) {
+            for (size_t w = 0; w < nw; ++w) { o[2 * w] = he[2 * w] & mask; o[2 * w + 1] = ho[2 * w + 1] & mask; }
+        } else {
+            for (size_t w = 0; w < nw; ++w) { o[2 * w] |= he[2 * w] & mask; o[2 * w + 1] |= ho[2 * w + 1] & mask; }
+        }
     }
     return static_cast<int>(m_framesize);
 }

@@ -44,6 +44,7 @@ private:
     size_t m_framesize;
     uint32_t m_polynomial, m_accum_init;
     size_t m_init;
+    std::vector<uint8_t> m_sequence;     // the (input-independent) sequence, generated on first use
 };
 
 // reference src/ConvEncoder.h, .cpp:59-150: K = 7 mother code of rate 1/4, six tail bits
