@@ -615,7 +615,9 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
                           (int)c->cur.taps.size() <= tf_max_fused_taps();
     // one fused kernel, unless the guard interval is windowed, the filter does not fit it, or CFR is on
     // (then: IFFT[+CFR][+gain] -> guard kernel -> FIR kernel)
-    const bool windowed = (c->cur.overlap > 0 || ((mask & DABGPU_STAGE_FIR) && !fir_fits) || c->cur.cfr_enable) &&
+    // (CFR has fused variants with the whole epilogue -- guard + FIR -- or with none of it)
+    const bool windowed = (c->cur.overlap > 0 || ((mask & DABGPU_STAGE_FIR) && !fir_fits) ||
+                           (c->cur.cfr_enable && !(mask & DABGPU_STAGE_FIR))) &&
                           !(mask & DABGPU_STAGE_NOGUARD);
     if (windowed && c->cur.overlap > 0) {
         const size_t W = c->cur.overlap;

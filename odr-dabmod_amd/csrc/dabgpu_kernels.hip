@@ -570,7 +570,7 @@ template <> struct ModeGeom<9> { static constexpr int nb_symbols = 76, K = 384, 
 template <> struct ModeGeom<8> { static constexpr int nb_symbols = 153, K = 192, null_size = 345, sym_size = 319; };
 template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768, null_size = 1328, sym_size = 1276; };
 
-// CFR (f-3, only without GUARD/FIR: the chain then continues with the stand-alone guard and FIR
+// CFR (f-3; either with the whole fused epilogue GUARD + FIR or with neither: then the chain continues with the stand-alone guard and FIR
 // kernels): crest-factor reduction of every symbol right after its IFFT, in registers -- clip, forward
 // FFT, error clip against the lane's own input bins, IFFT again -- plus the reference's statistics.
 // GVAR (carriers path with GAIN only): the gain mode is known to be "var" -- the statistics come from
@@ -578,12 +578,12 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // the third workgroup per CU) is compiled out.
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             !FIR ? 2 : (GVAR ? DABGPU_GVAR_WAVES
+                             (!FIR || CFR) ? 2 : (GVAR ? DABGPU_GVAR_WAVES
                                                   : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2 : DABGPU_TF_WAVES)))
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
-    static_assert(!CFR || (!GUARD && !FIR), "CFR variants stop after OfdmGenerator(+GainControl)");
+    static_assert(!CFR || (GUARD == FIR), "CFR variants: the full fused epilogue, or none of it");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
@@ -650,6 +650,7 @@ void tf_kernel(const TfArgs a)
     const int r0 = (tt == 0) ? 3 : 0;
     int kpos[6];
     cf hk[6];
+    cf hk8[CFR && FIR ? 8 : 1];      // CFR: the corrected spectrum is dense, all eight bins of the lane are filtered
     {
         const int rr[6] = {r0, 1, 2, 5, 6, 7};
 #pragma unroll
@@ -658,6 +659,10 @@ void tf_kernel(const TfArgs a)
             kpos[c] = (bin <= K / 2) ? bin - 1 : bin - N + K;
             if (FIR) hk[c] = a.t.fir_h[bin];
         }
+    }
+    if (CFR && FIR) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) hk8[m] = a.t.fir_h[tt + T * m];
     }
     int bitpos[6];
     unsigned phase[6];
@@ -743,7 +748,7 @@ void tf_kernel(const TfArgs a)
     // src/OfdmGenerator.cpp:222-277 and cfr_one_iteration :310-373).  v: IFFT output in, CFR output
     // out; refv: the lane's 8 input bins (a forward transform returns every bin to the lane it came
     // from, so the error is formed in place).  stats: also the side statistics of symbol s.
-    auto cfr_symbol = [&](cf *v, const cf *refv, int s, bool stats) __attribute__((always_inline)) {
+    auto cfr_symbol = [&](cf *v, cf *zf, const cf *refv, int s, bool stats) __attribute__((always_inline)) {
         const float clip2 = a.cfr_clip * a.cfr_clip, eclip2 = a.cfr_errclip * a.cfr_errclip;   // :315, :339
         const bool mer_sym = stats && s > 0 && s == (a.cfr_mer_base + frame) % nsym;             // :198, :250
         constexpr int NW = (T + 63) / 64;
@@ -790,7 +795,25 @@ void tf_kernel(const TfArgs a)
             }
             v[m] = cadd(c, e);
         }
-        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+        if (FIR) {
+            // the corrected spectrum and its filtered copy go back to the time domain as one packed transform;
+            // zf receives the filtered symbol
+            c2 v2[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const cf f = cmul(v[m], hk8[CFR && FIR ? m : 0]);
+                v2[m] = c2{make_float2(v[m].x, f.x), make_float2(v[m].y, f.y)};
+            }
+            F::template run<+1, DBUF, c2>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt,
+                                          DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                v[m] = mk(v2[m].re.x, v2[m].im.x);
+                zf[m] = mk(v2[m].re.y, v2[m].im.y);
+            }
+        } else {
+            F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+        }
         if (stats) {
             unsigned n1 = lane_on ? nclip : 0u, n2 = lane_on ? neclip : 0u;
 #pragma unroll
@@ -891,9 +914,9 @@ void tf_kernel(const TfArgs a)
         place(val, v);
         F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
         if (CFR) {
-            cf refv[8];
+            cf refv[8], zdummy[8];
             place(val, refv);
-            cfr_symbol(v, refv, 1, false);
+            cfr_symbol(v, zdummy, refv, 1, false);
         }
         g_null = symbol_gain_fused<T>(v, a.gain, red + 8, tt, lane_on);
     }
@@ -988,7 +1011,14 @@ void tf_kernel(const TfArgs a)
         }
         constexpr bool DUAL = FIR && DABGPU_DUAL_FFT;
         cf z[8];                                  // DUAL: the filtered symbol
-        if (DUAL) {
+        if (DUAL && CFR) {
+            // IFFT alone, crest-factor reduction on it, and back through the packed pair (inside cfr_symbol)
+            cf refv[8];
+            place(val, v);
+            F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+            place(val, refv);
+            cfr_symbol(v, z, refv, s, !lookahead);
+        } else if (DUAL) {
             // unfiltered and filtered transform of the symbol in lockstep (see struct c2)
             cf valf[6];
 #pragma unroll
@@ -1011,7 +1041,7 @@ void tf_kernel(const TfArgs a)
             if (CFR) {
                 cf refv[8];
                 place(val, refv);
-                cfr_symbol(v, refv, s, true);
+                cfr_symbol(v, z, refv, s, true);
             }
         }
 
@@ -1145,15 +1175,21 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0));
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
-#define TF_LAUNCH_CFR(FB, GN)                                                                  \
-    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, false, false, 0, true>), grid, block, lds, s, a)
+#define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
+    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, EPI, EPI, 0, true>), grid, block, lds, s, a)
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
     if (flags & TF_CFR) {
-        if (gd || fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
-        if (fb) { if (gn) TF_LAUNCH_CFR(true, true); else TF_LAUNCH_CFR(true, false); }
-        else    { if (gn) TF_LAUNCH_CFR(false, true); else TF_LAUNCH_CFR(false, false); }
+        // with the whole fused epilogue (guard + FIR) or with none of it
+        if (gd != fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
+        if (fr) {
+            if (fb) { if (gn) TF_LAUNCH_CFR(true, true, true); else TF_LAUNCH_CFR(true, false, true); }
+            else    { if (gn) TF_LAUNCH_CFR(false, true, true); else TF_LAUNCH_CFR(false, false, true); }
+        } else {
+            if (fb) { if (gn) TF_LAUNCH_CFR(true, true, false); else TF_LAUNCH_CFR(true, false, false); }
+            else    { if (gn) TF_LAUNCH_CFR(false, true, false); else TF_LAUNCH_CFR(false, false, false); }
+        }
         return hipGetLastError();
     }
 #define TF_LAUNCH_GVAR(GD, FR)                                                                 \
@@ -1211,7 +1247,7 @@ hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
         case 9: return launch_tf_n<9, 0>(a, flags, s);
         case 10: return launch_tf_n<10, 0>(a, flags, s);
         case 11:
-            return ((flags & TF_FIR) && a.ntaps == 45) ? launch_tf_n<11, 45>(a, flags, s)
+            return ((flags & TF_FIR) && a.ntaps == 45 && !(flags & TF_CFR)) ? launch_tf_n<11, 45>(a, flags, s)
                                                        : launch_tf_n<11, 0>(a, flags, s);
     }
     return hipErrorInvalidValue;
