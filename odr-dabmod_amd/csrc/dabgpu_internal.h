@@ -64,7 +64,7 @@ struct TfArgs {
 enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */ };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
-size_t tf_lds_bytes(int logN, unsigned flags);
+size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0);
 int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
 
 // Stand-alone stage kernels (per-stage drop-ins and the non-fused fallbacks).

@@ -26,6 +26,9 @@
 #include <algorithm>
 
 // build-time tuning knobs (tools/variants.sh sweeps them)
+#ifndef DABGPU_C2_PAD_SHIFT
+#define DABGPU_C2_PAD_SHIFT 4  // packed (16-byte) exchange elements: one pad slot per 2^shift elements (3 or 4)
+#endif
 #ifndef DABGPU_TF_WAVES
 #define DABGPU_TF_WAVES 3      // __launch_bounds__ waves per SIMD for the FIR variants of tf_kernel (<= 168 VGPRs)
 #endif
@@ -75,6 +78,12 @@ constexpr float kSqrtHalf = 0.70710678118654752440f;
 DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 DEV cf mk(float x, float y) { return make_float2(x, y); }
+// One-instruction square root / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp).  The per-symbol gain is a wave-uniform
+// scalar that every lane computes for itself; the correctly rounded sqrtf and division expand to ~17 and ~10
+// instructions each, which made this scalar a tenth of the fused kernel's vector instructions.  Arguments are
+// zero or far above FLT_MIN, so the denormal pre-scaling of sqrtf is not needed either.
+DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
+DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
 DEV cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 DEV cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
 DEV cf cmul(cf a, cf b) { return mk(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)); }
@@ -174,26 +183,30 @@ template <int LOGN> struct Fft {
     // address of a lane at base + compile-time offset, so the 16 accesses of an
     // exchange need 2 address registers instead of 16.
     static constexpr int LDS_ELEMS = N + N / 8;
+    // 16-byte elements are padded one slot per 16 (lane pairs 272 bytes apart: the b128 scatter with
+    // stride 1 and the gathers are both conflict-free), which also makes the packed buffer smaller
+    static constexpr int LDS_ELEMS2 = N + N / 16;
 
     // One barrier per exchange: consecutive exchanges alternate between two LDS
     // buffers, so the next scatter can never overtake a lane still gathering from
     // the previous one (that lane is at most one barrier behind).
     // 8-byte elements (cf): padded i + (i >> 3) for strides 1 and 8.  16-byte elements (c2,
-    // ds_*_b128): only the stride-1 scatter needs the padding (modelled: writes conflict-free,
-    // reads 2-way); strides 8 and 64 are conflict-free unpadded.
+    // ds_*_b128): only the stride-1 scatter needs padding, i + (i >> 4); strides 8 and 64 are
+    // conflict-free unpadded.
     template <int NS, bool DBUF, typename V> static DEV void exchange(V *v, V *lds, int t)
     {
-        // (the padded read address base + m (T + T/8) needs T to be a multiple of 8: tiny transforms go unpadded)
-        constexpr bool PAD = (T % 8 == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
+        // (the padded read address base + m (T + T/P) needs T to be a multiple of P: tiny transforms go unpadded)
+        constexpr int PS = sizeof(V) == 8 ? 3 : DABGPU_C2_PAD_SHIFT, P = 1 << PS;
+        constexpr bool PAD = (T % P == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
         if (PAD) {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
-            V *wp = lds + (j0 + (j0 >> 3));
+            V *wp = lds + (j0 + (j0 >> PS));
 #pragma unroll
-            for (int r = 0; r < 8; ++r) wp[r * NS + (r * NS) / 8] = v[r];
+            for (int r = 0; r < 8; ++r) wp[r * NS + (r * NS) / P] = v[r];
             lds_barrier();
-            const V *rp = lds + (t + (t >> 3));
+            const V *rp = lds + (t + (t >> PS));
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = rp[m * (T + T / 8)];
+            for (int m = 0; m < 8; ++m) v[m] = rp[m * (T + T / P)];
             if (!DBUF) lds_barrier();
         } else {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
@@ -466,7 +479,7 @@ template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, 
 #pragma unroll
             for (int w = 1; w < NW; ++w) m = fmaxf(m, red[w]);
         }
-        return ((int)m != 0) ? 32767.0f / m : 1.0f;
+        return ((int)m != 0) ? 32767.0f * fast_rcp(m) : 1.0f;
     }
     // per-lane partial sums of 8 samples in fp32: their rounding errors are independent
     // across the 256 lanes and average out (~1e-8 on the total); the cross-lane tree is fp32
@@ -494,10 +507,10 @@ template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, 
     }
     const double d0 = f0, d1 = f1, d2 = f2, d3 = f3;
     const double mr = d0 * invN, mi = d1 * invN;
-    const float vr = sqrtf((float)fmax(d2 * invN - mr * mr, 0.0)) * gp.var_variance,
-                vi = sqrtf((float)fmax(d3 * invN - mi * mi, 0.0)) * gp.var_variance;
+    const float vr = fast_sqrt((float)fmax(d2 * invN - mr * mr, 0.0)) * gp.var_variance,
+                vi = fast_sqrt((float)fmax(d3 * invN - mi * mi, 0.0)) * gp.var_variance;
     if ((int)vr == 0) return 1.0f;
-    return 32767.0f / fmaxf(vr, vi);
+    return 32767.0f * fast_rcp(fmaxf(vr, vi));
 }
 
 // ---------------------------------------------------------------------------
@@ -595,7 +608,10 @@ void tf_kernel(const TfArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
     int fpar = 0;                                                       // which half the next exchange uses
-    double *red = reinterpret_cast<double *>(fbuf + ((FIR && DABGPU_DUAL_FFT) ? 2 : 1) * (DBUF ? 2 : 1) * F::LDS_ELEMS);  // 16 doubles
+    // packed dual transforms (FIR variants) exchange 16-byte elements: LDS_ELEMS2 of them with the default padding
+    constexpr int kXElems = (FIR && DABGPU_DUAL_FFT) ? ((!DBUF && DABGPU_C2_PAD_SHIFT == 4) ? 2 * F::LDS_ELEMS2 : 2 * (DBUF ? 2 : 1) * F::LDS_ELEMS)
+                                                      : (DBUF ? 2 : 1) * F::LDS_ELEMS;
+    double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
     // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
     // that the boundary outputs read in[i + j] without a tail/head case split
     // frequency-domain gain statistics (coded-bits path): one packed word of phases per lane
@@ -603,7 +619,8 @@ void tf_kernel(const TfArgs a)
     // (carriers path: three complex bins per lane instead -- the general form of the same statistic)
     cf *bnd = reinterpret_cast<cf *>(phw + (GAIN ? (FROM_BITS ? T : 6 * T) : 0));
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
-    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * kBnd : 0));
+    constexpr int KB = NT ? NT - 1 : kBnd;      // slots per half buffer: the look-ahead C when it is a compile-time constant
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * KB : 0));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
     // small read-only tables copied to LDS once: read through global memory they compile to
@@ -611,17 +628,21 @@ void tf_kernel(const TfArgs a)
     // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
     float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
     float *mag_l = taps_l + kMaxTaps;
-    cf *unit8 = reinterpret_cast<cf *>(mag_l + 160);   // exp(i p pi/4) with exact 0 / +-1 entries
-    cf *tw8_l = unit8 + 8;                              // DABGPU_TW8_LDS: 7 x 8 twiddles
+    // exp(i p pi/4) with exact 0 / +-1 entries, in 8 rotated copies: entry [rot * 8 + p] = exp(i (p + rot) pi/4).
+    // The coded-bits path keeps its differential phases without the common "+1 eighth per symbol" term and
+    // unreduced (see advance); the rotation is the symbol's share, picked through the table's base address.
+    cf *unit8 = reinterpret_cast<cf *>(mag_l + 160);
+    cf *tw8_l = unit8 + 64;                             // DABGPU_TW8_LDS: 7 x 8 twiddles
     if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
     cf *tw64_l = tw8_l + 56;                            // DABGPU_TW64_LDS: 7 x 64 twiddles (FIR variants)
     // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
     float *cfr_red = reinterpret_cast<float *>(tw64_l + 448);
     constexpr bool TW64 = (DABGPU_TW64_LDS || (GVAR && DABGPU_GVAR_TW64)) && FIR && F::NR8 >= 3;
     if (TW64) F::fill_tw64(a.t.twiddle, tw64_l, t, (int)blockDim.x);
-    if (t < 8) {
-        const float cx = (float)((int)((kCX >> (2u * t)) & 3u) - 1);
-        const float cy = (float)((int)((kCX >> (2u * ((t + 6u) & 7u))) & 3u) - 1);
+    if (t < 64) {
+        const unsigned p = ((unsigned)t + ((unsigned)t >> 3)) & 7u;
+        const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
+        const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
         unit8[t] = mk(cx, cy);
     }
     for (int i = t; i < kMaxTaps; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
@@ -665,6 +686,8 @@ void tf_kernel(const TfArgs a)
         for (int m = 0; m < 8; ++m) hk8[m] = a.t.fir_h[tt + T * m];
     }
     int bitpos[6];
+    // differential state of the lane's carriers in units of 1/64 turn (8 per eighth), not reduced, and without the
+    // "+1 eighth" every data block adds to every carrier: phase of symbol s = (phase[c] / 8 + s - 1) mod 8
     unsigned phase[6];
     const uint8_t *fbits = nullptr;
     if (FROM_BITS) {
@@ -672,7 +695,7 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             bitpos[c] = a.t.src_carrier[kpos[c]];
-            phase[c] = 2u * a.t.phase_q[kpos[c]];
+            phase[c] = 16u * a.t.phase_q[kpos[c]];
         }
     }
     const cf *fcar = FROM_BITS ? nullptr
@@ -685,15 +708,19 @@ void tf_kernel(const TfArgs a)
         unsigned ib[6], qb[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
+#ifdef DABGPU_EXPERIMENT_NOBITS
+            ib[c] = bitpos[c] * 3; qb[c] = bitpos[c] * 5;
+#else
             ib[c] = blk[bitpos[c] >> 3];
             qb[c] = blk[(K >> 3) + (bitpos[c] >> 3)];
+#endif
         }
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const int sh = 7 - (bitpos[c] & 7);
-            const unsigned i1 = (ib[c] >> sh) & 1u, q1 = (qb[c] >> sh) & 1u;
-            const unsigned gcode = i1 ^ (q1 * 3u);  // 00->0 10->1 11->2 01->3 quarter turns
-            phase[c] = (phase[c] + 2u * gcode + 1u) & 7u;
+            const unsigned sh = 7u - ((unsigned)bitpos[c] & 7u);
+            const unsigned i1 = __builtin_amdgcn_ubfe(ib[c], sh, 1u), q1 = __builtin_amdgcn_ubfe(qb[c], sh, 1u);
+            const unsigned gcode = (i1 ^ q1) | (q1 << 1);  // 00->0 10->1 11->2 01->3 quarter turns
+            phase[c] += gcode << 4;
         }
     };
     // global -> register half of the staging of block d: lanes 0 .. K/16-1 fetch one dword
@@ -713,7 +740,8 @@ void tf_kernel(const TfArgs a)
             const float mg = s >= 1 ? mag_l[s - 1] : 0.f;
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
-                const cf u = unit8[phase[c]];
+                const unsigned rot64 = ((unsigned)(s - 1) & 7u) << 6;        // (byte offset of the rotated copy)
+                const cf u = *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) + ((phase[c] & 0x38u) | rot64));
                 val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
             }
         } else {
@@ -893,9 +921,9 @@ void tf_kernel(const TfArgs a)
         float P = 0.f, Q = 0.f;
 #pragma unroll
         for (int w = 0; w < (T + 63) / 64; ++w) { P += redf[2 * w]; Q += redf[2 * w + 1]; }
-        const float vr = sqrtf(fmaxf(0.5f * (P + Q), 0.f)) * a.gain.var_variance;
-        const float vi = sqrtf(fmaxf(0.5f * (P - Q), 0.f)) * a.gain.var_variance;
-        return ((int)vr == 0) ? 1.0f : 32767.0f / fmaxf(vr, vi);
+        const float vr = fast_sqrt(fmaxf(0.5f * (P + Q), 0.f)) * a.gain.var_variance;
+        const float vi = fast_sqrt(fmaxf(0.5f * (P - Q), 0.f)) * a.gain.var_variance;
+        return ((int)vr == 0) ? 1.0f : 32767.0f * fast_rcp(fmaxf(vr, vi));
     };
 
     // gain of the NULL symbol = gain computed on symbol 1 (reference
@@ -966,7 +994,7 @@ void tf_kernel(const TfArgs a)
         const int nz = len0 - C;                      // the last C outputs belong to `boundary`
         for (int i = t; i < nz; i += (int)blockDim.x) fout[i] = mk(0.f, 0.f);
         if (FIR) {
-            for (int i = t; i < kBnd; i += (int)blockDim.x) bnd[cur * 2 * kBnd + i] = mk(0.f, 0.f);
+            for (int i = t; i < KB; i += (int)blockDim.x) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
             have_prev = true;
             prev_pos = 0;
             prev_seg = len0;
@@ -991,13 +1019,20 @@ void tf_kernel(const TfArgs a)
                 //   S = sum over carrier pairs {k, -k} of cos(pi/4 (p_k + p_-k)),
                 // because sum_n x[n]^2 = N sum_k X[k] X[-k].  Carrier -k of the lane's three positive
                 // carriers lives in lane T - t (lane 0 pairs with itself): exchange one packed word.
-                const unsigned w = (tt == 0) ? (phase[3] | (phase[5] << 3) | (phase[4] << 6))
-                                             : (phase[5] | (phase[4] << 3) | (phase[3] << 6));
+                // (three 3-bit fields; the middle one stays where it is in the phase word)
+                auto pack3 = [](unsigned f0, unsigned f1, unsigned f2) __attribute__((always_inline)) -> unsigned {
+                    return __builtin_amdgcn_ubfe(f0, 3u, 3u) | (f1 & 0x38u) | ((f2 << 3) & 0x1C0u);
+                };
+                const unsigned w = (tt == 0) ? pack3(phase[3], phase[5], phase[4]) : pack3(phase[5], phase[4], phase[3]);
                 phw[tt] = w;
                 lds_barrier();
                 const unsigned o = phw[(T - tt) & (T - 1)];
-                float part = unit8[(phase[0] + (o & 7u)) & 7u].x + unit8[(phase[1] + ((o >> 3) & 7u)) & 7u].x +
-                             unit8[(phase[2] + ((o >> 6) & 7u)) & 7u].x;
+                // both phases of a pair carry the symbol's rotation: table copy 2 (s - 1) mod 8
+                const unsigned rot64 = ((unsigned)(2 * (s - 1)) & 7u) << 6;
+                auto cosp = [&](unsigned sum8) __attribute__((always_inline)) -> float {
+                    return reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) + ((sum8 & 0x38u) | rot64))->x;
+                };
+                float part = cosp(phase[0] + (o << 3)) + cosp(phase[1] + o) + cosp(phase[2] + (o >> 3));
                 part = wave_sum_dpp(lane_on ? part : 0.f);
                 float *redf = reinterpret_cast<float *>(red + 8 * (s & 1));
                 if ((t & 63) == 0) redf[t >> 6] = part;      // combined after the transform's barriers
@@ -1055,10 +1090,10 @@ void tf_kernel(const TfArgs a)
                 // |X| of the symbol: the table holds the COMPONENT magnitude; diagonal states
                 // (odd phase, the same parity on every carrier) have modulus sqrt(2) times that
                 const float mg = mag_l[s - 1];                               // the loop never sees s = 0 here
-                const float m2 = mg * mg * (float)(1u + (phase[0] & 1u));
-                const float vr = sqrtf(m2 * fmaxf((float)(K / 2) + S, 0.f)) * a.gain.var_variance;
-                const float vi = sqrtf(m2 * fmaxf((float)(K / 2) - S, 0.f)) * a.gain.var_variance;
-                g = ((int)vr == 0) ? 1.0f : 32767.0f / fmaxf(vr, vi);
+                const float m2 = mg * mg * (float)(1u + (((phase[0] >> 3) + (unsigned)(s - 1)) & 1u));
+                const float vr = fast_sqrt(m2 * fmaxf((float)(K / 2) + S, 0.f)) * a.gain.var_variance;
+                const float vi = fast_sqrt(m2 * fmaxf((float)(K / 2) - S, 0.f)) * a.gain.var_variance;
+                g = ((int)vr == 0) ? 1.0f : 32767.0f * fast_rcp(fmaxf(vr, vi));
             } else if (!FROM_BITS && !CFR && (GVAR || a.gain.mode == 2) && s > 0) {
                 g = spectral_gain(reinterpret_cast<const float *>(red + 8 * (s & 1)));
             } else if (GVAR) {
@@ -1094,7 +1129,7 @@ void tf_kernel(const TfArgs a)
                                  : (size_t)s * (size_t)N;
         if (FIR) {
             // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
-            cf *tail_new = bnd + (cur ^ 1) * 2 * kBnd, *tail_prev = bnd + cur * 2 * kBnd, *head = tail_prev + C;
+            cf *tail_new = bnd + (cur ^ 1) * 2 * KB, *tail_prev = bnd + cur * 2 * KB, *head = tail_prev + C;
             if (lane_on) {
                 // The last C samples sit in the top register slot(s); the head of the segment (the
                 // first C samples of the cyclic prefix) in slot m_h0 and maybe the following ones.
@@ -1119,7 +1154,9 @@ void tf_kernel(const TfArgs a)
                 }
             }
             lds_barrier();
+#ifndef DABGPU_EXPERIMENT_NOBND
             if (have_prev) boundary(tail_prev);
+#endif
             cur ^= 1;
             if (DUAL) {
 #pragma unroll
@@ -1156,9 +1193,9 @@ void tf_kernel(const TfArgs a)
         // end of the frame: the look-ahead runs off the buffer, missing terms are
         // dropped (reference src/FIRFilter.cpp:186-191)
         lds_barrier();
-        for (int i = t; i < C; i += (int)blockDim.x) bnd[cur * 2 * kBnd + C + i] = mk(0.f, 0.f);   // zero head
+        for (int i = t; i < C; i += (int)blockDim.x) bnd[cur * 2 * KB + C + i] = mk(0.f, 0.f);   // zero head
         lds_barrier();
-        boundary(bnd + cur * 2 * kBnd);
+        boundary(bnd + cur * 2 * KB);
     }
 }
 
@@ -1172,7 +1209,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const dim3 block(T < 64 ? 64 : T);
     const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
     const bool gvar = !(flags & TF_FROM_BITS) && (flags & TF_GAIN) && !(flags & TF_CFR) && a.gain.mode == 2;
-    const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0));
+    const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0), (flags & TF_FIR) ? NT : 0);
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
 #define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
@@ -1213,16 +1250,18 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 
 }  // namespace
 
-size_t tf_lds_bytes(int logN, unsigned flags)
+size_t tf_lds_bytes(int logN, unsigned flags, int nt)
 {
     const size_t N = (size_t)1 << logN;
     const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
-    const size_t elem = ((flags & TF_FIR) && DABGPU_DUAL_FFT) ? 2 * sizeof(float2) : sizeof(float2);
-    size_t b = (dbuf ? 2 : 1) * (N + N / 8) * elem + 16 * sizeof(double);
+    const bool dual = (flags & TF_FIR) && DABGPU_DUAL_FFT;
+    size_t b = dual ? ((!dbuf && DABGPU_C2_PAD_SHIFT == 4) ? (N + N / 16) : (dbuf ? 2 : 1) * (N + N / 8)) * 2 * sizeof(float2)
+                    : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
+    b += 16 * sizeof(double);
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
-    if (flags & TF_FIR) b += 4 * DABGPU_KBND * sizeof(float2);  // 2 x [tail | next head]
+    if (flags & TF_FIR) b += 4 * (nt ? nt - 1 : DABGPU_KBND) * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
-    b += (kMaxTaps + 160) * sizeof(float) + 8 * sizeof(float2);  // taps, |y_s| table, unit vectors
+    b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
 #if DABGPU_TW8_LDS
     b += 56 * sizeof(float2);
 #endif
