@@ -76,6 +76,16 @@ constexpr float kSqrtHalf = 0.70710678118654752440f;
 // barrier would wait for HBM write acknowledgements.  Nothing in these kernels
 // communicates between waves through global memory, so LDS ordering is all we need.
 DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// timing experiments (wrong results): elements per lane that an FFT exchange really moves through LDS
+#ifndef DABGPU_EXPERIMENT_XR
+#define DABGPU_EXPERIMENT_XR 8
+#endif
+// the barriers of the FFT exchanges (timing experiment: -DDABGPU_EXPERIMENT_NOXBAR drops them -- wrong results)
+#ifdef DABGPU_EXPERIMENT_NOXBAR
+DEV void xbarrier() { asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); }
+#else
+DEV void xbarrier() { lds_barrier(); }
+#endif
 
 DEV cf mk(float x, float y) { return make_float2(x, y); }
 // One-instruction square root / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp).  The per-symbol gain is a wave-uniform
@@ -202,22 +212,22 @@ template <int LOGN> struct Fft {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
             V *wp = lds + (j0 + (j0 >> PS));
 #pragma unroll
-            for (int r = 0; r < 8; ++r) wp[r * NS + (r * NS) / P] = v[r];
-            lds_barrier();
+            for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[r * NS + (r * NS) / P] = v[r];
+            xbarrier();
             const V *rp = lds + (t + (t >> PS));
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = rp[m * (T + T / P)];
-            if (!DBUF) lds_barrier();
+            for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[m * (T + T / P)];
+            if (!DBUF) xbarrier();
         } else {
             const int j0 = (t / NS) * NS * 8 + (t % NS);
             V *wp = lds + j0;
 #pragma unroll
-            for (int r = 0; r < 8; ++r) wp[r * NS] = v[r];
-            lds_barrier();
+            for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[r * NS] = v[r];
+            xbarrier();
             const V *rp = lds + t;
 #pragma unroll
-            for (int m = 0; m < 8; ++m) v[m] = rp[m * T];
-            if (!DBUF) lds_barrier();
+            for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[m * T];
+            if (!DBUF) xbarrier();
         }
     }
 
@@ -269,17 +279,29 @@ template <int LOGN> struct Fft {
     // conjugate twiddles when S < 0 (table holds exp(+2 pi i m/N))
     template <int S> static DEV cf twid(cf w) { return S > 0 ? w : mk(w.x, -w.y); }
 
-    template <int S, bool DBUF = true, typename V = cf>
+    // U8 / U64: read the stride-8 / stride-64 stage's twiddles from the LDS tables tw8 / tw64 (1), from the
+    // resident set tw (0), or decide by the pointer (-1).  Call sites that know say so: a pointer into the
+    // dynamic LDS block is never provably non-null, and the run-time test costs a scalar branch per twiddle.
+    template <int S, bool DBUF = true, typename V = cf, int U8 = -1, int U64 = -1>
     static DEV void run(V *v, V *lds2, int &par, const cf *tw, int t, const cf *tw8 = nullptr,
                         const cf *tw64 = nullptr)
     {
 #define DABGPU_NEXT_BUF (lds2 + ((DBUF && (par ^= 1)) ? LDS_ELEMS : 0))
-        dft8<S>(v);
-        exchange<1, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         int n = 0;
         cf w[7];
+        // table twiddles of the second stage: requested ahead of the first exchange, whose barriers their LDS
+        // round trip then hides behind (read after it, the compiler serialises them: four round trips per transform)
+        constexpr bool EARLY8 = U8 == 1 && NR8 >= 2;
+        if (EARLY8) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw8[r * 8 + (t & 7)]);
+        }
+        dft8<S>(v);
+        exchange<1, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         if (NR8 >= 2) {
-            if (DABGPU_TW8_LDS && tw8) {
+            if (EARLY8) {
+                n += 7;
+            } else if (U8 < 0 && DABGPU_TW8_LDS && tw8) {
 #pragma unroll
                 for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw8[r * 8 + (t & 7)]);
                 n += 7;
@@ -292,7 +314,7 @@ template <int LOGN> struct Fft {
             if (NR8 > 2 || RF > 1) exchange<8, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
-            if (tw64) {
+            if (U64 == 1 || (U64 < 0 && tw64)) {
 #pragma unroll
                 for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw64[r * 64 + (t & 63)]);
                 n += 7;
@@ -638,6 +660,7 @@ void tf_kernel(const TfArgs a)
     // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
     float *cfr_red = reinterpret_cast<float *>(tw64_l + 448);
     constexpr bool TW64 = (DABGPU_TW64_LDS || (GVAR && DABGPU_GVAR_TW64)) && FIR && F::NR8 >= 3;
+    constexpr int kU8 = DABGPU_TW8_LDS ? 1 : 0;
     if (TW64) F::fill_tw64(a.t.twiddle, tw64_l, t, (int)blockDim.x);
     if (t < 64) {
         const unsigned p = ((unsigned)t + ((unsigned)t >> 3)) & 7u;
@@ -802,7 +825,7 @@ void tf_kernel(const TfArgs a)
             sm = wave_sum_dpp(lane_on ? sm : 0.f);
             if ((t & 63) == 0) { cfr_red[2 * (t >> 6)] = pk; cfr_red[2 * (t >> 6) + 1] = sm; }
         }
-        F::template run<-1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+        F::template run<-1, DBUF, cf, kU8, 0>(v, fbuf, fpar, tw, tt, tw8_l, nullptr);
         if (stats && t == 0) {
             float p = 0.f;
             double q = 0.;
@@ -832,15 +855,14 @@ void tf_kernel(const TfArgs a)
                 const cf f = cmul(v[m], hk8[CFR && FIR ? m : 0]);
                 v2[m] = c2{make_float2(v[m].x, f.x), make_float2(v[m].y, f.y)};
             }
-            F::template run<+1, DBUF, c2>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt,
-                                          DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+            F::template run<+1, DBUF, c2, kU8, 0>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l, nullptr);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 v[m] = mk(v2[m].re.x, v2[m].im.x);
                 zf[m] = mk(v2[m].re.y, v2[m].im.y);
             }
         } else {
-            F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+            F::template run<+1, DBUF, cf, kU8, 0>(v, fbuf, fpar, tw, tt, tw8_l, nullptr);
         }
         if (stats) {
             unsigned n1 = lane_on ? nclip : 0u, n2 = lane_on ? neclip : 0u;
@@ -940,7 +962,7 @@ void tf_kernel(const TfArgs a)
         cf val[6], v[8];
         load_active(1, val);
         place(val, v);
-        F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+        F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
         if (CFR) {
             cf refv[8], zdummy[8];
             place(val, refv);
@@ -958,20 +980,42 @@ void tf_kernel(const TfArgs a)
     bool have_prev = false;
 
     // boundary outputs of the previous segment: 4 lanes per output, shuffle-reduced
+    constexpr int kThreads = T < 64 ? 64 : T;      // == blockDim.x (a compile-time constant keeps it out of the loop)
     auto boundary = [&](const cf *src) __attribute__((always_inline)) {
         // src = [tail (C) | head (C)]; output i of the C boundary outputs = sum_j taps[j] src[i + j].
         // Four lanes (one DPP quad) share an output, lane q taking taps q, q+4, ...
-        for (int i0 = 0; i0 < C; i0 += (int)blockDim.x / 4) {
+        for (int i0 = 0; i0 < C; i0 += kThreads / 4) {
             const int i = i0 + (t >> 2), q = t & 3;
             const int ii = i < C ? i : 0;
             cf acc = mk(0.f, 0.f);
-            // (rolled or lightly unrolled: fully unrolling its 12 iterations pushes the kernel into spilling)
+            if (NT > 0) {
+                // tap count known: all reads of a lane at base + immediate, issued together and waited for
+                // once (the rolled loop below pays one LDS round trip per tap).  The last group of four
+                // runs past the filter for q > 0: the zero padding of the tap table cancels it, and its
+                // sample read is redirected to an address inside the buffer.
+                constexpr int KT = NT > 0 ? (NT + 3) / 4 : 1, REM = NT - 4 * (KT - 1);    // lanes q < REM own a tap in the last group
+                const cf *sp = src + ii + q;
+                const float *tq = taps_l + q;
+                cf x[KT];
+                float tp[KT];
+#pragma unroll
+                for (int k = 0; k < KT - 1; ++k) { x[k] = sp[4 * k]; tp[k] = tq[4 * k]; }
+                x[KT - 1] = (REM == 4 || q < REM) ? sp[4 * (KT - 1)] : sp[0];
+                tp[KT - 1] = tq[4 * (KT - 1)];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    acc.x = fmaf(x[k].x, tp[k], acc.x);
+                    acc.y = fmaf(x[k].y, tp[k], acc.y);
+                }
+            } else {
+                // (rolled or lightly unrolled: fully unrolling its iterations pushes the kernel into spilling)
 #pragma unroll DABGPU_BND_UNROLL
-            for (int j = q; j < ntaps; j += 4) {
-                const cf x = src[ii + j];
-                const float tp = taps_l[j];
-                acc.x = fmaf(x.x, tp, acc.x);
-                acc.y = fmaf(x.y, tp, acc.y);
+                for (int j = q; j < ntaps; j += 4) {
+                    const cf x = src[ii + j];
+                    const float tp = taps_l[j];
+                    acc.x = fmaf(x.x, tp, acc.x);
+                    acc.y = fmaf(x.y, tp, acc.y);
+                }
             }
             acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);   // the 4 lanes of an output
             acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);   // are one DPP quad
@@ -1004,6 +1048,7 @@ void tf_kernel(const TfArgs a)
     }
 
     for (int s = s_loop; s < s_stop; ++s) {
+        if (FROM_BITS) __builtin_assume(s >= 1);    // (the blank null symbol was peeled off above)
         const bool lookahead = s >= s_end;      // FIR only: no output for this symbol
         cf val[6], v[8];
         uint32_t pf = 0u;
@@ -1050,7 +1095,7 @@ void tf_kernel(const TfArgs a)
             // IFFT alone, crest-factor reduction on it, and back through the packed pair (inside cfr_symbol)
             cf refv[8];
             place(val, v);
-            F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, nullptr);
+            F::template run<+1, DBUF, cf, kU8, 0>(v, fbuf, fpar, tw, tt, tw8_l, nullptr);
             place(val, refv);
             cfr_symbol(v, z, refv, s, !lookahead);
         } else if (DUAL) {
@@ -1063,8 +1108,7 @@ void tf_kernel(const TfArgs a)
             c2 v2[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) v2[r] = c2{make_float2(v[r].x, z[r].x), make_float2(v[r].y, z[r].y)};
-            F::template run<+1, DBUF, c2>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt,
-                                          DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+            F::template run<+1, DBUF, c2, kU8, TW64 ? 1 : 0>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l, tw64_l);
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 v[m] = mk(v2[m].re.x, v2[m].im.x);
@@ -1072,12 +1116,20 @@ void tf_kernel(const TfArgs a)
             }
         } else {
             place(val, v);
-            F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+            F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
             if (CFR) {
                 cf refv[8];
                 place(val, refv);
                 cfr_symbol(v, z, refv, s, true);
             }
+        }
+
+        if (FROM_BITS) {
+            // Park the prefetched block of the next symbol in LDS now, BEFORE anything of this iteration is
+            // stored: vmcnt retires in order and also counts stores, so a wait for this load placed after
+            // the boundary outputs' (conditional) store has to be vmcnt(0) -- every wave would sit out the
+            // full HBM write latency of that store once per symbol.  (Half bb^1 was last read an iteration ago.)
+            bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;
         }
 
         float g = 1.0f;
@@ -1167,13 +1219,10 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
                 for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
                 place(val, v);
-                F::template run<+1, DBUF>(v, fbuf, fpar, tw, tt, DABGPU_TW8_LDS ? tw8_l : nullptr, TW64 ? tw64_l : nullptr);
+                F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
             }
         }
-        if (FROM_BITS) {
-            bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;   // waits for the prefetch only
-            bb ^= 1;
-        }
+        if (FROM_BITS) bb ^= 1;
         if (lookahead) break;
         if (lane_on) {
             const int m_cp = (N - cpl) / T;   // first register slot that is also copied into the prefix
@@ -1990,7 +2039,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         }
 #pragma unroll
         for (int m = 0; m < 4; ++m) b0[m] = cscale(xn[m], (wnd(m) + wnd(m + 4)) * sc);
-        F::template run<+1, true, c2>(v2, fbuf2, fpar, tw, t, tw8_l);
+        F::template run<+1, true, c2, 1, 0>(v2, fbuf2, fpar, tw, t, tw8_l);
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             Fc[m] = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
@@ -2053,7 +2102,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
                 }
                 v2[m] = c2{make_float2(xa.x, xb.x), make_float2(xa.y, xb.y)};
             }
-            F::template run<+1, true, c2>(v2, fbuf2, fpar, tw, t, tw8_l);
+            F::template run<+1, true, c2, 1, 0>(v2, fbuf2, fpar, tw, t, tw8_l);
 #pragma unroll
             for (int m = 0; m < 4; ++m) o[m * Q + pa] = mk(v2[m].re.x, v2[m].im.x);
             if (pb < Q) {
@@ -2153,7 +2202,7 @@ void resampler_rational_kernel(const ResamplerArgs a, int hops_per_run)
         cf v[8];
 #pragma unroll
         for (int m = 0; m < 8; ++m) { const float w = wnd(m); v[m] = mk(x[m].x * w, -x[m].y * w); }
-        F::template run<+1, true>(v, xbuf, fpar, tw, tt, nullptr);
+        F::template run<+1, true, cf, 0, 0>(v, xbuf, fpar, tw, tt, nullptr);
 #pragma unroll
         for (int m = 0; m < 8; ++m) f[m] = mk(v[m].x * a.factor, -v[m].y * a.factor);
     };
@@ -2212,7 +2261,7 @@ void resampler_rational_kernel(const ResamplerArgs a, int hops_per_run)
             }
 #pragma unroll
             for (int i = 0; i < 8; ++i) v[i] = cmul(v[i], a.tw_out[(int)(((long)(l + TS * i) * pe) % nout)]);
-            FS::template run<+1, true>(v, gbuf, spar, tws, l, nullptr);
+            FS::template run<+1, true, cf, 0, 0>(v, gbuf, spar, tws, l, nullptr);
             if (p < L && lane_on) {
 #pragma unroll
                 for (int m = 0; m < 4; ++m) dst[(size_t)L * (l + TS * m) + p] = v[m];   // j = l + TS m < S / 2
