@@ -115,7 +115,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(ALGO_BYTES))
-    ap.add_argument("--frames", type=int, default=8192, help="transmission frames per step per GPU")
+    ap.add_argument("--frames", type=int, default=32768,
+                    help="transmission frames per step per GPU (32768 = 51.5 GB of IQ per step: sized for 288 GB of HBM)")
     ap.add_argument("--chunks", type=int, default=0, help="workgroups per frame (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
@@ -241,7 +242,8 @@ def main():
             extra = {}
             # the other BASELINE configs, and the headline workload one frame at a time (B = 1:
             # what a single real-time stream sees; the frame is split over 11 workgroups)
-            for wl, b2 in (("cfg2", B), ("ifft_fir_stage", B), ("cfg4", max(64, B // 4)),
+            bs = min(B, 8192)      # (their carrier inputs are built with torch temporaries: keep those modest)
+            for wl, b2 in (("cfg2", bs), ("ifft_fir_stage", bs), ("cfg4", max(64, bs // 4)),
                            (args.workload + "_B1", 1)):
                 if wl == args.workload:
                     continue

@@ -56,6 +56,9 @@
 #ifndef DABGPU_TW64_LDS
 #define DABGPU_TW64_LDS 0      // 1: the stride-64 stage's twiddles (lane%64) from a 7 x 64 LDS table as well
 #endif
+#ifndef DABGPU_ZONLY
+#define DABGPU_ZONLY 1         // Mode I coded-bits chain with FIR: prune the unfiltered transform to the boundary samples
+#endif
 #ifndef DABGPU_FFT_DBUF
 #define DABGPU_FFT_DBUF 0      // FIR variants: 1 = two LDS exchange buffers (one barrier per exchange), 0 = one buffer,
                                // two barriers (36 KB of LDS per workgroup -> three workgroups per CU); the
@@ -352,6 +355,75 @@ template <int LOGN> struct Fft {
         }
 #undef DABGPU_NEXT_BUF
     }
+
+    // Packed dual transform (N = 2048, one exchange buffer) whose FIRST half is wanted at two short runs of
+    // outputs only -- the FIR boundary samples of the frame kernel: sample t + 6T in the first wave (the head of
+    // the cyclic prefix starts at N - cp = 6T + 8) and sample t + 7T in the last wave (the symbol's tail).
+    // Identical to run<S, false, c2> up to the third butterfly stage.  The last exchange then moves the SECOND
+    // half alone, as 8-byte elements (ds_write_b128 costs 13 LDS cycles per wave, ds_write_b64 6; reads 4 vs 2),
+    // plus outputs 0 and 7 of the first half's stage -- the only inputs of the wanted samples:
+    //   sample t + 6T (slot 6 = butterfly 0, output 3) reads positions t + 512 q       = stage output 0 of lane (q, t)
+    //   sample t + 7T (slot 7 = butterfly 1, output 3) reads positions t + 256 + 512 q = stage output 7 of lane (q, t - 192)
+    // and the final radix-4 stage runs on the second half (z, natural order) and on that one sample (uedge;
+    // meaningful in waves 0 and 3).
+    template <int S, int U8>
+    static DEV void run_dual_zonly(c2 *v, c2 *lds, const cf *tw, int t, const cf *tw8, cf *z, cf &uedge)
+    {
+        static_assert(LOGN == 11, "geometry of transmission mode I");
+        int n = 0;
+        cf w[7];
+        if (U8 == 1) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw8[r * 8 + (t & 7)]);
+        }
+        dft8<S>(v);
+        exchange<1, false, c2>(v, lds, t);
+        if (U8 == 1) n += 7; else stage_twiddles<S>(tw, n, w);
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        dft8<S>(v);
+        exchange<8, false, c2>(v, lds, t);
+        stage_twiddles<S>(tw, n, w);
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        dft8<S>(v);
+        // third exchange: second half as cf, first half's outputs 0 and 7 beside it
+        cf *zl = reinterpret_cast<cf *>(lds);      // N elements
+        cf *u0 = zl + N, *u7 = u0 + T;             // [wave][lane]
+        cf *wp = zl + ((t / 64) * 512 + (t % 64));
+#pragma unroll
+        for (int r = 0; r < 8; ++r) wp[64 * r] = mk(v[r].re.y, v[r].im.y);
+        u0[t] = mk(v[0].re.x, v[0].im.x);
+        u7[t] = mk(v[7].re.x, v[7].im.x);
+        xbarrier();
+#pragma unroll
+        for (int m = 0; m < 8; ++m) z[m] = zl[t + T * m];
+        const int wv = t >> 6;                     // wave-uniform
+        cf e[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+        if (wv == 0 || wv == 3) {
+            const cf *up = (wv == 0) ? u0 + t : u7 + (t - 192);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) e[q] = up[64 * q];
+        }
+        xbarrier();
+        cf wb[2][3];
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+#pragma unroll
+            for (int r = 0; r < 3; ++r) wb[b][r] = twid<S>(tw[n + 3 * b + r]);
+            cf x0 = z[b], x1 = cmul(z[b + 2], wb[b][0]), x2 = cmul(z[b + 4], wb[b][1]), x3 = cmul(z[b + 6], wb[b][2]);
+            dft4<S>(x0, x1, x2, x3);
+            z[b] = x0; z[b + 2] = x1; z[b + 4] = x2; z[b + 6] = x3;
+        }
+        // output 3 of the butterfly: (x0 - x2) - S i (x1 - x3), twiddles of butterfly 0 (first wave) or 1 (last wave)
+        auto edge = [&](const cf *wq) __attribute__((always_inline)) -> cf {
+            const cf y1 = cmul(e[1], wq[0]), y2 = cmul(e[2], wq[1]), y3 = cmul(e[3], wq[2]);
+            return csub(csub(e[0], y2), mul_i<S>(csub(y1, y3)));
+        };
+        uedge = mk(0.f, 0.f);
+        if (wv == 0) uedge = edge(wb[0]);
+        else if (wv == 3) uedge = edge(wb[1]);
+    }
 };
 
 // ---------------------------------------------------------------------------
@@ -611,7 +683,10 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // GVAR (carriers path with GAIN only): the gain mode is known to be "var" -- the statistics come from
 // the spectrum and the time-domain reduction (which keeps both transforms of a symbol live and costs
 // the third workgroup per CU) is compiled out.
-template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false>
+// ZONLY (Mode I coded-bits path with the fused FIR, gain mode fix / var): the unfiltered transform is formed only where
+// the boundary FIR reads it (Fft::run_dual_zonly).
+template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
+          bool ZONLY = false>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
                              (!FIR || CFR) ? 2 : (GVAR ? DABGPU_GVAR_WAVES
                                                   : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2 : DABGPU_TF_WAVES)))
@@ -619,12 +694,15 @@ void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
     static_assert(!CFR || (GUARD == FIR), "CFR variants: the full fused epilogue, or none of it");
+    static_assert(!ZONLY || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT > 0 && !CFR && DABGPU_DUAL_FFT && !DABGPU_FFT_DBUF),
+                  "ZONLY: the dual transform of the Mode I coded-bits chain");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
     constexpr bool DBUF = !FIR || DABGPU_FFT_DBUF;   // exchange buffers: see DABGPU_FFT_DBUF
     const int t = threadIdx.x;
-    const bool lane_on = t < T;  // only N=256 (T=32) runs with idle lanes
+    const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
+    const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
     const int tt = lane_on ? t : 0;
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -1072,13 +1150,21 @@ void tf_kernel(const TfArgs a)
                 phw[tt] = w;
                 lds_barrier();
                 const unsigned o = phw[(T - tt) & (T - 1)];
-                // both phases of a pair carry the symbol's rotation: table copy 2 (s - 1) mod 8
-                const unsigned rot64 = ((unsigned)(2 * (s - 1)) & 7u) << 6;
-                auto cosp = [&](unsigned sum8) __attribute__((always_inline)) -> float {
-                    return reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) + ((sum8 & 0x38u) | rot64))->x;
-                };
-                float part = cosp(phase[0] + (o << 3)) + cosp(phase[1] + o) + cosp(phase[2] + (o >> 3));
-                part = wave_sum_dpp(lane_on ? part : 0.f);
+                // Every carrier of a symbol has the same phase parity (each block adds an odd number of eighths
+                // to all of them), so a pair's phase sum is an even number of eighths and its cosine is +1, 0 or -1:
+                // S = #(sum = 0 mod 8) - #(sum = 4 mod 8).  Counted per wave with ballots -- the additions run on
+                // the scalar unit.  Both phases of a pair carry the symbol's rotation: 2 (s - 1) eighths.
+                const unsigned rot8 = ((unsigned)(2 * (s - 1)) & 7u) << 3;
+                const unsigned c0 = (0u - rot8) & 0x38u, c4 = (0x20u - rot8) & 0x38u;
+                const unsigned fs[3] = {(phase[0] + (o << 3)) & 0x38u, (phase[1] + o) & 0x38u, (phase[2] + (o >> 3)) & 0x38u};
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    // (v_cmp_eq_u32 straight into an SGPR pair: 32 = ICMP_EQ)
+                    cnt += __builtin_popcountll(__builtin_amdgcn_uicmp(fs[j], c0, 32) & on_mask);
+                    cnt -= __builtin_popcountll(__builtin_amdgcn_uicmp(fs[j], c4, 32) & on_mask);
+                }
+                const float part = (float)cnt;
                 float *redf = reinterpret_cast<float *>(red + 8 * (s & 1));
                 if ((t & 63) == 0) redf[t >> 6] = part;      // combined after the transform's barriers
             }
@@ -1091,6 +1177,7 @@ void tf_kernel(const TfArgs a)
         }
         constexpr bool DUAL = FIR && DABGPU_DUAL_FFT;
         cf z[8];                                  // DUAL: the filtered symbol
+        cf uedge = mk(0.f, 0.f);                  // ZONLY: the lane's boundary sample of the unfiltered symbol
         if (DUAL && CFR) {
             // IFFT alone, crest-factor reduction on it, and back through the packed pair (inside cfr_symbol)
             cf refv[8];
@@ -1108,11 +1195,15 @@ void tf_kernel(const TfArgs a)
             c2 v2[8];
 #pragma unroll
             for (int r = 0; r < 8; ++r) v2[r] = c2{make_float2(v[r].x, z[r].x), make_float2(v[r].y, z[r].y)};
-            F::template run<+1, DBUF, c2, kU8, TW64 ? 1 : 0>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l, tw64_l);
+            if constexpr (ZONLY) {
+                F::template run_dual_zonly<+1, kU8>(v2, reinterpret_cast<c2 *>(fbuf), tw, tt, tw8_l, z, uedge);
+            } else {
+                F::template run<+1, DBUF, c2, kU8, TW64 ? 1 : 0>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l, tw64_l);
 #pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                v[m] = mk(v2[m].re.x, v2[m].im.x);
-                z[m] = mk(v2[m].re.y, v2[m].im.y);
+                for (int m = 0; m < 8; ++m) {
+                    v[m] = mk(v2[m].re.x, v2[m].im.x);
+                    z[m] = mk(v2[m].re.y, v2[m].im.y);
+                }
             }
         } else {
             place(val, v);
@@ -1150,6 +1241,8 @@ void tf_kernel(const TfArgs a)
                 g = spectral_gain(reinterpret_cast<const float *>(red + 8 * (s & 1)));
             } else if (GVAR) {
                 g = g_null;                                   // s == 0
+            } else if (ZONLY) {
+                g = 512.0f;                                   // mode fix (the launcher keeps mode max off this variant)
             } else {
                 g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
             }
@@ -1162,7 +1255,11 @@ void tf_kernel(const TfArgs a)
         // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the
         // (unfiltered, filtered) pairs the dual transform left side by side; everything below uses v and z as is
         constexpr bool PRESCALED = DUAL && GAIN;
-        if (PRESCALED) {
+        if (PRESCALED && ZONLY) {
+            uedge = cscale(uedge, g);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) z[m] = cscale(z[m], g);
+        } else if (PRESCALED) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const float2 re = make_float2(v[m].x, z[m].x) * g, im = make_float2(v[m].y, z[m].y) * g;
@@ -1187,7 +1284,14 @@ void tf_kernel(const TfArgs a)
                 // first C samples of the cyclic prefix) in slot m_h0 and maybe the following ones.
                 // Slot tests are wave-uniform, only the lane tests are vector work.
                 const int m_h0 = (N - cpl) / T;
-                if (C <= T) {      // the usual case (45 taps, T = 256): one tail slot, at most two head slots
+                if (ZONLY) {
+                    // cpl == cp here (coded-bits path: s >= 1).  Tail = slot 7 of the last C lanes; head = samples
+                    // [N - cp, N - cp + C) = slot 6 of lanes [h0, h0 + C), all in the first wave
+                    constexpr int h0 = (N - cp) - 6 * T;
+                    static_assert(!ZONLY || (h0 >= 0 && h0 + (NT - 1) <= 64 && NT - 1 <= 64), "boundary lanes");
+                    if (t >= T - C) tail_new[t - (T - C)] = uedge;
+                    if (t >= h0 && t < h0 + C) head[t - h0] = uedge;
+                } else if (C <= T) {      // the usual case (45 taps, T = 256): one tail slot, at most two head slots
                     if (t >= T - C) tail_new[t - (T - C)] = scaled(v[7]);
 #pragma unroll
                     for (int m = 0; m < 8; ++m) {
@@ -1285,6 +1389,12 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         return hipGetLastError();
     }
 #undef TF_LAUNCH_GVAR
+    if (LOGN == 11 && NT == 45 && fb && fr && gd && DABGPU_ZONLY && (!gn || a.gain.mode != 1)) {
+        // Mode I, default filter length, gain fix / var (or none): the variant that prunes the unfiltered transform
+        if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        return hipGetLastError();
+    }
     if (fb) {
         if (gn) { if (fr) TF_LAUNCH(true, true, true, true); else if (gd) TF_LAUNCH(true, true, true, false); else TF_LAUNCH(true, true, false, false); }
         else    { if (fr) TF_LAUNCH(true, false, true, true); else if (gd) TF_LAUNCH(true, false, true, false); else TF_LAUNCH(true, false, false, false); }
