@@ -24,6 +24,7 @@
 #include "dabgpu_internal.h"
 
 #include <algorithm>
+#include <type_traits>
 
 // build-time tuning knobs (tools/variants.sh sweeps them)
 #ifndef DABGPU_C2_PAD_SHIFT
@@ -55,6 +56,12 @@
 #endif
 #ifndef DABGPU_TW64_LDS
 #define DABGPU_TW64_LDS 0      // 1: the stride-64 stage's twiddles (lane%64) from a 7 x 64 LDS table as well
+#endif
+#ifndef DABGPU_RESAMPLER_PIPE
+#define DABGPU_RESAMPLER_PIPE 0   // x4 resampler: the two dual transforms of a hop pipelined against each other (Fft::run2).
+                                  // Measured: 3 % SLOWER than running them one after the other (285 k vs 292 k frames/s for
+                                  // cfg 4) -- a gather queues behind the other seven waves' LDS traffic, so the butterflies
+                                  // that wait for it still start late and every barrier still drains the LDS; kept as a knob
 #endif
 #ifndef DABGPU_ZONLY
 #define DABGPU_ZONLY 1         // Mode I coded-bits chain with FIR: prune the unfiltered transform to the boundary samples
@@ -206,32 +213,31 @@ template <int LOGN> struct Fft {
     // 8-byte elements (cf): padded i + (i >> 3) for strides 1 and 8.  16-byte elements (c2,
     // ds_*_b128): only the stride-1 scatter needs padding, i + (i >> 4); strides 8 and 64 are
     // conflict-free unpadded.
-    template <int NS, bool DBUF, typename V> static DEV void exchange(V *v, V *lds, int t)
+    // the two halves of an exchange: scatter after the stage with stride NS, gather in natural order
+    template <int NS, typename V> static DEV void xwrite(const V *v, V *lds, int t)
     {
         // (the padded read address base + m (T + T/P) needs T to be a multiple of P: tiny transforms go unpadded)
         constexpr int PS = sizeof(V) == 8 ? 3 : DABGPU_C2_PAD_SHIFT, P = 1 << PS;
         constexpr bool PAD = (T % P == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
-        if (PAD) {
-            const int j0 = (t / NS) * NS * 8 + (t % NS);
-            V *wp = lds + (j0 + (j0 >> PS));
+        const int j0 = (t / NS) * NS * 8 + (t % NS);
+        V *wp = lds + (PAD ? j0 + (j0 >> PS) : j0);
 #pragma unroll
-            for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[r * NS + (r * NS) / P] = v[r];
-            xbarrier();
-            const V *rp = lds + (t + (t >> PS));
+        for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[PAD ? r * NS + (r * NS) / P : r * NS] = v[r];
+    }
+    template <int NS, typename V> static DEV void xread(V *v, const V *lds, int t)
+    {
+        constexpr int PS = sizeof(V) == 8 ? 3 : DABGPU_C2_PAD_SHIFT, P = 1 << PS;
+        constexpr bool PAD = (T % P == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
+        const V *rp = lds + (PAD ? t + (t >> PS) : t);
 #pragma unroll
-            for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[m * (T + T / P)];
-            if (!DBUF) xbarrier();
-        } else {
-            const int j0 = (t / NS) * NS * 8 + (t % NS);
-            V *wp = lds + j0;
-#pragma unroll
-            for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[r * NS] = v[r];
-            xbarrier();
-            const V *rp = lds + t;
-#pragma unroll
-            for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[m * T];
-            if (!DBUF) xbarrier();
-        }
+        for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[PAD ? m * (T + T / P) : m * T];
+    }
+    template <int NS, bool DBUF, typename V> static DEV void exchange(V *v, V *lds, int t)
+    {
+        xwrite<NS, V>(v, lds, t);
+        xbarrier();
+        xread<NS, V>(v, lds, t);
+        if (!DBUF) xbarrier();
     }
 
     // SKIP8: the stride-8 stage reads its twiddles from the LDS table (fill_tw8) instead
@@ -423,6 +429,64 @@ template <int LOGN> struct Fft {
         uedge = mk(0.f, 0.f);
         if (wv == 0) uedge = edge(wb[0]);
         else if (wv == 3) uedge = edge(wb[1]);
+    }
+
+    // Two transforms (N a power of 8) software-pipelined against each other: while one transform's exchange is in
+    // flight -- its scatter or gather issued to the LDS -- the other one's butterflies run, so that LDS time and
+    // VALU time overlap inside every wave.  A workgroup that owns its CU alone (the resampler: 512 lanes, one
+    // workgroup per CU) otherwise runs these phases strictly one after the other: every barrier drains both.
+    // Each transform keeps one buffer of its own; every barrier both publishes one transform's scatter and
+    // retires the other one's gather.  The caller separates this from earlier users of the buffers by a barrier.
+    template <int S, typename V>
+    static DEV void run2(V *a, V *b, V *bufa, V *bufb, const cf *tw, int t, const cf *tw8)
+    {
+        static_assert(RF == 1 && NR8 >= 3, "radix-8 stages only");
+        cf w8[7], w[7];
+#pragma unroll
+        for (int r = 0; r < 7; ++r) w8[r] = twid<S>(tw8[r * 8 + (t & 7)]);
+        int n = 7;
+        auto stage = [&](V *v, const cf *ww) __attribute__((always_inline)) {
+#pragma unroll
+            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], ww[r - 1]);
+            dft8<S>(v);
+        };
+        // (the barrier is an asm statement: butterflies, being register-only, could be scheduled across it and
+        // out of the interval they are meant to fill -- tying their results to the statement keeps them in place)
+        auto bar_after = [&](V *v) __attribute__((always_inline)) {
+            asm volatile("" : "+v"(v[0].re.x), "+v"(v[1].re.x), "+v"(v[2].re.x), "+v"(v[3].re.x), "+v"(v[4].re.x),
+                              "+v"(v[5].re.x), "+v"(v[6].re.x), "+v"(v[7].re.x));
+            xbarrier();
+        };
+        dft8<S>(a);
+        xwrite<1, V>(a, bufa, t);
+        dft8<S>(b);
+        bar_after(b);
+        xread<1, V>(a, bufa, t);
+        xwrite<1, V>(b, bufb, t);
+        stage(a, w8);
+        bar_after(a);
+        xwrite<8, V>(a, bufa, t);
+        xread<1, V>(b, bufb, t);
+        stage(b, w8);
+        bar_after(b);
+        xread<8, V>(a, bufa, t);
+        xwrite<8, V>(b, bufb, t);
+        stage_twiddles<S>(tw, n, w);
+        stage(a, w);
+        bar_after(a);
+        if (NR8 > 3) xwrite<64, V>(a, bufa, t);
+        xread<8, V>(b, bufb, t);
+        stage(b, w);
+        if (NR8 > 3) {
+            bar_after(b);
+            xread<64, V>(a, bufa, t);
+            xwrite<64, V>(b, bufb, t);
+            stage_twiddles<S>(tw, n, w);
+            stage(a, w);
+            bar_after(a);
+            xread<64, V>(b, bufb, t);
+            stage(b, w);
+        }
     }
 };
 
@@ -2157,6 +2221,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         }
     }
     if (h0 + 1 < h1) fetch(h0 + 1, xn);
+    lds_barrier();       // the prologue's last gather is complete everywhere (run2 scatters without a barrier first)
 
     // branch twiddle of bin t + T m for branch p (see above); Nyquist bin gets both copies
     auto branch_rot = [](int p, int m) __attribute__((always_inline)) -> cf {
@@ -2183,16 +2248,14 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         const bool more = h + 1 < h1;
 
         cf o[4 * Q];                              // all Q branches of the lane's 4 output samples
-#pragma unroll
-        for (int pass = 0; pass < Q / 2; ++pass) {
-            const int pa = 2 * pass + 1;                       // first item: branch pa
-            const int pb = pa + 1;                             // second item: branch pb, or the forward FFT
-            c2 v2[8];
+        // item a of pass i: branch 2i+1; item b: branch 2i+2, or (last pass) the forward transform of the next hop
+        auto build = [&](auto passc, c2 *v2) __attribute__((always_inline)) {
+            constexpr int pa = 2 * decltype(passc)::value + 1, pb = pa + 1;
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 if (pb < Q) {
                     // two branches: both twiddle products as packed fp32 operations
-                    const float2 wr = make_float2(wp[pa].x, wp[pb].x), wi = make_float2(wp[pa].y, wp[pb].y);
+                    const float2 wr = make_float2(wp[pa].x, wp[pb < Q ? pb : 0].x), wi = make_float2(wp[pa].y, wp[pb < Q ? pb : 0].y);
                     const cf ra = branch_rot(pa, m), rb = branch_rot(pb, m);
                     const float2 rr = make_float2(ra.x, rb.x), ri = make_float2(ra.y, rb.y);
                     const float2 yr = G[m].x * wr - G[m].y * wi, yi = G[m].x * wi + G[m].y * wr;
@@ -2212,12 +2275,14 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
                 }
                 v2[m] = c2{make_float2(xa.x, xb.x), make_float2(xa.y, xb.y)};
             }
-            F::template run<+1, true, c2, 1, 0>(v2, fbuf2, fpar, tw, t, tw8_l);
+        };
+        auto consume = [&](auto passc, const c2 *v2) __attribute__((always_inline)) {
+            constexpr int pa = 2 * decltype(passc)::value + 1, pb = pa + 1;
 #pragma unroll
             for (int m = 0; m < 4; ++m) o[m * Q + pa] = mk(v2[m].re.x, v2[m].im.x);
             if (pb < Q) {
 #pragma unroll
-                for (int m = 0; m < 4; ++m) o[m * Q + pb] = mk(v2[m].re.y, v2[m].im.y);
+                for (int m = 0; m < 4; ++m) o[m * Q + (pb < Q ? pb : 0)] = mk(v2[m].re.y, v2[m].im.y);
             } else {
                 // branch p = 0 needs no transform: IDFT(DFT(u)) = NIN u, i.e. the input samples
                 // under the sum of the two window halves (b0, prepared a hop ahead), plus the
@@ -2235,6 +2300,25 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
                     G[m] = mk(fmaf(sgn, Fc[m].x, fn.x), fmaf(sgn, Fc[m].y, fn.y));
                     Fc[m] = fn;
                 }
+            }
+        };
+        if constexpr (Q == 4 && F::RF == 1 && DABGPU_RESAMPLER_PIPE) {
+            // both dual transforms of the hop, software-pipelined against each other (Fft::run2)
+            c2 va[8], vb[8];
+            build(std::integral_constant<int, 0>{}, va);
+            build(std::integral_constant<int, 1>{}, vb);
+            F::template run2<+1, c2>(va, vb, fbuf2, fbuf2 + F::LDS_ELEMS, tw, t, tw8_l);
+            consume(std::integral_constant<int, 0>{}, va);
+            consume(std::integral_constant<int, 1>{}, vb);
+        } else {
+            c2 v2[8];
+            build(std::integral_constant<int, 0>{}, v2);
+            F::template run<+1, true, c2, 1, 0>(v2, fbuf2, fpar, tw, t, tw8_l);
+            consume(std::integral_constant<int, 0>{}, v2);
+            if constexpr (Q == 4) {
+                build(std::integral_constant<int, 1>{}, v2);
+                F::template run<+1, true, c2, 1, 0>(v2, fbuf2, fpar, tw, t, tw8_l);
+                consume(std::integral_constant<int, 1>{}, v2);
             }
         }
         // the input after next is requested before this hop's stores (vmcnt retires in order) ...
