@@ -747,7 +747,8 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // GVAR (carriers path with GAIN only): the gain mode is known to be "var" -- the statistics come from
 // the spectrum and the time-domain reduction (which keeps both transforms of a symbol live and costs
 // the third workgroup per CU) is compiled out.
-// ZONLY (Mode I coded-bits path with the fused FIR, gain mode fix / var): the unfiltered transform is formed only where
+// ZONLY (Mode I with the fused FIR and no gain statistics over the time domain: the coded-bits path with gain fix / var,
+// the carriers path with gain var or none): the unfiltered transform is formed only where
 // the boundary FIR reads it (Fft::run_dual_zonly).
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
           bool ZONLY = false>
@@ -758,8 +759,9 @@ void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
     static_assert(!CFR || (GUARD == FIR), "CFR variants: the full fused epilogue, or none of it");
-    static_assert(!ZONLY || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT > 0 && !CFR && DABGPU_DUAL_FFT && !DABGPU_FFT_DBUF),
-                  "ZONLY: the dual transform of the Mode I coded-bits chain");
+    static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR && DABGPU_DUAL_FFT && !DABGPU_FFT_DBUF),
+                  "ZONLY: the dual transform of the Mode I chain with the fused FIR");
+    static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
@@ -1349,7 +1351,8 @@ void tf_kernel(const TfArgs a)
                 // Slot tests are wave-uniform, only the lane tests are vector work.
                 const int m_h0 = (N - cpl) / T;
                 if (ZONLY) {
-                    // cpl == cp here (coded-bits path: s >= 1).  Tail = slot 7 of the last C lanes; head = samples
+                    // Tail = slot 7 of the last C lanes.  Head (cpl == cp: the head of symbol 0, whose prefix is
+                    // longer in the carriers path, is read by nobody -- there is no segment before it) = samples
                     // [N - cp, N - cp + C) = slot 6 of lanes [h0, h0 + C), all in the first wave
                     constexpr int h0 = (N - cp) - 6 * T;
                     static_assert(!ZONLY || (h0 >= 0 && h0 + (NT - 1) <= 64 && NT - 1 <= 64), "boundary lanes");
@@ -1449,10 +1452,18 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 #define TF_LAUNCH_GVAR(GD, FR)                                                                 \
     hipLaunchKernelGGL((tf_kernel<LOGN, false, true, GD, FR, (FR ? NT : 0), false, true>), grid, block, lds, s, a)
     if (gvar) {
+        if (LOGN == 11 && NT == 45 && fr && gd && DABGPU_ZONLY) {
+            hipLaunchKernelGGL((tf_kernel<11, false, true, true, true, 45, false, true, true>), grid, block, lds, s, a);
+            return hipGetLastError();
+        }
         if (fr) TF_LAUNCH_GVAR(true, true); else if (gd) TF_LAUNCH_GVAR(true, false); else TF_LAUNCH_GVAR(false, false);
         return hipGetLastError();
     }
 #undef TF_LAUNCH_GVAR
+    if (LOGN == 11 && NT == 45 && !fb && !gn && fr && gd && DABGPU_ZONLY) {
+        hipLaunchKernelGGL((tf_kernel<11, false, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        return hipGetLastError();
+    }
     if (LOGN == 11 && NT == 45 && fb && fr && gd && DABGPU_ZONLY && (!gn || a.gain.mode != 1)) {
         // Mode I, default filter length, gain fix / var (or none): the variant that prunes the unfiltered transform
         if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true>), grid, block, lds, s, a);
