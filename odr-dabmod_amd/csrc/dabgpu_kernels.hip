@@ -28,7 +28,10 @@
 
 // build-time tuning knobs (tools/variants.sh sweeps them)
 #ifndef DABGPU_C2_PAD_SHIFT
-#define DABGPU_C2_PAD_SHIFT 4  // packed (16-byte) exchange elements: one pad slot per 2^shift elements (3 or 4)
+#define DABGPU_C2_PAD_SHIFT 3  // packed (16-byte) exchange elements: one pad slot per 2^shift elements (3 or 4).  ds_write_b128
+                               // is served 8 lanes at a time over a 128-byte bank window: the stride-1 scatter (lane t -> elements
+                               // 8t..8t+7) is conflict-free with one pad per 8 elements (144 t mod 128 = 16 t) and 2-way with one
+                               // per 16 (cfg 3: -2 %; SQ_LDS_BANK_CONFLICT 22 % of the LDS cycles)
 #endif
 #ifndef DABGPU_TF_WAVES
 #define DABGPU_TF_WAVES 3      // __launch_bounds__ waves per SIMD for the FIR variants of tf_kernel (<= 168 VGPRs)
@@ -203,8 +206,8 @@ template <int LOGN> struct Fft {
     // address of a lane at base + compile-time offset, so the 16 accesses of an
     // exchange need 2 address registers instead of 16.
     static constexpr int LDS_ELEMS = N + N / 8;
-    // 16-byte elements are padded one slot per 16 (lane pairs 272 bytes apart: the b128 scatter with
-    // stride 1 and the gathers are both conflict-free), which also makes the packed buffer smaller
+    // size of the packed (16-byte element) buffer with DABGPU_C2_PAD_SHIFT = 4, one pad slot per 16: smaller, but
+    // its stride-1 scatter is 2-way bank-conflicted (see the knob) -- the default pads one per 8 like LDS_ELEMS
     static constexpr int LDS_ELEMS2 = N + N / 16;
 
     // One barrier per exchange: consecutive exchanges alternate between two LDS
@@ -774,7 +777,7 @@ void tf_kernel(const TfArgs a)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
     int fpar = 0;                                                       // which half the next exchange uses
-    // packed dual transforms (FIR variants) exchange 16-byte elements: LDS_ELEMS2 of them with the default padding
+    // packed dual transforms (FIR variants) exchange 16-byte elements (LDS_ELEMS2 of them with DABGPU_C2_PAD_SHIFT = 4)
     constexpr int kXElems = (FIR && DABGPU_DUAL_FFT) ? ((!DBUF && DABGPU_C2_PAD_SHIFT == 4) ? 2 * F::LDS_ELEMS2 : 2 * (DBUF ? 2 : 1) * F::LDS_ELEMS)
                                                       : (DBUF ? 2 : 1) * F::LDS_ELEMS;
     double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
