@@ -33,6 +33,9 @@
                                // 8t..8t+7) is conflict-free with one pad per 8 elements (144 t mod 128 = 16 t) and 2-way with one
                                // per 16 (cfg 3: -2 %; SQ_LDS_BANK_CONFLICT 22 % of the LDS cycles)
 #endif
+#ifndef DABGPU_X1_ROWS
+#define DABGPU_X1_ROWS 1       // first FFT exchange kept one row per butterfly output (see Fft::xwrite)
+#endif
 #ifndef DABGPU_TF_WAVES
 #define DABGPU_TF_WAVES 3      // __launch_bounds__ waves per SIMD for the FIR variants of tf_kernel (<= 168 VGPRs)
 #endif
@@ -216,9 +219,23 @@ template <int LOGN> struct Fft {
     // 8-byte elements (cf): padded i + (i >> 3) for strides 1 and 8.  16-byte elements (c2,
     // ds_*_b128): only the stride-1 scatter needs padding, i + (i >> 4); strides 8 and 64 are
     // conflict-free unpadded.
-    // the two halves of an exchange: scatter after the stage with stride NS, gather in natural order
+    // the two halves of an exchange: scatter after the stage with stride NS, gather in natural order.
+    // First exchange (NS = 1): element (lane t, output r) -- position 8t + r of the autosort order -- is kept at
+    // r (T + 4) + t, one row per output.  The scatter is then contiguous across lanes, and the gather of lane t'
+    // (positions t' + T m, i.e. output t' % 8 of lane t'/8 + (T/8) m) reads (t' % 8)(T + 4) + t'/8 + (T/8) m:
+    // with a row pitch of T + 4 elements the 16 lanes that ds_read_b128 serves together ({0-3, 12-15, 20-27}, ...)
+    // and the 32 lanes of a ds_read_b64 group fall into distinct bank slots (4 (t' % 8) + t'/8 mod 16 resp. mod 32 takes
+    // every value once).  Both sides conflict-free; every address still base + immediate.
+    static constexpr int X1_PITCH = T + 4;
+    static constexpr bool X1_ROWS = DABGPU_X1_ROWS && T >= 32;      // (8 (T + 4) elements must fit in LDS_ELEMS)
     template <int NS, typename V> static DEV void xwrite(const V *v, V *lds, int t)
     {
+        if (NS == 1 && X1_ROWS) {
+            V *wp = lds + t;
+#pragma unroll
+            for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[r * X1_PITCH] = v[r];
+            return;
+        }
         // (the padded read address base + m (T + T/P) needs T to be a multiple of P: tiny transforms go unpadded)
         constexpr int PS = sizeof(V) == 8 ? 3 : DABGPU_C2_PAD_SHIFT, P = 1 << PS;
         constexpr bool PAD = (T % P == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
@@ -229,6 +246,12 @@ template <int LOGN> struct Fft {
     }
     template <int NS, typename V> static DEV void xread(V *v, const V *lds, int t)
     {
+        if (NS == 1 && X1_ROWS) {
+            const V *rp = lds + ((t & 7) * X1_PITCH + (t >> 3));
+#pragma unroll
+            for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[m * (T / 8)];
+            return;
+        }
         constexpr int PS = sizeof(V) == 8 ? 3 : DABGPU_C2_PAD_SHIFT, P = 1 << PS;
         constexpr bool PAD = (T % P == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
         const V *rp = lds + (PAD ? t + (t >> PS) : t);
