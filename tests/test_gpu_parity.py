@@ -715,6 +715,39 @@ def test_symbols_entry_point_matches_bits_entry_point(pkg):
         md.close()
 
 
+@pytest.mark.parametrize("with_gain", [True, False])
+def test_symbols_entry_with_fir_and_energy_in_the_null_symbol(pkg, with_gain):
+    """IFFT+FIR stage from the SignalMultiplexer output with a non-blank first symbol (a TII-like pattern):
+    the null segment's longer prefix and its tail go through the fused epilogue like any other symbol's."""
+    import torch
+    md = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        g = md.geometry
+        K, N, nsym = g["carriers"], g["spacing"], g["nb_symbols"] + 1
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        rs = np.random.RandomState(77)
+        car = np.exp(1j * (np.pi / 4) * (2 * rs.randint(0, 4, (2, nsym * K)) + 1)).astype(np.complex64)
+        null = np.zeros((2, K), np.complex64)
+        null[:, ::7] = car[:, :K:7]                      # sparse energy in symbol 0
+        car[:, :K] = null
+        stages = (pkg.STAGE_GAIN if with_gain else 0) | pkg.STAGE_FIR
+        out = torch.empty((2, md.out_samples_per_frame(stages)), dtype=torch.complex64, device="cuda")
+        md.symbols_dev(torch.from_numpy(car).cuda(), 2, stages, out)
+        y = out.cpu().numpy()
+        taps = O.fir_default_taps()
+        for f in range(2):
+            x = O.ofdm_generate(car[f], nsym, K, N)
+            if with_gain:
+                x = O.gain_control(x, N, 2, 1.0, 1.0 / 50000.0, 4.0)
+            x = O.guard_interval(x, nsym - 1, N, g["null_size"], g["sym_size"])
+            ref = O.fir_filter(x, taps)
+            assert rel_rms(y[f], ref) < REL_RMS, (f, rel_rms(y[f], ref))
+            nz = g["null_size"]
+            assert rel_rms(y[f][:nz], ref[:nz]) < 2 * REL_RMS           # the null segment on its own
+    finally:
+        md.close()
+
+
 def test_setters_from_another_thread_take_effect_between_frames(pkg):
     """The remote-control contract: setters may come from any thread at any time; every
     processed frame sees ONE consistent snapshot of the settings (here: digital gain 1.0 or 0.5, taps
