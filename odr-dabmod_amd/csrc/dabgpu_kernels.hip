@@ -430,7 +430,8 @@ template <int LOGN> struct Fft {
         xbarrier();
 #pragma unroll
         for (int m = 0; m < 8; ++m) z[m] = zl[t + T * m];
-        const int wv = t >> 6;                     // wave-uniform
+        const int wv = __builtin_amdgcn_readfirstlane(t >> 6);     // wave index, as a scalar: the branches below are
+                                                                   // then scalar branches, not exec-masked copies
         cf e[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
         if (wv == 0 || wv == 3) {
             const cf *up = (wv == 0) ? u0 + t : u7 + (t - 192);
