@@ -171,6 +171,35 @@ template <int S, typename V> DEV void dft4(V &x0, V &x1, V &x2, V &x3)
     x3 = csub(s1, s3);
 }
 
+// The odd half of an 8-point DFT: b1 and b3 are due a rotation by exp(S i pi/4) resp. exp(S 3 i pi/4), i.e. a
+// rotation by +-45 degrees without its factor sqrt(1/2) and then that factor.  The factor moves into the last layer
+// of the 4-point DFT, where it is the multiplier of an FMA: the four multiplications of rot1 / rot3 disappear.
+#ifndef DABGPU_FOLD_ROT
+#define DABGPU_FOLD_ROT 1
+#endif
+DEV cf axpy(cf a, float c, cf b) { return mk(fmaf(c, b.x, a.x), fmaf(c, b.y, a.y)); }          // a + c b
+DEV c2 axpy(c2 a, float c, c2 b) { return c2{a.re + c * b.re, a.im + c * b.im}; }
+template <int S> DEV cf urot1(cf b) { return mk(b.x - S * b.y, S * b.x + b.y); }                // sqrt(2) exp(S i pi/4) b
+template <int S> DEV cf urot3(cf b) { return mk(-b.x - S * b.y, S * b.x - b.y); }               // sqrt(2) exp(S 3 i pi/4) b
+template <int S> DEV c2 urot1(c2 b) { return c2{b.re - (float)S * b.im, (float)S * b.re + b.im}; }
+template <int S> DEV c2 urot3(c2 b) { return c2{-b.re - (float)S * b.im, (float)S * b.re - b.im}; }
+template <int S, typename V> DEV void dft8_odd(V &b0, V &b1, V &b2, V &b3)
+{
+    if (!DABGPU_FOLD_ROT) {
+        b1 = rot1<S>(b1);
+        b2 = mul_i<S>(b2);
+        b3 = rot3<S>(b3);
+        dft4<S>(b0, b1, b2, b3);
+        return;
+    }
+    const V p1 = urot1<S>(b1), p2 = mul_i<S>(b2), p3 = urot3<S>(b3);
+    const V s0 = cadd(b0, p2), s1 = csub(b0, p2), s2 = cadd(p1, p3), s3 = mul_i<S>(csub(p1, p3));
+    b0 = axpy(s0, kSqrtHalf, s2);
+    b2 = axpy(s0, -kSqrtHalf, s2);
+    b1 = axpy(s1, kSqrtHalf, s3);
+    b3 = axpy(s1, -kSqrtHalf, s3);
+}
+
 // 8-point DFT (decimation in frequency), natural order in place
 template <int S, typename V> DEV void dft8(V *v)
 {
@@ -178,13 +207,58 @@ template <int S, typename V> DEV void dft8(V *v)
     V a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
     V a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
     V a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
-    b1 = rot1<S>(b1);
-    b2 = mul_i<S>(b2);
-    b3 = rot3<S>(b3);
     dft4<S>(a0, a1, a2, a3);
-    dft4<S>(b0, b1, b2, b3);
+    dft8_odd<S>(b0, b1, b2, b3);
     v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
     v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+}
+
+// Twiddles W^1..W^7 on v[1..7], then the 8-point DFT.  Packed pairs: the products of the upper four inputs are folded
+// into the first butterfly layer -- a_i = u_i + v_{i+4} w (four packed FMAs, the same count as the product alone) and
+// b_i = 2 u_i - a_i (two) instead of product, sum and difference: 8 packed instructions fewer per stage.
+#ifndef DABGPU_FOLD_TWIDDLES
+#define DABGPU_FOLD_TWIDDLES 1
+#endif
+#if DABGPU_PK_OPSEL
+DEV c2 cfma(c2 t, c2 x, cf w)          // t + x * w
+{
+    const v2f tre = {t.re.x, t.re.y}, tim = {t.im.x, t.im.y}, xre = {x.re.x, x.re.y}, xim = {x.im.x, x.im.y}, ww = {w.x, w.y};
+    v2f r0, re, i0, im;
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r0) : "v"(xre), "v"(ww), "v"(tre));      // t.re + x.re w.x
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
+        : "=v"(re) : "v"(xim), "v"(ww), "v"(r0));                                                                        // - x.im w.y
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(i0) : "v"(xre), "v"(ww), "v"(tim));      // t.im + x.re w.y
+    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(im) : "v"(xim), "v"(ww), "v"(i0));       // + x.im w.x
+    return c2{make_float2(re.x, re.y), make_float2(im.x, im.y)};
+}
+#else
+DEV c2 cfma(c2 t, c2 x, cf w) { return cadd(t, cmul(x, w)); }
+#endif
+template <int S> DEV void twiddle_dft8(cf *v, const cf *w)
+{
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+    dft8<S>(v);
+}
+template <int S> DEV void twiddle_dft8(c2 *v, const cf *w)
+{
+    if (!DABGPU_FOLD_TWIDDLES) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+        dft8<S>(v);
+        return;
+    }
+    c2 a[4], b[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const c2 u = i == 0 ? v[0] : cmul(v[i], w[i - 1]);
+        a[i] = cfma(u, v[i + 4], w[i + 3]);
+        b[i] = c2{u.re * 2.0f - a[i].re, u.im * 2.0f - a[i].im};
+    }
+    dft4<S>(a[0], a[1], a[2], a[3]);
+    dft8_odd<S>(b[0], b[1], b[2], b[3]);
+    v[0] = a[0]; v[2] = a[1]; v[4] = a[2]; v[6] = a[3];
+    v[1] = b[0]; v[3] = b[1]; v[5] = b[2]; v[7] = b[3];
 }
 
 // ---------------------------------------------------------------------------
@@ -343,9 +417,7 @@ template <int LOGN> struct Fft {
             } else {
                 stage_twiddles<S>(tw, n, w);
             }
-#pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
-            dft8<S>(v);
+            twiddle_dft8<S>(v, w);
             if (NR8 > 2 || RF > 1) exchange<8, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 3) {
@@ -356,16 +428,12 @@ template <int LOGN> struct Fft {
             } else {
                 stage_twiddles<S>(tw, n, w);
             }
-#pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
-            dft8<S>(v);
+            twiddle_dft8<S>(v, w);
             if (NR8 > 3 || RF > 1) exchange<64, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (NR8 >= 4) {
             stage_twiddles<S>(tw, n, w);
-#pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
-            dft8<S>(v);
+            twiddle_dft8<S>(v, w);
             if (RF > 1) exchange<512, DBUF, V>(v, DABGPU_NEXT_BUF, t);
         }
         if (RF == 4) {
@@ -411,32 +479,56 @@ template <int LOGN> struct Fft {
         dft8<S>(v);
         exchange<1, false, c2>(v, lds, t);
         if (U8 == 1) n += 7; else stage_twiddles<S>(tw, n, w);
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
-        dft8<S>(v);
+        twiddle_dft8<S>(v, w);
         exchange<8, false, c2>(v, lds, t);
         stage_twiddles<S>(tw, n, w);
-#pragma unroll
-        for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
-        dft8<S>(v);
-        // third exchange: second half as cf, first half's outputs 0 and 7 beside it
-        cf *zl = reinterpret_cast<cf *>(lds);      // N elements
-        cf *u0 = zl + N, *u7 = u0 + T;             // [wave][lane]
-        cf *wp = zl + ((t / 64) * 512 + (t % 64));
-#pragma unroll
-        for (int r = 0; r < 8; ++r) wp[64 * r] = mk(v[r].re.y, v[r].im.y);
-        u0[t] = mk(v[0].re.x, v[0].im.x);
-        u7[t] = mk(v[7].re.x, v[7].im.x);
+        twiddle_dft8<S>(v, w);
+        // third exchange: second half alone, first half's outputs 0 and 7 beside it.  Real and imaginary parts go to
+        // separate planes (N floats each, 32 x 256 bytes apart) with ds_write2st64_b32 / ds_read2st64_b32: those take their
+        // two dwords from / deliver them to ANY two registers, so the halves of the (unfiltered, filtered) register pairs
+        // need no moves into (re, im) order on the way out, and arrive as (re, im) pairs on the way back.  Written by
+        // hand: the backend's own pairing is switched off (Makefile), and it would not pair across planes anyway.
+        float *zre = reinterpret_cast<float *>(lds);                 // [N] re, [N] im
+        float *ure = zre + 2 * N;                                    // [T] u0.re, [T] u0.im, [T] u7.re, [T] u7.im
+        {
+            const unsigned waddr = (unsigned)(uintptr_t)(zre + ((t / 64) * 512 + (t % 64)));    // LDS byte address
+            const unsigned uaddr = (unsigned)(uintptr_t)(ure + t);
+#define DABGPU_ZW(R)                                                                                          \
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:%3 offset1:%4"                                  \
+                         :: "v"(waddr), "v"(v[R].re.y), "v"(v[R].im.y), "n"(R), "n"(32 + R) : "memory")
+            DABGPU_ZW(0); DABGPU_ZW(1); DABGPU_ZW(2); DABGPU_ZW(3); DABGPU_ZW(4); DABGPU_ZW(5); DABGPU_ZW(6); DABGPU_ZW(7);
+#undef DABGPU_ZW
+            static_assert(T == 256, "plane offsets below are in units of 64 dwords");
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:0 offset1:4" :: "v"(uaddr), "v"(v[0].re.x), "v"(v[0].im.x) : "memory");
+            asm volatile("ds_write2st64_b32 %0, %1, %2 offset0:8 offset1:12" :: "v"(uaddr), "v"(v[7].re.x), "v"(v[7].im.x) : "memory");
+        }
         xbarrier();
-#pragma unroll
-        for (int m = 0; m < 8; ++m) z[m] = zl[t + T * m];
         const int wv = __builtin_amdgcn_readfirstlane(t >> 6);     // wave index, as a scalar: the branches below are
                                                                    // then scalar branches, not exec-masked copies
         cf e[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
         if (wv == 0 || wv == 3) {
-            const cf *up = (wv == 0) ? u0 + t : u7 + (t - 192);
+            const float *up = (wv == 0) ? ure + t : ure + 2 * T + (t - 192);
 #pragma unroll
-            for (int q = 0; q < 4; ++q) e[q] = up[64 * q];
+            for (int q = 0; q < 4; ++q) e[q] = mk(up[64 * q], up[T + 64 * q]);
+        }
+        {
+            const unsigned raddr = (unsigned)(uintptr_t)(zre + t);
+            v2f zz[8];
+            // (the wait is part of the statement: the compiler does not count LDS operations issued from asm)
+            asm volatile("ds_read2st64_b32 %0, %8 offset0:0 offset1:32\n\t"
+                         "ds_read2st64_b32 %1, %8 offset0:4 offset1:36\n\t"
+                         "ds_read2st64_b32 %2, %8 offset0:8 offset1:40\n\t"
+                         "ds_read2st64_b32 %3, %8 offset0:12 offset1:44\n\t"
+                         "ds_read2st64_b32 %4, %8 offset0:16 offset1:48\n\t"
+                         "ds_read2st64_b32 %5, %8 offset0:20 offset1:52\n\t"
+                         "ds_read2st64_b32 %6, %8 offset0:24 offset1:56\n\t"
+                         "ds_read2st64_b32 %7, %8 offset0:28 offset1:60\n\t"
+                         "s_waitcnt lgkmcnt(0)"
+                         : "=&v"(zz[0]), "=&v"(zz[1]), "=&v"(zz[2]), "=&v"(zz[3]), "=&v"(zz[4]), "=&v"(zz[5]), "=&v"(zz[6]),
+                           "=&v"(zz[7])
+                         : "v"(raddr) : "memory");
+#pragma unroll
+            for (int m = 0; m < 8; ++m) z[m] = mk(zz[m].x, zz[m].y);
         }
         xbarrier();
         cf wb[2][3];
@@ -473,9 +565,7 @@ template <int LOGN> struct Fft {
         for (int r = 0; r < 7; ++r) w8[r] = twid<S>(tw8[r * 8 + (t & 7)]);
         int n = 7;
         auto stage = [&](V *v, const cf *ww) __attribute__((always_inline)) {
-#pragma unroll
-            for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], ww[r - 1]);
-            dft8<S>(v);
+            twiddle_dft8<S>(v, ww);
         };
         // (the barrier is an asm statement: butterflies, being register-only, could be scheduled across it and
         // out of the interval they are meant to fill -- tying their results to the statement keeps them in place)
