@@ -505,8 +505,9 @@ template <int LOGN> struct Fft {
         xbarrier();
         const int wv = __builtin_amdgcn_readfirstlane(t >> 6);     // wave index, as a scalar: the branches below are
                                                                    // then scalar branches, not exec-masked copies
-        cf e[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
-        if (wv == 0 || wv == 3) {
+        const bool edge_wave = wv == 0 || wv == 3;
+        cf e[4];                                                   // (read only where edge_wave)
+        if (edge_wave) {
             const float *up = (wv == 0) ? ure + t : ure + 2 * T + (t - 192);
 #pragma unroll
             for (int q = 0; q < 4; ++q) e[q] = mk(up[64 * q], up[T + 64 * q]);
@@ -540,14 +541,19 @@ template <int LOGN> struct Fft {
             dft4<S>(x0, x1, x2, x3);
             z[b] = x0; z[b + 2] = x1; z[b + 4] = x2; z[b + 6] = x3;
         }
-        // output 3 of the butterfly: (x0 - x2) - S i (x1 - x3), twiddles of butterfly 0 (first wave) or 1 (last wave)
-        auto edge = [&](const cf *wq) __attribute__((always_inline)) -> cf {
-            const cf y1 = cmul(e[1], wq[0]), y2 = cmul(e[2], wq[1]), y3 = cmul(e[3], wq[2]);
-            return csub(csub(e[0], y2), mul_i<S>(csub(y1, y3)));
-        };
+        // output 3 of the butterfly: (x0 - x2) - S i (x1 - x3).  The last wave needs the twiddles of butterfly 1,
+        // W^{r (t + T)} = W^{r t} exp(S i r pi/4): butterfly 0's, and three fixed rotations on the products -- selecting
+        // between two twiddle sets would cost every wave a dozen register copies
         uedge = mk(0.f, 0.f);
-        if (wv == 0) uedge = edge(wb[0]);
-        else if (wv == 3) uedge = edge(wb[1]);
+        if (edge_wave) {
+            cf y1 = cmul(e[1], wb[0][0]), y2 = cmul(e[2], wb[0][1]), y3 = cmul(e[3], wb[0][2]);
+            if (wv == 3) {
+                y1 = rot1<S>(y1);
+                y2 = mul_i<S>(y2);
+                y3 = rot3<S>(y3);
+            }
+            uedge = csub(csub(e[0], y2), mul_i<S>(csub(y1, y3)));
+        }
     }
 
     // Two transforms (N a power of 8) software-pipelined against each other: while one transform's exchange is in
