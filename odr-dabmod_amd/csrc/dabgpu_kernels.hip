@@ -213,6 +213,19 @@ template <int S, typename V> DEV void dft8(V *v)
     v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
 }
 
+// The same with v[4] known to be zero (first stage of the frame kernel: bin t + 4T lies in the unoccupied band)
+template <int S, typename V> DEV void dft8_v4zero(V *v)
+{
+    V a0 = v[0], b0 = v[0];
+    V a1 = cadd(v[1], v[5]), b1 = csub(v[1], v[5]);
+    V a2 = cadd(v[2], v[6]), b2 = csub(v[2], v[6]);
+    V a3 = cadd(v[3], v[7]), b3 = csub(v[3], v[7]);
+    dft4<S>(a0, a1, a2, a3);
+    dft8_odd<S>(b0, b1, b2, b3);
+    v[0] = a0; v[2] = a1; v[4] = a2; v[6] = a3;
+    v[1] = b0; v[3] = b1; v[5] = b2; v[7] = b3;
+}
+
 // Twiddles W^1..W^7 on v[1..7], then the 8-point DFT.  Packed pairs: the products of the upper four inputs are folded
 // into the first butterfly layer -- a_i = u_i + v_{i+4} w (four packed FMAs, the same count as the product alone) and
 // b_i = 2 u_i - a_i (two) instead of product, sum and difference: 8 packed instructions fewer per stage.
@@ -476,7 +489,7 @@ template <int LOGN> struct Fft {
 #pragma unroll
             for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw8[r * 8 + (t & 7)]);
         }
-        dft8<S>(v);
+        dft8_v4zero<S>(v);            // (every caller is the frame kernel: input 4 is in the empty band)
         exchange<1, false, c2>(v, lds, t);
         if (U8 == 1) n += 7; else stage_twiddles<S>(tw, n, w);
         twiddle_dft8<S>(v, w);
@@ -1047,9 +1060,10 @@ void tf_kernel(const TfArgs a)
         }
     };
     // scatter them into the first-stage register layout
-    auto place = [&](const cf *val, cf *v) __attribute__((always_inline)) {
-        v[0] = r0 == 0 ? val[0] : mk(0.f, 0.f);
-        v[3] = r0 == 0 ? mk(0.f, 0.f) : val[0];
+    const float m_r0 = r0 == 0 ? 1.0f : 0.0f, m_r3 = 1.0f - m_r0;       // (two multiplies are two packed instructions
+    auto place = [&](const cf *val, cf *v) __attribute__((always_inline)) {   //  per pair; two selects are four)
+        v[0] = cscale(val[0], m_r0);
+        v[3] = cscale(val[0], m_r3);
         v[4] = mk(0.f, 0.f);
         v[1] = val[1]; v[2] = val[2]; v[5] = val[3]; v[6] = val[4]; v[7] = val[5];
     };
