@@ -933,8 +933,7 @@ void tf_kernel(const TfArgs a)
     // exp(i p pi/4) with exact 0 / +-1 entries, in 8 rotated copies: entry [rot * 8 + p] = exp(i (p + rot) pi/4).
     // The coded-bits path keeps its differential phases without the common "+1 eighth per symbol" term and
     // unreduced (see advance); the rotation is the symbol's share, picked through the table's base address.
-    // (64-byte aligned: load_active ORs the entry offset into the table's address)
-    cf *unit8 = reinterpret_cast<cf *>((reinterpret_cast<uintptr_t>(mag_l + 160) + 63) & ~(uintptr_t)63);
+    cf *unit8 = reinterpret_cast<cf *>(mag_l + 160);
     cf *tw8_l = unit8 + 64;                             // DABGPU_TW8_LDS: 7 x 8 twiddles
     if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
     cf *tw64_l = tw8_l + 56;                            // DABGPU_TW64_LDS: 7 x 64 twiddles (FIR variants)
@@ -1045,12 +1044,7 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const unsigned rot64 = ((unsigned)(s - 1) & 7u) << 6;        // (byte offset of the rotated copy)
-                // (one v_and_or_b32; left to itself the compiler turns the OR of disjoint bits into an add and needs two)
-                // and reads through the raw LDS address, table base folded into the scalar operand)
-                unsigned off;
-                asm("v_and_or_b32 %0, %1, 0x38, %2" : "=v"(off) : "v"(phase[c]), "s"(rot64 + (unsigned)(uintptr_t)unit8));
-                const unsigned long long uu = *reinterpret_cast<const __attribute__((address_space(3))) unsigned long long *>((uintptr_t)off);
-                const cf u = mk(__uint_as_float((unsigned)uu), __uint_as_float((unsigned)(uu >> 32)));
+                const cf u = *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) + ((phase[c] & 0x38u) | rot64));
                 val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
             }
         } else {
@@ -1638,7 +1632,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
     if (flags & TF_FIR) b += 4 * (nt ? nt - 1 : DABGPU_KBND) * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
-    b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2) + 64;  // taps, |y_s| table, unit vectors (8 rotations, 64-byte aligned)
+    b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
 #if DABGPU_TW8_LDS
     b += 56 * sizeof(float2);
 #endif
