@@ -202,15 +202,17 @@ def main():
     algo = ALGO_BYTES[args.workload]
     achieved = algo * B / (kern_ms * 1e-3) / 1e9  # GB/s per GPU, per-launch HIP-event time
 
-    traffic = None
+    traffic, busy = None, {}
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
             t = json.load(open(tp)).get(args.workload)
             if t and t.get("frames") == B:
                 traffic = t.get("hbm_bytes_per_launch")
+                # the kernel is VALU / LDS bound, not HBM bound: utilisation of both from the same rocprofv3 counter runs
+                busy = {k: t[k] for k in ("valu_busy", "lds_busy") if k in t}
         except Exception:
-            traffic = None
+            traffic, busy = None, {}
 
     line = {
         "metric": "Mode-I TX frames/sec (196608 IQ/frame)",
@@ -237,7 +239,7 @@ def main():
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "kernel": "tf_kernel" if args.workload != "cfg4" else "tf_kernel+resampler_kernel",
-                     "algorithmic_bytes_per_frame": algo, "kernel_ms_per_launch": round(kern_ms, 4)},
+                     "algorithmic_bytes_per_frame": algo, "kernel_ms_per_launch": round(kern_ms, 4), **busy},
     }
 
     if rank == 0 and world == 1:

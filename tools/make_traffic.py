@@ -15,5 +15,16 @@ d["_about"] = ("HBM bytes per launch from rocprofv3 PMC passes (tools/profile_be
                "(FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, MI355X_MICROARCH.md 'HBM')")
 d[workload] = {"frames": frames, "hbm_bytes_per_launch": int(w * 1024 + 2 * f * 1024), "write_size_kb": w,
                "fetch_size_kb": f, "algorithmic_bytes_per_launch": algo * frames}
+# compute-side utilisation in the same (counter-collecting) runs: the kernel is not HBM bound, SURVEY 8(d) asks for
+# the VALU figure beside the HBM one.  GRBM_GUI_ACTIVE sums the 8 XCDs; a wave64 VALU instruction holds its SIMD for
+# 4 cycles (1024 SIMDs); SQ_LDS_IDX_ACTIVE sums the LDS-array cycles of the 256 CUs.
+def cnt(name):
+    m = re.search(name + r"\s+([0-9.e+]+)", txt)
+    return float(m.group(1)) if m else None
+gui, valu, lds = cnt("GRBM_GUI_ACTIVE"), cnt("SQ_INSTS_VALU"), cnt("SQ_LDS_IDX_ACTIVE")
+if gui and valu and lds:
+    cyc = gui / 8
+    d[workload].update({"valu_busy": round(valu * 4 / (1024 * cyc), 3), "lds_busy": round(lds / (256 * cyc), 3),
+                        "valu_insts_per_launch": valu, "gpu_cycles_per_launch_profiled": cyc})
 json.dump(d, open(path, "w"), indent=1)
 print(d[workload])
