@@ -7,3 +7,5 @@ mkdir -p /tmp/isa && cd /tmp/isa
 S=${KERNEL:-_ZN6dabgpu12_GLOBAL__N_19tf_kernelILi11ELb1ELb1ELb1ELb1ELi45ELb0ELb0EEEvNS_6TfArgsE}
 awk -v s="$S:" '$1==s{p=1} p{print} p&&/s_endpgm/{exit}' kernels.s > cfg3.s
 grep -A10 "Function Name: $S" remarks.log | grep -E "VGPRs:|AGPRs|Scratch|Occupancy|LDS" | sed 's/.*remark: //; s/\[-R.*//'
+# (pointers that lose their LDS address space turn into FLAT accesses; spills into scratch_: neither belongs in these kernels)
+echo "flat_ instructions in the file: $(grep -c '^\s*flat_' kernels.s), scratch_: $(grep -c '^\s*scratch_' kernels.s)"
