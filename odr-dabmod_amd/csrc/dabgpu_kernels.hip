@@ -989,16 +989,22 @@ void tf_kernel(const TfArgs a)
         for (int m = 0; m < 8; ++m) hk8[m] = a.t.fir_h[tt + T * m];
     }
     int bitpos[6];
-    // differential state of the lane's carriers in units of 1/64 turn (8 per eighth), not reduced, and without the
-    // "+1 eighth" every data block adds to every carrier: phase of symbol s = (phase[c] / 8 + s - 1) mod 8
-    unsigned phase[6];
+    // differential state of the lane's carriers, without the
+    // "+1 eighth" every data block adds to every carrier: phase of symbol s = 2 q_c + s - 1 eighths.
+    // Kept as six 4-bit fields of ONE register, in quarter turns (every increment is an even number of eighths): the
+    // block update and the pair sums of the gain statistic work on all fields at once.  Field of carrier c at bit
+    // fpos[c]: the positive carriers 0, 1, 2 at bits 0, 4, 8; the negative ones so that bits 12.. read (-k0, -k1, -k2)
+    // in the lane that holds them -- carriers (5, 4, 3) at bits (12, 16, 20), lane 0 (which pairs with itself and has
+    // bin 3T in slot 0): carriers (3, 5, 4).
+    unsigned P = 0u;
+    unsigned fpos[6] = {0u, 4u, 8u, tt == 0 ? 12u : 20u, tt == 0 ? 20u : 16u, tt == 0 ? 16u : 12u};
     const uint8_t *fbits = nullptr;
     if (FROM_BITS) {
         fbits = a.bits + (size_t)frame * (size_t)(G::nb_symbols - 1) * (size_t)(K / 4);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             bitpos[c] = a.t.src_carrier[kpos[c]];
-            phase[c] = 16u * a.t.phase_q[kpos[c]];
+            P |= ((unsigned)a.t.phase_q[kpos[c]] & 3u) << fpos[c];
         }
     }
     const cf *fcar = FROM_BITS ? nullptr
@@ -1018,13 +1024,15 @@ void tf_kernel(const TfArgs a)
             qb[c] = blk[(K >> 3) + (bitpos[c] >> 3)];
 #endif
         }
+        unsigned I = 0u, Q = 0u;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             const unsigned sh = 7u - ((unsigned)bitpos[c] & 7u);
-            const unsigned i1 = __builtin_amdgcn_ubfe(ib[c], sh, 1u), q1 = __builtin_amdgcn_ubfe(qb[c], sh, 1u);
-            const unsigned gcode = (i1 ^ q1) | (q1 << 1);  // 00->0 10->1 11->2 01->3 quarter turns
-            phase[c] += gcode << 4;
+            I |= __builtin_amdgcn_ubfe(ib[c], sh, 1u) << fpos[c];
+            Q |= __builtin_amdgcn_ubfe(qb[c], sh, 1u) << fpos[c];
         }
+        // (I, Q) = 00 -> 0, 10 -> 1, 11 -> 2, 01 -> 3 quarter turns, in every field at once; the guard bits absorb the carry
+        P = (P + ((I ^ Q) | (Q << 1))) & 0x333333u;
     };
     // global -> register half of the staging of block d: lanes 0 .. K/16-1 fetch one dword
     // each.  Kept free of divergent control flow on purpose (the other lanes re-read word 0
@@ -1044,7 +1052,8 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
             for (int c = 0; c < 6; ++c) {
                 const unsigned rot64 = ((unsigned)(s - 1) & 7u) << 6;        // (byte offset of the rotated copy)
-                const cf u = *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) + ((phase[c] & 0x38u) | rot64));
+                const cf u = *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) +
+                                                          ((__builtin_amdgcn_ubfe(P, fpos[c], 2u) << 4) | rot64));
                 val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
             }
         } else {
@@ -1345,27 +1354,22 @@ void tf_kernel(const TfArgs a)
                 //   S = sum over carrier pairs {k, -k} of cos(pi/4 (p_k + p_-k)),
                 // because sum_n x[n]^2 = N sum_k X[k] X[-k].  Carrier -k of the lane's three positive
                 // carriers lives in lane T - t (lane 0 pairs with itself): exchange one packed word.
-                // (three 3-bit fields; the middle one stays where it is in the phase word)
-                auto pack3 = [](unsigned f0, unsigned f1, unsigned f2) __attribute__((always_inline)) -> unsigned {
-                    return __builtin_amdgcn_ubfe(f0, 3u, 3u) | (f1 & 0x38u) | ((f2 << 3) & 0x1C0u);
-                };
-                const unsigned w = (tt == 0) ? pack3(phase[3], phase[5], phase[4]) : pack3(phase[5], phase[4], phase[3]);
-                phw[tt] = w;
+                phw[tt] = P >> 12;                           // fields (-k0, -k1, -k2) of this lane
                 lds_barrier();
                 const unsigned o = phw[(T - tt) & (T - 1)];
                 // Every carrier of a symbol has the same phase parity (each block adds an odd number of eighths
                 // to all of them), so a pair's phase sum is an even number of eighths and its cosine is +1, 0 or -1:
-                // S = #(sum = 0 mod 8) - #(sum = 4 mod 8).  Counted per wave with ballots -- the additions run on
-                // the scalar unit.  Both phases of a pair carry the symbol's rotation: 2 (s - 1) eighths.
-                const unsigned rot8 = ((unsigned)(2 * (s - 1)) & 7u) << 3;
-                const unsigned c0 = (0u - rot8) & 0x38u, c4 = (0x20u - rot8) & 0x38u;
-                const unsigned fs[3] = {(phase[0] + (o << 3)) & 0x38u, (phase[1] + o) & 0x38u, (phase[2] + (o >> 3)) & 0x38u};
+                // S = #(sum = 0 mod 4 quarter turns) - #(sum = 2 mod 4).  Both phases of a pair carry the symbol's
+                // rotation, s - 1 quarter turns in all.  The three sums in one addition (fields cannot carry into each
+                // other: 3 + 3 + 3 < 16); counted per wave with ballots -- the additions run on the scalar unit.
+                const unsigned sums = P + o + (((unsigned)(s - 1) & 3u) * 0x111u);
                 int cnt = 0;
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
+                    const unsigned f = sums & (3u << (4 * j));
                     // (v_cmp_eq_u32 straight into an SGPR pair: 32 = ICMP_EQ)
-                    cnt += __builtin_popcountll(__builtin_amdgcn_uicmp(fs[j], c0, 32) & on_mask);
-                    cnt -= __builtin_popcountll(__builtin_amdgcn_uicmp(fs[j], c4, 32) & on_mask);
+                    cnt += __builtin_popcountll(__builtin_amdgcn_uicmp(f, 0u, 32) & on_mask);
+                    cnt -= __builtin_popcountll(__builtin_amdgcn_uicmp(f, 2u << (4 * j), 32) & on_mask);
                 }
                 const float part = (float)cnt;
                 float *redf = reinterpret_cast<float *>(red + 8 * (s & 1));
@@ -1436,7 +1440,7 @@ void tf_kernel(const TfArgs a)
                 // |X| of the symbol: the table holds the COMPONENT magnitude; diagonal states
                 // (odd phase, the same parity on every carrier) have modulus sqrt(2) times that
                 const float mg = mag_l[s - 1];                               // the loop never sees s = 0 here
-                const float m2 = mg * mg * (float)(1u + (((phase[0] >> 3) + (unsigned)(s - 1)) & 1u));
+                const float m2 = mg * mg * (float)(1u + ((unsigned)(s - 1) & 1u));   // (the carriers' own parts are even)
                 const float vr = fast_sqrt(m2 * fmaxf((float)(K / 2) + S, 0.f)) * a.gain.var_variance;
                 const float vi = fast_sqrt(m2 * fmaxf((float)(K / 2) - S, 0.f)) * a.gain.var_variance;
                 g = ((int)vr == 0) ? 1.0f : 32767.0f * fast_rcp(fmaxf(vr, vi));
