@@ -691,6 +691,57 @@ def test_device_path_batch_is_frame_independent_and_matches_host_path(pkg):
         md1.close()
 
 
+def _dab_demodulate_mode1(y, early=0):
+    """Receiver for one Mode-I frame of the guard-interval output: strip the cyclic prefix (FFT window `early` samples
+    before the end of the symbol: any window inside the cyclic extension only rotates all symbols alike), FFT, undo the
+    differential modulation, the frequency interleaver (ETSI EN 300 401 14.6: pi(j) = 13 pi(j-1) + 511 mod 2048) and the
+    QPSK mapping -> the 28 800 coded bytes.  Written from the standard, independent of the oracle."""
+    N, K, nsym, null, sym = 2048, 1536, 76, 2656, 2552
+    z = np.empty((nsym, K), np.complex128)
+    for s in range(nsym):
+        seg = y[null + s * sym: null + (s + 1) * sym]
+        X = np.fft.fft(seg[sym - N - early: sym - early].astype(np.complex128))
+        z[s, :K // 2] = X[1:K // 2 + 1]
+        z[s, K // 2:] = X[N - K // 2:]
+    d = z[1:] * np.conj(z[:-1])                                 # 75 data symbols
+    idx, pi = [], 0
+    for _ in range(1, N):
+        pi = (13 * pi + N // 4 - 1) % N
+        if (N - K) // 2 <= pi <= N - (N - K) // 2 and pi != N // 2:
+            idx.append(pi - (1 + N // 2) if pi > N // 2 else pi + (K - N // 2))
+    idx = np.array(idx)
+    q = d[:, idx]                                               # carrier n of the mapper sits at position idx[n]
+    ibits = (q.real < 0).astype(np.uint8).reshape(75, K // 8, 8)
+    qbits = (q.imag < 0).astype(np.uint8).reshape(75, K // 8, 8)
+    w = (1 << np.arange(7, -1, -1)).astype(np.uint16)
+    blocks = np.concatenate([(ibits * w).sum(-1), (qbits * w).sum(-1)], axis=1).astype(np.uint8)   # [75][384]
+    return blocks.reshape(-1)
+
+
+def test_full_size_batch_round_trip_through_a_receiver(pkg):
+    """Size-independent property at BASELINE size: 96 frames (one second of air time) modulated on the device come back
+    bit for bit through an independent OFDM receiver -- with and without GainControl (a per-symbol scale cannot move a
+    decision) and after the FIR filter (the same factor H[k] on both symbols of a differential pair: it leaves |H[k]|^2;
+    the FFT window is placed 44 samples early, clear of the samples that look into the next symbol)."""
+    import torch
+    B = 96
+    md = pkg.Modulator(mode=1, max_frames=B)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        per = md.geometry["tf_input_bytes"]
+        rs = np.random.RandomState(2024)
+        bits = np.frombuffer(rs.bytes(B * per), np.uint8).reshape(B, per)
+        d_bits = torch.from_numpy(bits.copy()).cuda()
+        for stages, early in ((0, 0), (pkg.STAGE_GAIN, 0), (pkg.STAGE_GAIN | pkg.STAGE_FIR, 44)):
+            out = torch.empty((B, md.out_samples_per_frame(stages)), dtype=torch.complex64, device="cuda")
+            md.chain_dev(d_bits, B, stages, out)
+            y = out.cpu().numpy()
+            for f in range(0, B, 7):                            # every 7th frame: seconds of numpy FFTs, not minutes
+                assert np.array_equal(_dab_demodulate_mode1(y[f], early), bits[f]), (stages, f)
+    finally:
+        md.close()
+
+
 def test_symbols_entry_point_matches_bits_entry_point(pkg):
     """cfg 2 from the SignalMultiplexer output (946 176 B/frame) == cfg 2 from coded bits."""
     import torch
