@@ -742,6 +742,30 @@ def test_full_size_batch_round_trip_through_a_receiver(pkg):
         md.close()
 
 
+def test_cfg4_stream_round_trip_through_a_receiver(pkg):
+    """cfg 4 (FIR -> Resampler x4 -> MemlessPoly) as one stream of 4 frames: every 4th output sample is the input
+    sample one hop (2048 samples) earlier -- branch 0 of the interpolation -- and the predistorter only bends
+    amplitude and phase slightly, so the frames decode bit for bit from the decimated stream."""
+    import torch
+    B = 4
+    md = pkg.Modulator(mode=1, max_frames=B)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_resampler(2048000, 8192000)
+        md.set_poly(POLY_AM, POLY_PM)
+        per = md.geometry["tf_input_bytes"]
+        rs = np.random.RandomState(4096)
+        bits = np.frombuffer(rs.bytes(B * per), np.uint8).reshape(B, per)
+        stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY
+        out = torch.empty((B, md.out_samples_per_frame(stages)), dtype=torch.complex64, device="cuda")
+        md.chain_dev(torch.from_numpy(bits.copy()).cuda(), B, stages, out)
+        stream = out.cpu().numpy().reshape(-1)[4 * 2048::4]          # back at 2.048 Msps, the hop of delay removed
+        for f in range(B - 1):                                       # (the last frame's last hop comes with the next call)
+            assert np.array_equal(_dab_demodulate_mode1(stream[f * 196608:(f + 1) * 196608], 44), bits[f]), f
+    finally:
+        md.close()
+
+
 def test_symbols_entry_point_matches_bits_entry_point(pkg):
     """cfg 2 from the SignalMultiplexer output (946 176 B/frame) == cfg 2 from coded bits."""
     import torch
