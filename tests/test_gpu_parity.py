@@ -16,6 +16,7 @@ import pytest
 
 import oracle as O
 from tests.conftest import load_pkg
+from tests.receiver import dab_demodulate_mode1
 from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, format_edges, format_input, lut_table, synth_bits,
                                 synth_signal)
 
@@ -691,33 +692,6 @@ def test_device_path_batch_is_frame_independent_and_matches_host_path(pkg):
         md1.close()
 
 
-def _dab_demodulate_mode1(y, early=0):
-    """Receiver for one Mode-I frame of the guard-interval output: strip the cyclic prefix (FFT window `early` samples
-    before the end of the symbol: any window inside the cyclic extension only rotates all symbols alike), FFT, undo the
-    differential modulation, the frequency interleaver (ETSI EN 300 401 14.6: pi(j) = 13 pi(j-1) + 511 mod 2048) and the
-    QPSK mapping -> the 28 800 coded bytes.  Written from the standard, independent of the oracle."""
-    N, K, nsym, null, sym = 2048, 1536, 76, 2656, 2552
-    z = np.empty((nsym, K), np.complex128)
-    for s in range(nsym):
-        seg = y[null + s * sym: null + (s + 1) * sym]
-        X = np.fft.fft(seg[sym - N - early: sym - early].astype(np.complex128))
-        z[s, :K // 2] = X[1:K // 2 + 1]
-        z[s, K // 2:] = X[N - K // 2:]
-    d = z[1:] * np.conj(z[:-1])                                 # 75 data symbols
-    idx, pi = [], 0
-    for _ in range(1, N):
-        pi = (13 * pi + N // 4 - 1) % N
-        if (N - K) // 2 <= pi <= N - (N - K) // 2 and pi != N // 2:
-            idx.append(pi - (1 + N // 2) if pi > N // 2 else pi + (K - N // 2))
-    idx = np.array(idx)
-    q = d[:, idx]                                               # carrier n of the mapper sits at position idx[n]
-    ibits = (q.real < 0).astype(np.uint8).reshape(75, K // 8, 8)
-    qbits = (q.imag < 0).astype(np.uint8).reshape(75, K // 8, 8)
-    w = (1 << np.arange(7, -1, -1)).astype(np.uint16)
-    blocks = np.concatenate([(ibits * w).sum(-1), (qbits * w).sum(-1)], axis=1).astype(np.uint8)   # [75][384]
-    return blocks.reshape(-1)
-
-
 def test_full_size_batch_round_trip_through_a_receiver(pkg):
     """Size-independent property at BASELINE size: 96 frames (one second of air time) modulated on the device come back
     bit for bit through an independent OFDM receiver -- with and without GainControl (a per-symbol scale cannot move a
@@ -737,7 +711,7 @@ def test_full_size_batch_round_trip_through_a_receiver(pkg):
             md.chain_dev(d_bits, B, stages, out)
             y = out.cpu().numpy()
             for f in range(0, B, 7):                            # every 7th frame: seconds of numpy FFTs, not minutes
-                assert np.array_equal(_dab_demodulate_mode1(y[f], early), bits[f]), (stages, f)
+                assert np.array_equal(dab_demodulate_mode1(y[f], early), bits[f]), (stages, f)
     finally:
         md.close()
 
@@ -761,7 +735,7 @@ def test_cfg4_stream_round_trip_through_a_receiver(pkg):
         md.chain_dev(torch.from_numpy(bits.copy()).cuda(), B, stages, out)
         stream = out.cpu().numpy().reshape(-1)[4 * 2048::4]          # back at 2.048 Msps, the hop of delay removed
         for f in range(B - 1):                                       # (the last frame's last hop comes with the next call)
-            assert np.array_equal(_dab_demodulate_mode1(stream[f * 196608:(f + 1) * 196608], 44), bits[f]), f
+            assert np.array_equal(dab_demodulate_mode1(stream[f * 196608:(f + 1) * 196608], 44), bits[f]), f
     finally:
         md.close()
 

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from tests.receiver import dab_demodulate_mode1
 from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, format_edges, format_input, lut_table, synth_bits,
                                 synth_signal)
 
@@ -333,3 +334,21 @@ def test_oracle_vs_live_reference_on_fresh_random_input():
     for gm in (0, 1, 2):
         a = O.gain_control(t, N, gm, 1.0, 1.0, 4.0)
         assert np.array_equal(a.view(np.uint32), O.ref_gain_control(t, N, gm, 1.0, 1.0, 4.0).view(np.uint32))
+
+
+def test_oracle_chain_decodes_through_an_independent_receiver():
+    """The oracle's FFT-based stages have no reference run behind them (FFTW is not in the image): an independent
+    check of their orientation, bin layout and timing -- the oracle's Mode-I frames decode bit for bit through a
+    receiver written from the standard.  cfg 2, cfg 3 (FIR: window 44 samples early) and cfg 4 as a stream (every
+    4th sample, one hop of delay)."""
+    rs = np.random.RandomState(11)
+    bits = np.frombuffer(rs.bytes(3 * 28800), np.uint8).reshape(3, 28800)
+    y = O.Chain(mode=1, stages=0).process(bits[:1])
+    assert np.array_equal(dab_demodulate_mode1(y[0]), bits[0])
+    y = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1.0 / 50000.0).process(bits[:1])
+    assert np.array_equal(dab_demodulate_mode1(y[0], 44), bits[0])
+    y = O.Chain(mode=1, stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000, am=POLY_AM, pm=POLY_PM,
+                fast=True).process(bits)
+    stream = y.reshape(-1)[4 * 2048::4]
+    for f in range(2):
+        assert np.array_equal(dab_demodulate_mode1(stream[f * 196608:(f + 1) * 196608], 44), bits[f]), f
