@@ -16,7 +16,7 @@ import pytest
 
 import oracle as O
 from tests.conftest import load_pkg
-from tests.receiver import dab_demodulate_mode1
+from tests.receiver import dab_demodulate, dab_demodulate_mode1
 from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, format_edges, format_input, lut_table, synth_bits,
                                 synth_signal)
 
@@ -712,6 +712,26 @@ def test_full_size_batch_round_trip_through_a_receiver(pkg):
             y = out.cpu().numpy()
             for f in range(0, B, 7):                            # every 7th frame: seconds of numpy FFTs, not minutes
                 assert np.array_equal(dab_demodulate_mode1(y[f], early), bits[f]), (stages, f)
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("mode", [2, 3, 4])
+def test_other_modes_round_trip_through_a_receiver(pkg, mode):
+    """Transmission modes II - IV, cfg 2 and cfg 3, three frames each, decoded by the independent receiver."""
+    import torch
+    md = pkg.Modulator(mode=mode, max_frames=3)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        per = md.geometry["tf_input_bytes"]
+        rs = np.random.RandomState(50 + mode)
+        bits = np.frombuffer(rs.bytes(3 * per), np.uint8).reshape(3, per)
+        for stages, early in ((0, 0), (pkg.STAGE_GAIN | pkg.STAGE_FIR, 44)):
+            out = torch.empty((3, md.out_samples_per_frame(stages)), dtype=torch.complex64, device="cuda")
+            md.chain_dev(torch.from_numpy(bits.copy()).cuda(), 3, stages, out)
+            y = out.cpu().numpy()
+            for f in range(3):
+                assert np.array_equal(dab_demodulate(y[f], mode, early), bits[f]), (stages, f)
     finally:
         md.close()
 
