@@ -63,7 +63,8 @@ enum {
 typedef struct dabgpu_ctx dabgpu_ctx;
 
 typedef struct {
-    int mode;          /* transmission mode 1..4 (src/DabModulator.cpp:84-122) */
+    int mode;          /* transmission mode 1..4 (src/DabModulator.cpp:84-122); 0 = IV, as the stage classes
+                        * read it (src/PhaseReference.cpp:72-76, src/FrequencyInterleaver.cpp:57-58) */
     int device;        /* HIP device ordinal */
     int max_frames;    /* largest n_frames of a *_process call (scratch sizing); 0 -> 1 */
     int chunks_per_frame; /* workgroups per transmission frame for the fused kernel; 0 = auto */

@@ -113,7 +113,8 @@ struct dabgpu_ctx {
     size_t cfr_last_frames = 0;
     hipStream_t cfr_last_stream = nullptr;
     bool tii_insert = true;               // TII::m_insert (src/TII.h:112): this frame of the stream carries TII
-    unsigned long long tii_seg_epoch = 0; // settings epoch / stage mask the cached segment was built for
+    bool tables_valid = false;            // apply_settings has uploaded every table group once
+    unsigned long long tii_seg_epoch = 0; // 1 while the cached segment matches the settings (apply_settings zeroes it), and its stage mask
     unsigned tii_seg_mask = ~0u;
     int tii_seg_len = 0;
 
@@ -127,12 +128,19 @@ struct dabgpu_ctx {
     // asynchronous host path (dabgpu_chain_submit / dabgpu_chain_collect): two batches in flight,
     // pinned staging on both sides, device->host copies on their own stream
     struct Slot {
-        void *h_in = nullptr, *h_out = nullptr;        // pinned (hipHostMalloc)
-        size_t h_in_cap = 0, h_out_cap = 0, out_bytes = 0;
+        void *h_in = nullptr;                          // pinned (hipHostMalloc)
+        size_t h_in_cap = 0, out_bytes = 0;
+        int h_out_index = 0;                           // which of the three pinned output buffers this batch lands in
         DevBuf d_in, d_out;
         hipEvent_t computed = nullptr, copied = nullptr;
         bool busy = false;
     } slot[2];
+    // Pinned output buffers, THREE for two batches in flight: submit n copies into buffer n mod 3, so the
+    // buffer handed out by collect() of batch n is next written by submit n + 3 -- after the collect at the
+    // latest the second next submit.  (With one buffer per slot the very next submit overwrote it.)
+    void *h_out[3] = {nullptr, nullptr, nullptr};
+    size_t h_out_cap[3] = {0, 0, 0};
+    unsigned long long submit_seq = 0;
     hipStream_t copy_stream = nullptr;
     int slot_head = 0, slot_count = 0;                 // oldest batch in flight, number in flight
 };
@@ -245,21 +253,40 @@ int build_tables(dabgpu_ctx *c)
     return DABGPU_OK;
 }
 
-// take the settings snapshot and (re)upload what changed
+// Take the settings snapshot and (re)upload the tables of the parameter GROUPS that changed: filter taps
+// (+ their frequency response), guard window, predistorter coefficients, resampler.  Gain, CFR and TII
+// parameters are kernel arguments / cached-segment keys and need no upload at all.  A table is only
+// rewritten after the device has drained: the previous call may still be running on a caller's stream.
 int apply_settings(dabgpu_ctx *c)
 {
+    Settings prev;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         if (c->set.epoch == c->applied_epoch) return DABGPU_OK;
+        prev = c->cur;
         c->cur = c->set;
         c->set.resampler_reset = false;
         c->applied_epoch = c->set.epoch;
     }
+    const bool first = !c->tables_valid;
+    const bool taps_changed = first || prev.taps != c->cur.taps;
+    const bool window_changed = c->cur.overlap && (first || prev.overlap != c->cur.overlap);
+    const bool coef_changed = first || std::memcmp(prev.am, c->cur.am, sizeof prev.am) ||
+                              std::memcmp(prev.pm, c->cur.pm, sizeof prev.pm) ||
+                              std::memcmp(prev.lut, c->cur.lut, sizeof prev.lut);
+    const bool rs_changed = first || prev.rs_in != c->cur.rs_in || prev.rs_out != c->cur.rs_out || c->cur.resampler_reset;
+    const bool tii_changed = prev.tii_comb != c->cur.tii_comb || prev.tii_pattern != c->cur.tii_pattern ||
+                             prev.tii_old_variant != c->cur.tii_old_variant || prev.cfr_enable != c->cur.cfr_enable ||
+                             prev.cfr_clip != c->cur.cfr_clip || prev.cfr_errclip != c->cur.cfr_errclip ||
+                             prev.overlap != c->cur.overlap;
+    if (taps_changed || tii_changed) c->tii_seg_epoch = 0;      // the cached TII segment went through the old filter / CFR
+    if (!(taps_changed || window_changed || coef_changed || rs_changed)) return DABGPU_OK;
+    if (!first) HIPCHK(c, hipDeviceSynchronize());
     hipStream_t s = c->stream;
-    std::vector<float> taps(kMaxTaps, 0.0f);   // the fused kernel's copy (longer filters take the unfused kernels)
-    std::copy(c->cur.taps.begin(), c->cur.taps.begin() + std::min<size_t>(c->cur.taps.size(), kMaxTaps), taps.begin());
-    HIPCHK(c, upload(c->d_taps, taps, s));
-    {
+    if (taps_changed) {
+        std::vector<float> taps(kMaxTaps, 0.0f);   // the fused kernel's copy (longer filters take the unfused kernels)
+        std::copy(c->cur.taps.begin(), c->cur.taps.begin() + std::min<size_t>(c->cur.taps.size(), kMaxTaps), taps.begin());
+        HIPCHK(c, upload(c->d_taps, taps, s));
         // frequency response seen by the look-ahead FIR on a cyclically extended symbol:
         // H[k] = sum_j taps[j] exp(+2 pi i j k / N), evaluated in float64
         const int N = c->g.N;
@@ -275,7 +302,7 @@ int apply_settings(dabgpu_ctx *c)
         }
         HIPCHK(c, upload(c->d_firh, h, s));
     }
-    if (c->cur.overlap) {
+    if (window_changed) {
         // src/GuardIntervalInserter.cpp:106-111
         const size_t W = c->cur.overlap;
         std::vector<float> w(2 * W);
@@ -283,14 +310,17 @@ int apply_settings(dabgpu_ctx *c)
             w[i] = (float)(0.5 * (1.0 - std::cos(M_PI * (double)i / (double)(2 * W - 1))));
         HIPCHK(c, upload(c->d_window, w, s));
     }
-    std::vector<float> coef(48, 0.f);
-    std::copy(c->cur.am, c->cur.am + 5, coef.begin());
-    std::copy(c->cur.pm, c->cur.pm + 5, coef.begin() + 8);
-    std::copy(c->cur.lut, c->cur.lut + 32, coef.begin() + 16);
-    HIPCHK(c, upload(c->d_coef, coef, s));
+    if (coef_changed) {
+        std::vector<float> coef(48, 0.f);
+        std::copy(c->cur.am, c->cur.am + 5, coef.begin());
+        std::copy(c->cur.pm, c->cur.pm + 5, coef.begin() + 8);
+        std::copy(c->cur.lut, c->cur.lut + 32, coef.begin() + 16);
+        HIPCHK(c, upload(c->d_coef, coef, s));
+    }
+    c->tables_valid = true;
 
     // resampler geometry, src/Resampler.cpp:65-112
-    {
+    if (rs_changed) {
         size_t a = c->cur.rs_in, b = c->cur.rs_out;
         while (b) { size_t t = a % b; a = b; b = t; }
         const size_t L = c->cur.rs_out / a, M = c->cur.rs_in / a;
@@ -567,7 +597,7 @@ int tii_carrier_set(int mode, int comb, int pattern, std::vector<uint8_t> &acp)
 int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t native, hipStream_t s)
 {
     const unsigned key = mask & (DABGPU_STAGE_FIR | DABGPU_STAGE_NOGUARD);
-    if (c->tii_seg_epoch == c->applied_epoch && c->tii_seg_mask == key) return DABGPU_OK;
+    if (c->tii_seg_epoch != 0 && c->tii_seg_mask == key) return DABGPU_OK;
     const size_t K = (size_t)c->g.K, car_bytes = (size_t)(c->g.nb_symbols + 1) * K * sizeof(float2);
     std::vector<uint8_t> acp;
     if (tii_carrier_set(c->g.mode, c->cur.tii_comb, c->cur.tii_pattern, acp))
@@ -588,7 +618,7 @@ int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t nativ
     const size_t ext = (mask & DABGPU_STAGE_NOGUARD) ? (size_t)c->g.N
                                                      : (size_t)c->g.null_size + 2 * c->cur.overlap + 8;
     c->tii_seg_len = (int)std::min(native, ext);
-    c->tii_seg_epoch = c->applied_epoch;
+    c->tii_seg_epoch = 1;
     c->tii_seg_mask = key;
     return DABGPU_OK;
 }
@@ -779,12 +809,13 @@ void dabgpu_destroy(dabgpu_ctx *c)
         b->release();
     for (auto &sl : c->slot) {
         if (sl.h_in) (void)hipHostFree(sl.h_in);
-        if (sl.h_out) (void)hipHostFree(sl.h_out);
         sl.d_in.release();
         sl.d_out.release();
         if (sl.computed) (void)hipEventDestroy(sl.computed);
         if (sl.copied) (void)hipEventDestroy(sl.copied);
     }
+    for (void *h : c->h_out)
+        if (h) (void)hipHostFree(h);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->ev0) (void)hipEventDestroy(c->ev0);
     if (c->ev1) (void)hipEventDestroy(c->ev1);
@@ -809,6 +840,10 @@ int dabgpu_set_gain(dabgpu_ctx *c, int gain_mode, float digital, float normalise
     if (!c) return DABGPU_E_INVALID;
     if (gain_mode < 0 || gain_mode > 2) return fail(c, DABGPU_E_INVALID, "invalid gainmode");
     std::lock_guard<std::mutex> lk(c->mu);
+    // (the adapters push their parameters on every frame: only a CHANGE makes the processing thread look)
+    if (c->set.gain_mode == gain_mode && c->set.digital == digital && c->set.normalise == normalise &&
+        c->set.var_variance == var_variance)
+        return DABGPU_OK;
     c->set.gain_mode = gain_mode; c->set.digital = digital; c->set.normalise = normalise;
     c->set.var_variance = var_variance;
     ++c->set.epoch;
@@ -821,6 +856,7 @@ int dabgpu_set_fir_taps(dabgpu_ctx *c, const float *taps, size_t n)
     if (!taps || n == 0) return fail(c, DABGPU_E_INVALID, "FIRFilter: taps file has invalid format.");
     if (n > (size_t)kMaxTapsUnfused) return fail(c, DABGPU_E_INVALID, "FIRFilter: more than 512 taps not supported");
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->set.taps.size() == n && std::equal(taps, taps + n, c->set.taps.begin())) return DABGPU_OK;
     c->set.taps.assign(taps, taps + n);
     ++c->set.epoch;
     return DABGPU_OK;
@@ -832,6 +868,7 @@ int dabgpu_set_window_overlap(dabgpu_ctx *c, size_t overlap)
 {
     if (!c) return DABGPU_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->set.overlap == overlap) return DABGPU_OK;
     c->set.overlap = overlap;
     ++c->set.epoch;
     return DABGPU_OK;
@@ -841,6 +878,8 @@ int dabgpu_set_cfr(dabgpu_ctx *c, int enable, float clip, float error_clip)
 {
     if (!c) return DABGPU_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->set.cfr_enable == (enable != 0) && c->set.cfr_clip == clip && c->set.cfr_errclip == error_clip)
+        return DABGPU_OK;
     c->set.cfr_enable = enable != 0;
     c->set.cfr_clip = clip;
     c->set.cfr_errclip = error_clip;
@@ -889,6 +928,9 @@ int dabgpu_set_tii(dabgpu_ctx *c, int enable, int comb, int pattern, int old_var
     if (pattern < 0 || pattern > 69) return fail(c, DABGPU_E_INVALID, "TII::TII pattern not valid!");
     if (comb < 0 || comb > 23) return fail(c, DABGPU_E_INVALID, "TII::TII comb not valid!");
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->set.tii_enable == (enable != 0) && c->set.tii_comb == comb && c->set.tii_pattern == pattern &&
+        c->set.tii_old_variant == (old_variant != 0))
+        return DABGPU_OK;
     c->set.tii_enable = enable != 0;
     c->set.tii_comb = comb;
     c->set.tii_pattern = pattern;
@@ -911,6 +953,7 @@ int dabgpu_set_poly(dabgpu_ctx *c, const float am[5], const float pm[5])
 {
     if (!c || !am || !pm) return DABGPU_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (!c->set.poly_is_lut && std::equal(am, am + 5, c->set.am) && std::equal(pm, pm + 5, c->set.pm)) return DABGPU_OK;
     std::copy(am, am + 5, c->set.am);
     std::copy(pm, pm + 5, c->set.pm);
     c->set.poly_is_lut = false;
@@ -922,6 +965,7 @@ int dabgpu_set_lut(dabgpu_ctx *c, float scalefactor, const float lut[32])
 {
     if (!c || !lut) return DABGPU_E_INVALID;
     std::lock_guard<std::mutex> lk(c->mu);
+    if (c->set.poly_is_lut && c->set.lut_scale == scalefactor && std::equal(lut, lut + 32, c->set.lut)) return DABGPU_OK;
     c->set.lut_scale = scalefactor;
     std::copy(lut, lut + 32, c->set.lut);
     c->set.poly_is_lut = true;
@@ -1330,12 +1374,13 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
         HIPCHK(c, hipHostMalloc(&sl.h_in, std::max<size_t>(in_bytes, 16), hipHostMallocDefault));
         sl.h_in_cap = in_bytes;
     }
-    if (sl.h_out_cap < need) {
-        if (sl.h_out) (void)hipHostFree(sl.h_out);
-        sl.h_out = nullptr;
-        sl.h_out_cap = 0;
-        HIPCHK(c, hipHostMalloc(&sl.h_out, std::max<size_t>(need, 16), hipHostMallocDefault));
-        sl.h_out_cap = need;
+    const int ho = (int)(c->submit_seq % 3);
+    if (c->h_out_cap[ho] < need) {
+        if (c->h_out[ho]) (void)hipHostFree(c->h_out[ho]);
+        c->h_out[ho] = nullptr;
+        c->h_out_cap[ho] = 0;
+        HIPCHK(c, hipHostMalloc(&c->h_out[ho], std::max<size_t>(need, 16), hipHostMallocDefault));
+        c->h_out_cap[ho] = need;
     }
     HIPCHK(c, sl.d_in.reserve(std::max<size_t>(in_bytes, 16)));
     HIPCHK(c, sl.d_out.reserve(std::max<size_t>(need, 16)));
@@ -1347,11 +1392,13 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     HIPCHK(c, hipEventRecord(sl.computed, c->stream));
     // the copy back runs on its own stream: the next batch's kernels overlap it
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.computed, 0));
-    if (need) HIPCHK(c, hipMemcpyAsync(sl.h_out, sl.d_out.p, need, hipMemcpyDeviceToHost, c->copy_stream));
+    if (need) HIPCHK(c, hipMemcpyAsync(c->h_out[ho], sl.d_out.p, need, hipMemcpyDeviceToHost, c->copy_stream));
     HIPCHK(c, hipEventRecord(sl.copied, c->copy_stream));
     sl.out_bytes = need;
+    sl.h_out_index = ho;
     sl.busy = true;
     ++c->slot_count;
+    ++c->submit_seq;
     return DABGPU_OK;
 }
 
@@ -1362,7 +1409,7 @@ int dabgpu_chain_collect(dabgpu_ctx *c, const void **iq, size_t *out_bytes)
     if (c->slot_count == 0) return fail(c, DABGPU_E_INVALID, "no batch in flight");
     dabgpu_ctx::Slot &sl = c->slot[c->slot_head];
     HIPCHK(c, hipEventSynchronize(sl.copied));
-    *iq = sl.h_out;
+    *iq = c->h_out[sl.h_out_index];
     if (out_bytes) *out_bytes = sl.out_bytes;
     sl.busy = false;
     c->slot_head ^= 1;

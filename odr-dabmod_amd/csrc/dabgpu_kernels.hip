@@ -6,17 +6,19 @@
 // -> SignalMultiplexer -> OfdmGenerator -> GainControl -> GuardIntervalInserter
 // -> FIRFilter sub-graph (src/DabModulator.cpp:385-419) with no intermediate in
 // HBM.  A workgroup owns a run of consecutive OFDM symbols of one frame:
-//   * the differential-modulation state (a 3-bit phase per carrier) lives in
-//     registers, 6 carriers per lane, laid out so that each lane's carriers are
-//     exactly its inputs of the first FFT stage (no scatter through LDS);
-//   * the N-point backward FFT is a Stockham radix-8 autosort, 8 points per
-//     lane, exchanged through a 16 KiB XOR-swizzled LDS buffer (conflict-free
-//     ds_write_b64 / ds_read_b64), twiddles resident in registers;
-//   * gain statistics are wave-shuffle + LDS reductions over the FFT output
-//     while it is still in registers;
-//   * the cyclic prefix is a second LDS store of the same registers into a
-//     stream buffer, and the FIR runs over that buffer (register-blocked, taps
-//     in SGPRs) and stores straight to HBM.
+//   * the differential-modulation state lives in registers as integer phases (six 4-bit fields of one
+//     register per lane); each lane's six carriers are exactly its inputs of the first FFT stage, so
+//     nothing is scattered through LDS;
+//   * the N-point backward FFT is a Stockham radix-8 autosort (8 . 8 . 8 . 4 for N = 2048), 8 points
+//     per lane, three exchanges through one padded LDS buffer (row layout for the first, additive
+//     padding for the stride-8 one; every access is base + immediate), twiddles in registers / a small
+//     LDS table;
+//   * gain statistics come from the SPECTRUM (population variance through Parseval on carrier pairs),
+//     counted with ballots; modes max / fix reduce over the FFT output with DPP;
+//   * the cyclic prefix is a second store of the same registers;
+//   * the FIR is spectral: the unfiltered and the filtered IFFT of a symbol run as ONE packed dual
+//     transform (struct c2), the unfiltered half pruned to the 88 samples the 44-tap boundary FIR
+//     between two symbols reads (Fft::run_dual_zonly); only those boundary outputs are a direct FIR.
 // HBM traffic is therefore the compulsory 28.8 kB in + 1.57 MB out per frame.
 //
 // No MFMA (no dense contraction in this path), wave64 throughout.
@@ -1737,11 +1739,45 @@ __global__ void diff_mod_kernel(const cf *__restrict__ phase, const cf *__restri
 
 // a7 GainControl stand-alone: one workgroup per symbol pair (statistics symbol,
 // output symbol); N/8 lanes, 8 samples per lane.
+//
+// Gain mode var replays the reference's x86 code path operation for operation (src/GainControl.cpp:251-340):
+// the symbol is N/2 vectors {re0, im0, re1, im1}; four independent fp32 running means (mean += (x - mean) / count),
+// the two means of each part averaged, four running variances against those, averaged, sqrt, times var_variance.
+// The recurrence is serial in the sample index, so four lanes -- one per SSE lane -- walk the symbol (staged in LDS)
+// while the rest of the workgroup waits: ~2 x N/2 dependent divisions per symbol, microseconds, and the drop-in
+// stage then returns the reference's gain BIT FOR BIT instead of the exact population variance the fused chain
+// uses (which differs from this recurrence by up to 5e-7 relative).  Products and sums are rounded separately.
+DEV float gain_var_replay(const float *sym, int nvec, float var_variance, int l)
+{
+#pragma clang fp contract(off)
+    float mean = 0.f;
+    for (int v = 0; v < nvec; ++v) {
+        const float d = sym[4 * v + l] - mean;
+        mean = mean + d / (float)(v + 1);
+    }
+    // lanes {0,2} hold re, {1,3} hold im
+    const float other = __shfl_xor(mean, 2, 64);
+    const float m2 = (mean + other) * 0.5f;
+    float var = 0.f;
+    for (int v = 0; v < nvec; ++v) {
+        const float diff = sym[4 * v + l] - m2;
+        const float sq = diff * diff;
+        const float d = sq - var;
+        var = var + d / (float)(v + 1);
+    }
+    const float merged = (var + __shfl_xor(var, 2, 64)) * 0.5f;       // lanes 0 and 1: re and im
+    const float sd = sqrtf(merged) * var_variance;
+    const float sd_re = __shfl(sd, 0, 64), sd_im = __shfl(sd, 1, 64);
+    if ((int)sd_re == 0) return 1.0f;
+    return 32767.0f / (sd_re > sd_im ? sd_re : sd_im);
+}
+
 template <int LOGN> __global__ void gain_kernel(const cf *__restrict__ in, size_t nsym,
                                                 GainParams gp, cf *__restrict__ out)
 {
     constexpr int N = 1 << LOGN, T = N / 8;
     __shared__ double red[16];
+    __shared__ float stat[2 * N];
     const size_t s = blockIdx.x;
     const int t = threadIdx.x;
     const bool on = t < T;
@@ -1750,7 +1786,26 @@ template <int LOGN> __global__ void gain_kernel(const cf *__restrict__ in, size_
     cf v[8];
 #pragma unroll
     for (int m = 0; m < 8; ++m) v[m] = in[src * N + tt + T * m];
-    const float g = symbol_gain<T>(v, gp, red, tt, on) * gp.constant;
+    float g;
+    if (gp.mode == 2) {
+        if (on) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) reinterpret_cast<cf *>(stat)[t + T * m] = v[m];
+        }
+        __syncthreads();
+        if (t < 64) {                                   // the first wave; lanes 0..3 carry the four statistics
+            const float gv = gain_var_replay(stat, N / 2, gp.var_variance, t & 3);
+            if (t == 0) reinterpret_cast<float *>(red)[0] = gv;
+        }
+        __syncthreads();
+        g = reinterpret_cast<float *>(red)[0];
+    } else {
+        g = symbol_gain<T>(v, gp, red, tt, on);
+    }
+    {
+#pragma clang fp contract(off)
+        g = g * gp.constant;
+    }
     if (!on) return;
 #pragma unroll
     for (int m = 0; m < 8; ++m) {

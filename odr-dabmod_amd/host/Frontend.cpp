@@ -393,6 +393,19 @@ int EtiReader::loadEtiData(const Buffer &dataIn)
                 }
                 take(n);
                 m_state = State::Eoh;
+                {
+                    // Consistency against the 6144-byte frame (the reference does not check: a header whose
+                    // sub-channels overrun the frame would make m_remaining wrap and the reader swallow the
+                    // frames that follow as payload).  Refuse it and resynchronise on the next frame.
+                    size_t need = 4 /* EOH */ + myFicSource->getFramesize() + 4 /* EOF */ + 4 /* TIST */;
+                    for (const auto &src : mySources) need += src->framesize();
+                    if (need > m_remaining) {
+                        m_state = State::Sync;
+                        m_stc.clear();
+                        mySources.clear();
+                        throw std::runtime_error("EtiReader: stream characterisation exceeds the 6144-byte ETI frame");
+                    }
+                }
                 break;
             }
             case State::Eoh:                                   // MNSC + header CRC (not checked, as in the reference)
@@ -595,7 +608,14 @@ struct EtiFrontend::Sub {
     Buffer b0, b1, b2, b3, b4;
 };
 
-EtiFrontend::EtiFrontend(unsigned mode) : m_mode(mode ? mode : 1), m_reader(m_tist_offset) {}
+// Mode 0 ("take it from the ETI stream") is only a provisional Mode I in the reference's constructor; the
+// flowgraph is built by DabModulator::process with setMode(m_settings.dabMode), which rejects it
+// (src/DabModulator.cpp:75-80, :131-133, :119-121).  The stage classes below that level (PhaseReference,
+// FrequencyInterleaver: src/PhaseReference.cpp:72-76) read 0 as Mode IV, and so does dabgpu_create.
+EtiFrontend::EtiFrontend(unsigned mode) : m_mode(mode), m_reader(m_tist_offset)
+{
+    if (mode < 1 || mode > 4) throw std::runtime_error("DabModulator::setMode invalid mode size");
+}
 
 void EtiFrontend::build()
 {

@@ -8,6 +8,7 @@
 #include <algorithm>
 #include <cctype>
 #include <cstring>
+#include <complex>
 #include <fstream>
 #include <deque>
 #include <numeric>
@@ -716,8 +717,9 @@ std::string MemlessPoly::serialise_coefficients() const
         for (float c : m_am) ss << c << std::endl;
         for (float c : m_pm) ss << c << std::endl;
     } else {
+        // (the reference's table is std::array<complexf, 32>: operator<< prints "(re,im)", src/MemlessPoly.cpp:131-138)
         ss << 2 << std::endl << m_lut.size() << std::endl << m_lut_scale << std::endl;
-        for (float c : m_lut) ss << c << std::endl;
+        for (float c : m_lut) ss << std::complex<float>(c) << std::endl;
     }
     return ss.str();
 }
@@ -744,8 +746,10 @@ void MemlessPoly::set_parameter(const std::string &parameter, const std::string 
         std::stringstream ss(value);
         try {
             load_coefficients(ss);
-            std::ofstream f(m_coefs_file);     // the reference writes RC-set coefficients back
-            f << serialise_coefficients();
+            // "Write back to the file to ensure we will start up with the same settings next time": the
+            // value as received (src/MemlessPoly.cpp:431-437)
+            std::ofstream f(m_coefs_file);
+            f << value;
         } catch (const std::runtime_error &e) {
             throw ParameterError(e.what());
         }
@@ -766,7 +770,7 @@ const std::string MemlessPoly::get_parameter(const std::string &parameter) const
 {
     if (parameter == "ncoefs") {
         std::lock_guard<std::mutex> lock(m_coefs_mutex);
-        return std::to_string(m_is_lut ? m_lut.size() : m_am.size());
+        return std::to_string(m_am.size());                  // the AM vector's size whatever the type (:453-454)
     }
     if (parameter == "coefs") return serialise_coefficients();
     if (parameter == "coeffile") return m_coefs_file;
@@ -776,8 +780,12 @@ const std::string MemlessPoly::get_parameter(const std::string &parameter) const
 const json::map_t MemlessPoly::get_all_values() const
 {
     json::map_t m;
-    m["coeffile"].v = m_coefs_file;
+    {
+        std::lock_guard<std::mutex> lock(m_coefs_mutex);
+        m["ncoefs"].v = m_am.size();
+    }
     m["coefs"].v = serialise_coefficients();
+    m["coeffile"].v = m_coefs_file;
     return m;
 }
 

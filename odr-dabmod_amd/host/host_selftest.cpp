@@ -9,6 +9,13 @@
 //       cifGain -> cifGuard -> cifFilter -> output) from the drop-in stages, feeds
 //       <nframes> blocks of hot-path input, and writes what reaches the sink; then
 //       runs the same frames through the single DabGpuChain plugin.
+//   host_selftest cfg4 <bits.bin> <nframes> <graph_out.iq> <poly.coef> <output rate>
+//       the same graph continued the way src/DabModulator.cpp:403-406 continues it for an SDR sink
+//       with a resampler and a predistorter: ... cifFilter -> cifRes -> cifPoly -> output (Mode I).
+//   host_selftest memlesspoly <frame.iq> <out prefix> <format-1 file> <format-2 file> <identity file>
+//       the MemlessPoly drop-in fed from coefficient FILES and through its remote-control
+//       parameters ncoefs / coefs / coeffile (reference src/MemlessPoly.cpp:145-232, :413-470); writes
+//       <prefix>.poly.iq, .lut.iq, .rc.iq, .identity.iq, .invalid.iq
 #include "Flowgraph.h"
 #include "Frontend.h"
 #include "GpuStages.h"
@@ -18,7 +25,9 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <sstream>
 #include <stdexcept>
+#include <variant>
 
 namespace {
 
@@ -279,6 +288,159 @@ std::vector<uint8_t> read_all(const std::string &path)
     return std::vector<uint8_t>((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
 }
 
+
+// one frame through a pipelined stage: the frame comes back on the following call (reference
+// src/ModPlugin.cpp:90-154), so every frame is pushed twice
+void through_pipeline(ModCodec &stage, const std::vector<uint8_t> &frame, const std::string &path)
+{
+    Buffer out;
+    for (int k = 0; k < 2; ++k) {
+        Buffer in(frame.size(), frame.data());
+        stage.process(&in, &out);
+    }
+    std::ofstream f(path, std::ios::binary);
+    f.write(static_cast<const char *>(out.getData()), static_cast<std::streamsize>(out.getLength()));
+}
+
+std::string slurp(const std::string &path)
+{
+    std::ifstream f(path);
+    return std::string((std::istreambuf_iterator<char>(f)), std::istreambuf_iterator<char>());
+}
+
+int run_memlesspoly(int argc, char **argv)
+{
+    if (argc < 7) {
+        std::fprintf(stderr, "usage: host_selftest memlesspoly <frame.iq> <out prefix> <fmt1 file> <fmt2 file> <identity file>\n");
+        return 2;
+    }
+    const std::vector<uint8_t> frame = read_all(argv[2]);
+    const std::string prefix = argv[3], f1 = argv[4], f2 = argv[5], fid = argv[6];
+    std::string coefs_file = f1;
+    MemlessPoly poly(coefs_file, 4);
+    CHECK(std::string(poly.name()) == "MemlessPoly" && poly.get_rc_name() == "memlesspoly");
+    CHECK(poly.get_parameter("coeffile") == f1 && poly.get_parameter("ncoefs") == "5");
+    // format 1: "1 / 5 / 5 AM values / 5 PM values", one per line -- what python/dpd/Adapt.py:142-155 writes
+    {
+        std::stringstream ss(poly.get_parameter("coefs"));
+        int fmt = 0, n = 0;
+        ss >> fmt >> n;
+        CHECK(fmt == 1 && n == 5);
+        std::stringstream file(slurp(f1));
+        int ffmt, fn;
+        file >> ffmt >> fn;
+        for (int i = 0; i < 10; ++i) {
+            float a, b;
+            ss >> a;
+            file >> b;
+            CHECK(a == b);
+        }
+    }
+    through_pipeline(poly, frame, prefix + ".poly.iq");
+    // coeffile: load another file (format 2, look-up table) while running
+    poly.set_parameter("coeffile", f2);
+    CHECK(poly.get_parameter("coeffile") == f2);
+    CHECK(poly.get_parameter("coefs").substr(0, 5) == "2\n32\n");
+    CHECK(std::get<uint64_t>(poly.get_all_values().at("ncoefs").v) == 5);     // the AM vector keeps its size
+    through_pipeline(poly, frame, prefix + ".lut.iq");
+    // coefs: coefficients as a string in the file's own format; written back to the current coefficient file
+    const std::string rc = "1\n5\n0.9\n0.1\n-0.02\n0.004\n0.0005\n0.01\n-0.03\n0.002\n0.001\n-0.0002\n";
+    poly.set_parameter("coefs", rc);
+    CHECK(slurp(f2) == rc);
+    CHECK(poly.get_parameter("coeffile") == f2);
+    through_pipeline(poly, frame, prefix + ".rc.iq");
+    // the identity file the reference ships (python/poly.coef)
+    poly.set_parameter("coeffile", fid);
+    through_pipeline(poly, frame, prefix + ".identity.iq");
+    // errors: read-only and unknown parameters, wrong coefficient count, missing file -- ParameterError, settings kept
+    auto throws = [&](const std::string &p, const std::string &v) {
+        try { poly.set_parameter(p, v); } catch (const ParameterError &) { return true; }
+        return false;
+    };
+    CHECK(throws("ncoefs", "5"));
+    CHECK(throws("nonsense", "1"));
+    CHECK(throws("coefs", "1\n4\n1\n0\n0\n0\n0\n0\n0\n0\n"));
+    CHECK(throws("coefs", "1\n5\n1\n0\n0\n"));                                    // EOF before ten values
+    CHECK(throws("coeffile", prefix + ".does-not-exist"));
+    bool threw = false;
+    try { (void)poly.get_parameter("nonsense"); } catch (const ParameterError &) { threw = true; }
+    CHECK(threw);
+    CHECK(poly.get_parameter("coeffile") == fid);
+    // unknown format id: no exception, settings invalid, frames pass through (src/MemlessPoly.cpp:227-231, :404-408)
+    poly.set_parameter("coefs", "3\n1\n1.0\n");
+    CHECK(poly.get_parameter("coefs").empty());
+    through_pipeline(poly, frame, prefix + ".invalid.iq");
+    // a constructor given a missing file throws like the reference's
+    threw = false;
+    try {
+        std::string missing = prefix + ".does-not-exist";
+        MemlessPoly bad(missing, 1);
+    } catch (const std::runtime_error &) { threw = true; }
+    CHECK(threw);
+    std::printf("host_selftest memlesspoly: OK (%d checks)\n", g_checks);
+    return 0;
+}
+
+int run_cfg4(int argc, char **argv)
+{
+    if (argc < 7) {
+        std::fprintf(stderr, "usage: host_selftest cfg4 <bits.bin> <nframes> <graph.iq> <poly.coef> <output rate>\n");
+        return 2;
+    }
+    const std::vector<uint8_t> bits = read_all(argv[2]);
+    const size_t nframes = static_cast<size_t>(std::atoi(argv[3]));
+    std::string coefFile = argv[5];
+    const size_t outputRate = static_cast<size_t>(std::atol(argv[6]));
+    const unsigned mode = 1;
+    const size_t nbSymbols = 76, nbCarriers = 1536, spacing = 2048, nullSize = 2656, symSize = 2552;
+    const size_t block = (nbSymbols - 1) * nbCarriers / 4;
+    if (bits.size() < nframes * block) throw std::runtime_error("bits file too short");
+    GainMode gainMode = GainMode::GAIN_VAR;
+    float digitalGain = 1.0f, gainmodeVariance = 4.0f, cfrClip = 1.0f, cfrErrorClip = 1.0f;
+    const float normalise = 1.0f / 50000.0f;                  // what every SDR sink sets (src/DabMod.cpp:293,304)
+    bool enableCfr = false;
+    size_t windowOverlap = 0;
+    std::string tapsFile = "default";
+
+    auto cifPart = std::make_shared<BlockSource>(bits, block);
+    auto cifMap = std::make_shared<QpskSymbolMapper>(nbCarriers, false);
+    auto cifRef = std::make_shared<PhaseReference>(mode, false);
+    auto cifFreq = std::make_shared<FrequencyInterleaver>(mode, false);
+    auto cifDiff = std::make_shared<DifferentialModulator>(nbCarriers, false);
+    auto cifNull = std::make_shared<NullSymbol>(nbCarriers, sizeof(complexf));
+    auto cifSig = std::make_shared<SignalMultiplexer>();
+    auto cifOfdm = std::make_shared<OfdmGeneratorCF32>(1 + nbSymbols, nbCarriers, spacing, enableCfr, cfrClip,
+                                                       cfrErrorClip);
+    auto cifGain = std::make_shared<GainControl>(spacing, gainMode, digitalGain, normalise, gainmodeVariance);
+    auto cifGuard = std::make_shared<GuardIntervalInserter>(nbSymbols, spacing, nullSize, symSize, windowOverlap,
+                                                            FFTEngine::FFTW);
+    auto cifFilter = std::make_shared<FIRFilter>(tapsFile);
+    // src/DabModulator.cpp:265-268: resolution = m_spacing;  :256-262: MemlessPoly(polyCoefFilename, polyNumThreads)
+    auto cifRes = std::make_shared<Resampler>(2048000, outputRate, spacing);
+    auto cifPoly = std::make_shared<MemlessPoly>(coefFile, 4);
+    auto output = std::make_shared<FileSink>(argv[4]);
+
+    Flowgraph fg(true);
+    fg.connect(cifPart, cifMap);
+    fg.connect(cifMap, cifFreq);
+    fg.connect(cifRef, cifDiff);
+    fg.connect(cifFreq, cifDiff);
+    fg.connect(cifNull, cifSig);
+    fg.connect(cifDiff, cifSig);
+    fg.connect(cifSig, cifOfdm);
+    fg.connect(cifOfdm, cifGain);
+    fg.connect(cifGain, cifGuard);
+    fg.connect(cifGuard, cifFilter);
+    fg.connect(cifFilter, cifRes);                            // :403-406
+    fg.connect(cifRes, cifPoly);
+    fg.connect(cifPoly, output);
+    int rounds_ok = 0;
+    for (size_t i = 0; i < nframes; ++i) rounds_ok += fg.run() ? 1 : 0;
+    std::printf("cfg4 stage graph: %zu rounds, %d reached the sink (%d frames written)\n", nframes, rounds_ok,
+                output->frames);
+    return 0;
+}
+
 int run_gpu(int argc, char **argv)
 {
     if (argc < 7) {
@@ -428,6 +590,8 @@ int main(int argc, char **argv)
     try {
         if (argc >= 2 && std::string(argv[1]) == "cpu") return run_cpu();
         if (argc >= 2 && std::string(argv[1]) == "gpu") return run_gpu(argc, argv);
+        if (argc >= 2 && std::string(argv[1]) == "cfg4") return run_cfg4(argc, argv);
+        if (argc >= 2 && std::string(argv[1]) == "memlesspoly") return run_memlesspoly(argc, argv);
         std::fprintf(stderr, "usage: host_selftest cpu | gpu ...\n");
         return 2;
     } catch (const std::exception &e) {

@@ -25,3 +25,17 @@ def load_pkg():
 @pytest.fixture(scope="session")
 def pkg():
     return load_pkg()
+
+
+def record_bound(name, measured, limit):
+    """Log a measured worst case next to the bound it is held to (gpurun_out/measured_bounds.jsonl, one JSON
+    object per line; copied to profiles/ when a bound is (re)derived from it) and return measured <= limit."""
+    import json
+    try:
+        d = os.path.join(ROOT, "gpurun_out")
+        os.makedirs(d, exist_ok=True)
+        with open(os.path.join(d, "measured_bounds.jsonl"), "a") as f:
+            f.write(json.dumps({"name": name, "measured": float(measured), "limit": float(limit)}) + "\n")
+    except OSError:
+        pass
+    return float(measured) <= float(limit)

@@ -99,6 +99,28 @@ def test_frontend_rejects_what_the_reference_throws_on(fe_mod):
         fe.eti_to_bits(synth_eti(8, subchannels=((0, 21, 0),)), 1)   # no UEP profile 56 kbit/s level 1
 
 
+def test_frontend_refuses_a_header_whose_subchannels_overrun_the_frame(fe_mod):
+    """STC entries that add up to more than the 6144-byte frame holds (2 x 1280 kbit/s here): the reader must not
+    consume the following frames as payload -- it throws and resynchronises (the reference does not check)."""
+    fe = fe_mod.Frontend()
+    eti = synth_eti(8, subchannels=((0, 48, 0x22), (100, 48, 0x22)))
+    for f in eti:
+        for i in range(2):                                  # STL = 480 words = 3840 bytes each
+            f[8 + 4 * i + 2] = (0x22 << 2) | (480 >> 8)
+            f[8 + 4 * i + 3] = 480 & 0xFF
+    with pytest.raises(ValueError):
+        fe.eti_to_bits(eti, 1)
+    # the same reader geometry with a layout that fits is accepted
+    assert fe.eti_to_bits(synth_eti(8, subchannels=((0, 48, 0x22), (100, 48, 0x22))), 1).shape[0] == 2
+
+
+def test_frontend_mode_zero_is_rejected_like_dabmodulator_setmode(fe_mod):
+    """DabModulator::process builds the flowgraph with setMode(dabMode), which throws for 0
+    (src/DabModulator.cpp:131-133, :119-121)."""
+    with pytest.raises(ValueError):
+        fe_mod.Frontend().eti_to_bits(synth_eti(8), 0)
+
+
 @pytest.mark.skipif(not O.have_ref(), reason="reference build (oracle/_ref) not present")
 def test_frontend_vs_live_reference_on_fresh_streams(fe_mod):
     mine = fe_mod.Frontend()

@@ -174,3 +174,79 @@ def test_config1_eti_file_to_iq_file(tmp_path, fmt):
         got = np.fromfile(fout, dtype=np.int16)
         d = np.abs(got.astype(np.int32) - want.astype(np.int32))
         assert got.size == want.size and d.max() <= 1 and (d != 0).mean() < 1e-2
+
+
+POLY_AM = (1.0, 0.05, -0.01, 0.002, 0.0)       # the non-identity set of SURVEY 8 a13 / cfg 4
+POLY_PM = (0.0, 0.02, 0.003, 0.0, 0.0)
+
+
+@pytest.mark.gpu
+def test_memlesspoly_adapter_coefficient_files_and_rc(tmp_path):
+    """the C++ MemlessPoly drop-in constructed from a format-1 coefficient file (what
+    python/dpd/Adapt.py:142-155 writes), switched to a format-2 look-up table through `coeffile`, to a new
+    polynomial through `coefs` (written back to the file, src/MemlessPoly.cpp:427-437), and to the identity file
+    python/poly.coef; outputs against the oracle's MemlessPoly (itself bit-identical to the reference class)."""
+    import oracle as O
+    from tests.golden.synth import synth_signal
+    build_host()
+    x = synth_signal(196608, seed=41) * np.float32(1 / 100)                 # |x| < 0.91 as at normalise 1/50000
+    fx, prefix = str(tmp_path / "frame.iq"), str(tmp_path / "out")
+    f1, f2, fid = (str(tmp_path / n) for n in ("poly1.coef", "lut2.coef", "identity.coef"))
+    x.tofile(fx)
+    O.write_poly_file(f1, POLY_AM, POLY_PM)
+    lut = (1.0 + 0.01 * np.arange(32)).astype(np.float32)
+    scale = float(2 ** 32 / 0.95)
+    O.write_lut_file(f2, scale, lut)
+    # the identity file, byte for byte what the reference ships as python/poly.coef
+    open(fid, "w").write("1\n5\n1.0\n0.0\n0.0\n0.0\n0.0\n0.0\n0.0\n0.0\n0.0\n0.0\n")
+    r = subprocess.run([BIN, "memlesspoly", fx, prefix, f1, f2, fid], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "memlesspoly: OK" in r.stdout
+
+    def rel(name, ref):
+        y = np.fromfile(prefix + name, dtype=np.complex64)
+        assert y.size == ref.size
+        return np.linalg.norm(y - ref) / np.linalg.norm(ref), y
+
+    ref_poly = O.memless_poly(x, POLY_AM, POLY_PM)
+    e, y = rel(".poly.iq", ref_poly)
+    assert e < 1e-6
+    # SURVEY 8 a11: rel <= 4e-7 per sample (fused multiply-add against mul + add), on samples that are not tiny
+    from tests.conftest import record_bound
+    assert record_bound("a13 poly per-sample rel", np.max(np.abs(y - ref_poly) / np.maximum(np.abs(ref_poly), 1e-3)), 4e-7)
+    ref_lut = O.memless_lut(x, scale, lut)
+    y = np.fromfile(prefix + ".lut.iq", dtype=np.complex64)
+    assert (np.abs(y - ref_lut) > 1e-6 * np.abs(ref_lut)).mean() <= 1e-5     # a sample on a bin edge may flip bins
+    e, _ = rel(".rc.iq", O.memless_poly(x, (0.9, 0.1, -0.02, 0.004, 0.0005), (0.01, -0.03, 0.002, 0.001, -0.0002)))
+    assert e < 1e-6
+    e, y = rel(".identity.iq", x)
+    assert e < 1e-7                                                          # identity: A = 1, phase 0
+    assert np.array_equal(np.fromfile(prefix + ".invalid.iq", dtype=np.complex64), x)   # invalid settings: pass-through
+    # the file the RC wrote back holds the string as received
+    assert open(f2).read().split() == "1 5 0.9 0.1 -0.02 0.004 0.0005 0.01 -0.03 0.002 0.001 -0.0002".split()
+
+
+@pytest.mark.gpu
+def test_flowgraph_cfg4_resampler_and_memlesspoly_stages_match_oracle(tmp_path):
+    """The DabModulator-shaped graph continued through cifRes -> cifPoly (src/DabModulator.cpp:403-406), from the
+    drop-in stage classes: BASELINE config 4 (2.048 -> 8.192 Msps, non-trivial polynomial from a coefficient file)."""
+    import oracle as O
+    from tests.golden.synth import synth_bits
+    build_host()
+    n, mode = 6, 1
+    per = O.tf_input_bytes(mode)
+    bits = np.stack([synth_bits(per, seed=600 + i) for i in range(n)])
+    fbits, fgraph, fcoef = (str(tmp_path / x) for x in ("bits.bin", "graph.iq", "poly.coef"))
+    bits.tofile(fbits)
+    O.write_poly_file(fcoef, POLY_AM, POLY_PM)
+    r = subprocess.run([BIN, "cfg4", fbits, str(n), fgraph, fcoef, "8192000"], capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    stages = O.STAGE_GAIN | O.STAGE_FIR | O.STAGE_RESAMPLE | O.STAGE_POLY
+    ref = O.Chain(mode=mode, stages=stages, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000,
+                  am=POLY_AM, pm=POLY_PM).process(bits)
+    graph = np.fromfile(fgraph, dtype=np.complex64).reshape(-1, 4 * O.tf_samples(mode))
+    # GainControl, FIRFilter and MemlessPoly are pipelined: one transmission frame each at start-up
+    assert graph.shape[0] == n - 3
+    for f in range(n - 3):
+        assert np.linalg.norm(graph[f] - ref[f]) / np.linalg.norm(ref[f]) < 1e-6
