@@ -417,19 +417,32 @@ bool resampler_fast_ratio(const dabgpu_ctx *c)
     return c->rs_nout % c->rs_nin == 0 && (c->rs_nout / c->rs_nin == 2 || c->rs_nout / c->rs_nin == 4);
 }
 
+// Ratios the kernels cover: L / M (reduced) with M a power of two up to the FFT size N of the transmission mode,
+// any L -- up- and down-sampling.  Then nin = 2 N is a power of two and the nout = (nin / M) L point transform
+// factors into L branches of nin / M points.  Every other ratio is one the reference itself cannot run on whole
+// transmission frames: with M = 2^a 5^b, b > 0 (the input rate is 2 048 000 = 2^14 5^3), half its FFT size does
+// not divide the frame length, and its hop loop (src/Resampler.cpp:142) runs past the input buffer; with M > N
+// its `factor` is 1 or 0 (src/Resampler.cpp:69-75).
+const char *resampler_ratio_error(int N, size_t in_rate, size_t out_rate)
+{
+    if (!in_rate || !out_rate) return "Resampler: invalid rate";
+    if (in_rate == out_rate) return nullptr;
+    size_t a = in_rate, b = out_rate;
+    while (b) { size_t t = a % b; a = b; b = t; }
+    const size_t L = out_rate / a, M = in_rate / a;
+    if (!is_pow2(M) || M > (size_t)N)
+        return "Resampler: only ratios L/M with M a power of two up to the FFT size are supported "
+               "(the reference's hop size does not divide a transmission frame for any other)";
+    if ((2 * (size_t)N / M) * L > ((size_t)1 << 20)) return "Resampler: output FFT size beyond 2^20";
+    return nullptr;
+}
+
 int check_resampler(dabgpu_ctx *c)
 {
-    // Up-sampling by L / M with M a power of two (output rates that are multiples of 2048000 / M: 2.4, 2.5,
-    // 3.072, 4, 6.144, 8, 10 ... Msps): then nin = 2 N is a power of two and the nout-point transform
-    // factors into L transforms of nin / M points.  Other ratios (M not a power of two, down-sampling) would
-    // need arbitrary-length transforms.
-    const size_t nin = (size_t)c->rs_nin, M = c->rs_M, L = c->rs_L;
-    const size_t S = M ? nin / M : 0;                    // transform size of a branch; instantiated: nin .. nin / 64 (32 in Mode I)
-    const bool ok = is_pow2(nin) && nin >= 512 && nin <= 4096 && is_pow2(M) && nin % M == 0 && L > M && S >= 8 &&
-                    (S * 64 >= nin || (nin == 4096 && S == 32)) && L <= 4096 && (size_t)c->rs_nout == S * L;
-    if (!ok)
-        return fail(c, DABGPU_E_INVALID,
-                    "Resampler: only up-sampling by L/M with M a power of two (<= 128 in Mode I) is supported");
+    const char *e = resampler_ratio_error(c->g.N, c->cur.rs_in, c->cur.rs_out);
+    if (e) return fail(c, DABGPU_E_INVALID, e);
+    if ((size_t)c->rs_nin != 2 * (size_t)c->g.N || (size_t)c->rs_nout != (size_t)c->rs_nin / c->rs_M * c->rs_L)
+        return fail(c, DABGPU_E_INVALID, "Resampler: inconsistent geometry");
     return DABGPU_OK;
 }
 
@@ -942,7 +955,8 @@ int dabgpu_set_tii(dabgpu_ctx *c, int enable, int comb, int pattern, int old_var
 int dabgpu_set_resampler(dabgpu_ctx *c, size_t in_rate, size_t out_rate)
 {
     if (!c) return DABGPU_E_INVALID;
-    if (!in_rate || !out_rate) return fail(c, DABGPU_E_INVALID, "Resampler: invalid rate");
+    // an unsupported ratio fails HERE, at configuration time (the drop-in's constructor), not at the first frame
+    if (const char *e = resampler_ratio_error(c->g.N, in_rate, out_rate)) return fail(c, DABGPU_E_INVALID, e);
     std::lock_guard<std::mutex> lk(c->mu);
     c->set.rs_in = in_rate; c->set.rs_out = out_rate; c->set.resampler_reset = true;
     ++c->set.epoch;

@@ -417,6 +417,14 @@ int run_cfg4(int argc, char **argv)
     auto cifFilter = std::make_shared<FIRFilter>(tapsFile);
     // src/DabModulator.cpp:265-268: resolution = m_spacing;  :256-262: MemlessPoly(polyCoefFilename, polyNumThreads)
     auto cifRes = std::make_shared<Resampler>(2048000, outputRate, spacing);
+    {
+        // a ratio no kernel covers (M = 5: the reference's own hop size would not divide a frame) is refused by the
+        // constructor, not by the first process() call
+        bool threw = false;
+        try { Resampler bad(2048000, 2457600, spacing); } catch (const std::runtime_error &) { threw = true; }
+        CHECK(threw);
+        Resampler down(2048000, 1024000, spacing);            // down-sampling constructs
+    }
     auto cifPoly = std::make_shared<MemlessPoly>(coefFile, 4);
     auto output = std::make_shared<FileSink>(argv[4]);
 

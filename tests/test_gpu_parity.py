@@ -276,15 +276,55 @@ def test_resampler_state_carries_across_calls(pkg, out_rate):
         md.close()
 
 
-@pytest.mark.parametrize("out_rate", [1024000, 2500000, 2048001, 3000000])
-def test_resampler_ratios_without_a_kernel_are_refused(pkg, out_rate):
-    """Down-sampling, and L / M with M not a power of two (or beyond 128 in Mode I), would need
-    arbitrary-length transforms: an error, never a wrong signal."""
-    md = pkg.Modulator(mode=1, max_frames=1)
+# (rate, L, M): down-sampling (1 024 000 = 1/2, 1 536 000 = 3/4), many-branch up-sampling with short branch
+# transforms (2 500 000 = 625/512: 8-point branches; 3 000 000 = 375/256: 16-point), and the one-lane-per-branch
+# kernel (M = 1024, 2048: 4- and 2-point branches) in both directions
+GENERAL_RATES = [(1024000, 1, 2), (1536000, 3, 4), (2500000, 625, 512), (3000000, 375, 256), (2050000, 1025, 1024),
+                 (2049000, 2049, 2048), (2046000, 1023, 1024), (2047000, 2047, 2048), (2000000, 125, 128)]
+
+
+@pytest.mark.parametrize("out_rate,L,M", GENERAL_RATES)
+def test_resampler_general_ratios(pkg, out_rate, L, M):
+    """Any L / M with M a power of two (src/Resampler.cpp:62-77), including the Nyquist-averaging down-sampling
+    branch (:165-177), against the oracle (arbitrary-length float64 DFTs), state carried across two calls."""
+    md = pkg.Modulator(mode=1, max_frames=2)
     try:
         md.set_resampler(2048000, out_rate)
-        with pytest.raises(pkg.DabGpuError, match="Resampler: only up-sampling"):
-            md.resample(np.zeros(4096, np.complex64))
+        r = O.Resampler(2048000, out_rate, 2048)
+        x = synth_signal(2 * 196608, seed=61) * np.float32(1 / 160)
+        for part in (x[:196608], x[196608:]):
+            y = md.resample(part)
+            ref = r.process(part)
+            assert y.size == ref.size == part.size * L // M
+            assert record_bound("a10 resampler %d rel-RMS" % out_rate, rel_rms(y, ref), REL_RMS)
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("out_rate", [2048001, 2457600, 4096])
+def test_resampler_ratios_the_reference_cannot_run_are_refused_at_configuration(pkg, out_rate):
+    """M = 2 048 000 / gcd not a power of two (2 457 600: M = 5 -> FFT size 4100, whose half does not divide a
+    transmission frame: the reference's hop loop would run past its input) or beyond the FFT size (2 048 001, 4096):
+    refused by set_resampler itself -- the drop-in's constructor -- never at the first frame, never a wrong signal."""
+    md = pkg.Modulator(mode=1, max_frames=1)
+    try:
+        with pytest.raises(pkg.DabGpuError, match="Resampler: only ratios"):
+            md.set_resampler(2048000, out_rate)
+        md.resample(np.zeros(4096, np.complex64))            # the previous (identity) setting is still in force
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("mode,out_rate", [(2, 1024000), (3, 1536000), (4, 2500000), (2, 2064000)])
+def test_resampler_general_ratios_other_modes(pkg, mode, out_rate):
+    md = pkg.Modulator(mode=mode, max_frames=2)
+    try:
+        N = md.geometry["spacing"]
+        md.set_resampler(2048000, out_rate)
+        r = O.Resampler(2048000, out_rate, N)
+        x = synth_signal(2 * md.geometry["tf_samples"], seed=62) * np.float32(1 / 160)
+        y = md.resample(x)
+        assert rel_rms(y, r.process(x)) < REL_RMS
     finally:
         md.close()
 
