@@ -2,7 +2,7 @@
 """Condense a tools/profile.sh output directory (rocprofv3 rocpd sqlite) into a short summary."""
 import glob, os, sqlite3, sys, collections
 d = sys.argv[1]
-KEEP = ("tf_kernel", "resampler_kernel", "poly_kernel", "fir_kernel", "gain_kernel", "guard_")
+KEEP = ("tf_kernel", "resampler", "poly_kernel", "fir_kernel", "gain_kernel", "guard_")
 print("== kernel stats (rocprofv3 --kernel-trace --stats)")
 for f in glob.glob(os.path.join(d, "stats", "**", "*.db"), recursive=True):
     c = sqlite3.connect(f)
