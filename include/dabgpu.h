@@ -211,6 +211,17 @@ DABGPU_API int dabgpu_format_process_dev(dabgpu_ctx *ctx, const void *d_in, size
 
 /* ---- the fused chain ----------------------------------------------------- */
 
+/* FormatConverter as the last step of the chain (the reference wires it after cifPoly when the output is not
+ * complexf, src/DabModulator.cpp:270-276, :407): format = 0 (complexf, the default) or DABGPU_FMT_*.  With s16 the
+ * chain's last kernel stores the integers itself where it has a variant for it (Mode I coded-bits chain ending in
+ * the filter, or in the x2 / x4 resampler with or without the polynomial predistorter) -- half the bytes written,
+ * half the bytes copied to the host; every other combination converts in a kernel of its own.  Output sizes of
+ * dabgpu_chain_out_bytes_per_frame / _process / _submit follow the format.  dabgpu_get_num_clipped: the number of
+ * clipped components of the most recent chain call (FormatConverter::get_num_clipped_samples, :56-59), after
+ * waiting for that call. */
+DABGPU_API int dabgpu_set_output_format(dabgpu_ctx *ctx, int format);
+DABGPU_API int dabgpu_get_num_clipped(dabgpu_ctx *ctx, size_t *num_clipped);
+
 /* bytes of IQ produced per transmission frame for a stage mask */
 DABGPU_API size_t dabgpu_chain_out_bytes_per_frame(const dabgpu_ctx *ctx, unsigned stage_mask);
 

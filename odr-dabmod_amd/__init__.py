@@ -32,6 +32,7 @@ EXPORTS = [
     "dabgpu_chain_submit", "dabgpu_chain_collect", "dabgpu_set_cfr", "dabgpu_get_cfr_stats",
     "dabgpu_cic_equalizer_process", "dabgpu_set_tii", "dabgpu_tii_process",
     "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
+    "dabgpu_set_output_format", "dabgpu_get_num_clipped",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -123,6 +124,8 @@ def load_library():
     lib.dabgpu_format_process.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, szp]
     lib.dabgpu_format_process_dev.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, vp, vp]
     lib.dabgpu_time_chain_dev.argtypes = [vp, vp, sz, u, vp, sz, C.c_int, C.POINTER(C.c_float)]
+    lib.dabgpu_set_output_format.argtypes = [vp, C.c_int]
+    lib.dabgpu_get_num_clipped.argtypes = [vp, szp]
     _lib = lib
     return lib
 
@@ -327,22 +330,42 @@ class Modulator:
         return ob.value
 
     # ---- fused chain -------------------------------------------------------
+    def set_output_format(self, fmt=None):
+        """FormatConverter as the chain's last step: None / "complexf", or "s16" / "u8" / "s8"."""
+        code = 0 if fmt in (None, "complexf") else FORMATS.get(fmt, (99, None))[0]
+        self._chk(self._lib.dabgpu_set_output_format(self._h, code))
+        self._out_dtype = np.complex64 if code == 0 else FORMATS[fmt][1]
+
+    def num_clipped(self):
+        """Clipped components of the most recent chain call (FormatConverter::get_num_clipped_samples)."""
+        n = C.c_size_t()
+        self._chk(self._lib.dabgpu_get_num_clipped(self._h, C.byref(n)))
+        return int(n.value)
+
+    def out_bytes_per_frame(self, stages):
+        return self._lib.dabgpu_chain_out_bytes_per_frame(self._h, stages)
+
     def out_samples_per_frame(self, stages):
-        return self._lib.dabgpu_chain_out_bytes_per_frame(self._h, stages) // 8
+        """Complex samples per frame (8 bytes each as complexf; 4 / 2 with an integer output format)."""
+        dt = np.dtype(getattr(self, "_out_dtype", np.complex64))
+        per_sample = 8 if dt == np.complex64 else 2 * dt.itemsize
+        return self._lib.dabgpu_chain_out_bytes_per_frame(self._h, stages) // per_sample
 
     def chain(self, bits, stages):
-        """Host path: bits (n_frames x tf_input_bytes uint8) -> complex64 (n_frames x samples)."""
+        """Host path: bits (n_frames x tf_input_bytes uint8) -> complex64 (n_frames x samples), or the integer
+        components (n_frames x 2 * samples) when an output format is set."""
         bits = np.ascontiguousarray(bits, np.uint8).reshape(-1)
         per = self.geometry["tf_input_bytes"]
         if bits.size % per:
             raise DabGpuError("chain: input size not valid")
         n = bits.size // per
-        ns = self.out_samples_per_frame(stages)
-        out = np.empty(n * ns, np.complex64)
+        dt = np.dtype(getattr(self, "_out_dtype", np.complex64))
+        per_out = self.out_bytes_per_frame(stages) // dt.itemsize
+        out = np.empty(n * per_out, dt)
         ob = C.c_size_t()
         self._chk(self._lib.dabgpu_chain_process(self._h, bits.ctypes.data, n, stages,
                                                  out.ctypes.data, out.nbytes, C.byref(ob)))
-        return out.reshape(n, ns)
+        return out.reshape(n, per_out)
 
     def submit(self, bits, stages):
         """Asynchronous host path: queue a batch (at most two in flight)."""
@@ -357,7 +380,8 @@ class Modulator:
         copy=False: valid until the second next submit)."""
         p, n = C.c_void_p(), C.c_size_t()
         self._chk(self._lib.dabgpu_chain_collect(self._h, C.byref(p), C.byref(n)))
-        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_float)), shape=(n.value // 4,)).view(np.complex64)
+        dt = np.dtype(getattr(self, "_out_dtype", np.complex64))
+        a = np.ctypeslib.as_array(C.cast(p, C.POINTER(C.c_uint8)), shape=(n.value,)).view(dt)
         return a.copy() if copy else a
 
     def _stream_handle(self, tensor, stream):

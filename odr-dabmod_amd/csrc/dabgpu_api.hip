@@ -77,6 +77,7 @@ struct Settings {
     float lut_scale = 0.f, lut[32] = {0};
     bool cfr_enable = false;               // src/ConfigParser.h: enableCfr / cfrClip / cfrErrorClip
     float cfr_clip = 1.0f, cfr_errclip = 1.0f;
+    int out_format = 0;                    // 0 = complexf, else DABGPU_FMT_*: FormatConverter as the chain's last step
     bool tii_enable = false, tii_old_variant = false;   // src/TII.h:42-69 (tii_config_t)
     int tii_comb = 0, tii_pattern = 0;
     unsigned long long epoch = 1;  // bumped by every setter
@@ -101,7 +102,8 @@ struct dabgpu_ctx {
     size_t rs_L = 1, rs_M = 1;
     float rs_factor = 1.f;
     // scratch
-    DevBuf d_a, d_b, d_c, d_in, d_out, d_count;
+    DevBuf d_a, d_b, d_c, d_in, d_out, d_count, d_fmt, d_clip;
+    hipStream_t clip_stream = nullptr;     // stream of the most recent chain call that converted its output
     // TII (f-4): carrier set, the one-frame carrier image and its native-rate response, gain of symbol 1
     DevBuf d_acp, d_tii_car, d_tii_frame, d_gain1, d_cic;
     size_t cic_spacing = 0;               // what d_cic was built for (CicEqualizer, a12)
@@ -448,7 +450,7 @@ int check_resampler(dabgpu_ctx *c)
 
 // stream of `total` samples at d_in -> resampled at d_out (stateful)
 int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out, hipStream_t s,
-                  bool fuse_poly = false)
+                  bool fuse_poly = false, unsigned long long *s16_clipped = nullptr)
 {
     int rc = check_resampler(c);
     if (rc) return rc;
@@ -463,6 +465,7 @@ int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out
     a.in = d_in; a.halo = (const float2 *)c->d_rs_halo.p;
     a.out = d_out; a.nhops = nhops;
     a.poly = (fuse_poly && resampler_fast_ratio(c)) ? (const float *)c->d_coef.p : nullptr;
+    a.clipped = s16_clipped;
     a.L = (int)c->rs_L;
     a.M = (int)c->rs_M;
     a.tw_s = (const float2 *)c->d_rs_tw_s.p;
@@ -498,13 +501,17 @@ size_t out_samples_per_frame(const dabgpu_ctx *c, unsigned mask, size_t L, size_
     return n;
 }
 
+size_t bytes_per_sample(int fmt) { return fmt ? dabgpu_format_size(fmt) : sizeof(float2); }
+
 // The chain on device pointers.  from_bits: d_in is coded bits, else carriers.
 // The native-rate part of the chain (everything up to and including FIRFilter) for n_frames frames
 // into native_out (`native` samples per frame).
 int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,
-               float2 *native_out, size_t native, float *gain1, hipStream_t s, bool keep_stats = true)
+               float2 *native_out, size_t native, float *gain1, hipStream_t s, bool keep_stats = true,
+               unsigned long long *s16_clipped = nullptr)
 {
     TfArgs a{};
+    a.clipped = s16_clipped;
     a.g = c->g;
     a.t = tables_of(c);
     a.gain = gain_of(c);
@@ -550,6 +557,7 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
     if (!windowed) {
         if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
         if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
+        if (s16_clipped) flags |= TF_OUT_S16;
         a.chunks_per_frame = auto_chunks(c, n_frames);
         a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
         a.out = native_out;
@@ -637,7 +645,7 @@ int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t nativ
 }
 
 int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask,
-              float2 *d_out, size_t out_cap, size_t *out_bytes, hipStream_t s)
+              void *d_out_v, size_t out_cap, size_t *out_bytes, hipStream_t s, bool apply_format = true)
 {
     int rc = apply_settings(c);
     if (rc) return rc;
@@ -646,8 +654,13 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     if ((mask & DABGPU_STAGE_FIR) && c->cur.taps.empty())
         return fail(c, DABGPU_E_INVALID, "FIRFilter: no taps loaded");
     if ((mask & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) mask &= ~DABGPU_STAGE_RESAMPLE;
+    if (mask & DABGPU_STAGE_RESAMPLE)
+        if ((rc = check_resampler(c))) return rc;
+    // FormatConverter as the last step of the chain (src/DabModulator.cpp:395-419): the stage-level entry points
+    // that borrow the chain (OfdmGenerator, the TII segment) stay complexf
+    const int fmt = apply_format ? c->cur.out_format : 0;
     const size_t per = out_samples_per_frame(c, mask, c->rs_L, c->rs_M);
-    const size_t need = n_frames * per * sizeof(float2);
+    const size_t need = n_frames * per * bytes_per_sample(fmt);
     if (out_bytes) *out_bytes = need;
     if (need > out_cap) return fail(c, DABGPU_E_CAPACITY, "output buffer too small");
     if (n_frames == 0) return DABGPU_OK;
@@ -667,6 +680,31 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
         if (W > (size_t)(c->g.sym_size - c->g.N))
             return fail(c, DABGPU_E_INVALID, "window overlap larger than the guard interval");
     }
+    const bool tii = from_bits && c->cur.tii_enable;
+
+    // s16 leaves the LAST kernel of the chain directly where that kernel has a variant for it: the frame kernel
+    // (Mode I coded-bits chain with guard interval and the default-length filter) or the x2 / x4 resampler (with
+    // the polynomial predistorter inside, or none).  Every other combination, and u8 / s8, converts afterwards.
+    unsigned long long *clip = nullptr;
+    bool fuse_native = false, fuse_post = false;
+    if (fmt) {
+        HIPCHK(c, c->d_clip.reserve(16));
+        HIPCHK(c, hipMemsetAsync(c->d_clip.p, 0, 16, s));
+        clip = (unsigned long long *)c->d_clip.p;
+        c->clip_stream = s;
+        if (fmt == DABGPU_FMT_S16 && !tii && !windowed && from_bits) {
+            const bool poly_ok = !(mask & DABGPU_STAGE_POLY) || (!c->cur.poly_is_lut && (mask & DABGPU_STAGE_RESAMPLE));
+            fuse_native = !post && c->g.logN == 11 && c->cur.taps.size() == 45 && (mask & DABGPU_STAGE_FIR) &&
+                          !(mask & DABGPU_STAGE_NOGUARD) && !c->cur.cfr_enable &&
+                          !((mask & DABGPU_STAGE_GAIN) && c->cur.gain_mode == DABGPU_GAIN_MAX);
+            fuse_post = (mask & DABGPU_STAGE_RESAMPLE) && resampler_fast_ratio(c) && c->rs_nin == 4096 && poly_ok;
+        }
+    }
+    float2 *d_out = (float2 *)d_out_v;
+    if (fmt && !fuse_native && !fuse_post) {
+        HIPCHK(c, c->d_fmt.reserve(n_frames * per * sizeof(float2)));
+        d_out = (float2 *)c->d_fmt.p;
+    }
 
     // where the native-rate stream goes
     float2 *native_out = d_out;
@@ -675,7 +713,6 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
         native_out = (float2 *)c->d_a.p;
     }
 
-    const bool tii = from_bits && c->cur.tii_enable;
     float *gain1 = nullptr;
     if (tii) {
         if ((rc = ensure_tii_segment(c, mask, windowed, native, s))) return rc;
@@ -684,7 +721,9 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             gain1 = (float *)c->d_gain1.p;
         }
     }
-    if ((rc = run_native(c, d_in, from_bits, n_frames, mask, windowed, native_out, native, gain1, s))) return rc;
+    if ((rc = run_native(c, d_in, from_bits, n_frames, mask, windowed, native_out, native, gain1, s, true,
+                         fuse_native ? clip : nullptr)))
+        return rc;
     if (tii)
         HIPCHK(c, launch_tii_add(native_out, native, (const float2 *)c->d_tii_frame.p, c->tii_seg_len, gain1,
                                  c->tii_insert ? 1 : 0, n_frames, s));
@@ -703,7 +742,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
                 HIPCHK(c, c->d_b.reserve(n_frames * per * sizeof(float2)));
                 dst = (float2 *)c->d_b.p;
             }
-            rc = run_resampler(c, cur, n, dst, s, fuse);
+            rc = run_resampler(c, cur, n, dst, s, fuse, fuse_post ? clip : nullptr);
             if (rc) return rc;
             cur = dst;
             n = n_frames * per;
@@ -714,6 +753,8 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             if (rc) return rc;
         }
     }
+    if (fmt && !fuse_native && !fuse_post)
+        HIPCHK(c, launch_format((const float *)d_out, 2 * n_frames * per, fmt, d_out_v, clip, s));
     return DABGPU_OK;
 }
 
@@ -816,7 +857,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
-                      &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count,
+                      &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count, &c->d_fmt, &c->d_clip,
                       &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1, &c->d_cic,
                       &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();
@@ -960,6 +1001,30 @@ int dabgpu_set_resampler(dabgpu_ctx *c, size_t in_rate, size_t out_rate)
     std::lock_guard<std::mutex> lk(c->mu);
     c->set.rs_in = in_rate; c->set.rs_out = out_rate; c->set.resampler_reset = true;
     ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_output_format(dabgpu_ctx *c, int format)
+{
+    if (!c) return DABGPU_E_INVALID;
+    if (format != 0 && !dabgpu_format_size(format)) return fail(c, DABGPU_E_INVALID, "FormatConverter: Invalid format");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->set.out_format == format) return DABGPU_OK;
+    c->set.out_format = format;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_get_num_clipped(dabgpu_ctx *c, size_t *num_clipped)
+{
+    CTXCHK(c);
+    if (!num_clipped) return fail(c, DABGPU_E_INVALID, "null argument");
+    *num_clipped = 0;
+    if (!c->d_clip.p) return DABGPU_OK;
+    HIPCHK(c, hipStreamSynchronize(c->clip_stream ? c->clip_stream : c->stream));
+    unsigned long long v = 0;
+    HIPCHK(c, hipMemcpy(&v, c->d_clip.p, sizeof v, hipMemcpyDeviceToHost));
+    *num_clipped = (size_t)v;
     return DABGPU_OK;
 }
 
@@ -1159,7 +1224,7 @@ int dabgpu_ofdm_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *ou
     if ((rc = check_out(c, need, out_cap, out_bytes))) return rc;
     HIPCHK(c, c->d_b.reserve(need));
     size_t ob = 0;
-    rc = run_chain(c, c->d_c.p, false, 1, DABGPU_STAGE_NOGUARD, (float2 *)c->d_b.p, need, &ob, c->stream);
+    rc = run_chain(c, c->d_c.p, false, 1, DABGPU_STAGE_NOGUARD, (float2 *)c->d_b.p, need, &ob, c->stream, false);
     if (rc) return rc;
     return io.out(out, c->d_b.p, need);
 }
@@ -1320,7 +1385,12 @@ size_t dabgpu_chain_out_bytes_per_frame(const dabgpu_ctx *c, unsigned mask)
         while (b) { size_t t = a % b; a = b; b = t; }
         L = c->set.rs_out / a; M = c->set.rs_in / a;
     }
-    return out_samples_per_frame(c, mask, L, M) * sizeof(float2);
+    int fmt;
+    {
+        std::lock_guard<std::mutex> lk(const_cast<dabgpu_ctx *>(c)->mu);
+        fmt = c->set.out_format;
+    }
+    return out_samples_per_frame(c, mask, L, M) * bytes_per_sample(fmt);
 }
 
 int dabgpu_chain_process_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames, unsigned mask,
@@ -1349,7 +1419,7 @@ int dabgpu_chain_process(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, un
     if (rc) return rc;
     unsigned m2 = mask;
     if ((m2 & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) m2 &= ~DABGPU_STAGE_RESAMPLE;
-    const size_t need = n_frames * out_samples_per_frame(c, m2, c->rs_L, c->rs_M) * sizeof(float2);
+    const size_t need = n_frames * out_samples_per_frame(c, m2, c->rs_L, c->rs_M) * bytes_per_sample(c->cur.out_format);
     if ((rc = check_out(c, need, out_cap, out_bytes))) return rc;
     HostIO io(c);
     if ((rc = io.in(c->d_in, bits, n_frames * tf_in_bytes(c->g)))) return rc;
@@ -1374,7 +1444,7 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     unsigned m2 = mask;
     if ((m2 & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) m2 &= ~DABGPU_STAGE_RESAMPLE;
     const size_t in_bytes = n_frames * tf_in_bytes(c->g);
-    const size_t need = n_frames * out_samples_per_frame(c, m2, c->rs_L, c->rs_M) * sizeof(float2);
+    const size_t need = n_frames * out_samples_per_frame(c, m2, c->rs_L, c->rs_M) * bytes_per_sample(c->cur.out_format);
     dabgpu_ctx::Slot &sl = c->slot[(c->slot_head + c->slot_count) & 1];
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!sl.computed) {

@@ -59,13 +59,17 @@ struct TfArgs {
     unsigned *cfr_counts;     // [frame][2]: clipped samples, clipped errors (pre-zeroed)
     double *cfr_mer;          // [frame][2]: sum |before|^2, sum |after - before|^2 of the MER symbol (pre-zeroed)
     double *cfr_papr;         // [frame][nb_symbols+1][4]: peak, mean of |x|^2 before / after CFR (pre-zeroed)
+    // TF_OUT_S16: `out` holds 4-byte s16 pairs; the number of clipped components is ADDED to *clipped
+    unsigned long long *clipped;
 };
 
-enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */ };
+enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */,
+               TF_OUT_S16 = 64 };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0);
 int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
+bool tf_has_s16(const TfArgs &a, unsigned flags);   // a frame-kernel variant stores s16 itself (TF_OUT_S16)
 
 // Stand-alone stage kernels (per-stage drop-ins and the non-fused fallbacks).
 hipError_t launch_qpsk(const uint8_t *in, size_t nbytes, int K, float2 *out, hipStream_t s);
@@ -112,6 +116,7 @@ struct ResamplerArgs {
     const float2 *halo;     // nin samples: the two hops before `in` (zeros at stream start)
     float2 *out;            // nhops * nout/2
     const float *poly;      // nullptr, or am[5] at [0..4] and pm[5] at [8..12]: MemlessPoly fused into the store
+    unsigned long long *clipped;   // non-null: store s16 pairs (FormatConverter fused, x2 / x4 kernels with nin = 4096)
     size_t nhops;
     // rational ratios L/M (the general kernel): nout = (nin / M) * L
     int L, M;
@@ -119,5 +124,6 @@ struct ResamplerArgs {
     const float2 *tw_l;     // L entries exp(+2 pi i m / L)
 };
 hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s);
+bool resampler_has_s16(const ResamplerArgs &a);
 
 }  // namespace dabgpu

@@ -148,6 +148,18 @@ DEV c2 cmul(c2 a, cf w)
 DEV c2 cmul(c2 a, cf w) { return c2{a.re * w.x - a.im * w.y, a.re * w.y + a.im * w.x}; }
 #endif
 
+// a * b + c on both halves, as ONE packed FMA whatever the surrounding code looks like.  A sum of two products
+// written with operators (x * y - z * w) leaves the choice of the product that is fused to the instruction selector,
+// and that choice can differ between two instantiations of the same kernel: the variants of a kernel that differ
+// in their output format only must produce the same floats.
+typedef float v2f_ __attribute__((ext_vector_type(2)));
+DEV float2 pk_fma(float2 a, float2 b, float2 c)
+{
+    const v2f_ r = __builtin_elementwise_fma(v2f_{a.x, a.y}, v2f_{b.x, b.y}, v2f_{c.x, c.y});
+    return make_float2(r.x, r.y);
+}
+DEV float2 pk_neg(float2 a) { return make_float2(-a.x, -a.y); }
+
 // multiply by (S * i)
 template <int S> DEV cf mul_i(cf a) { return S > 0 ? mk(-a.y, a.x) : mk(a.y, -a.x); }
 template <int S> DEV c2 mul_i(c2 a) { return S > 0 ? c2{-a.im, a.re} : c2{a.im, -a.re}; }
@@ -180,7 +192,7 @@ template <int S, typename V> DEV void dft4(V &x0, V &x1, V &x2, V &x3)
 #define DABGPU_FOLD_ROT 1
 #endif
 DEV cf axpy(cf a, float c, cf b) { return mk(fmaf(c, b.x, a.x), fmaf(c, b.y, a.y)); }          // a + c b
-DEV c2 axpy(c2 a, float c, c2 b) { return c2{a.re + c * b.re, a.im + c * b.im}; }
+DEV c2 axpy(c2 a, float c, c2 b) { return c2{pk_fma(b.re, make_float2(c, c), a.re), pk_fma(b.im, make_float2(c, c), a.im)}; }
 template <int S> DEV cf urot1(cf b) { return mk(b.x - S * b.y, S * b.x + b.y); }                // sqrt(2) exp(S i pi/4) b
 template <int S> DEV cf urot3(cf b) { return mk(-b.x - S * b.y, S * b.x - b.y); }               // sqrt(2) exp(S 3 i pi/4) b
 template <int S> DEV c2 urot1(c2 b) { return c2{b.re - (float)S * b.im, (float)S * b.re + b.im}; }
@@ -268,7 +280,7 @@ template <int S> DEV void twiddle_dft8(c2 *v, const cf *w)
     for (int i = 0; i < 4; ++i) {
         const c2 u = i == 0 ? v[0] : cmul(v[i], w[i - 1]);
         a[i] = cfma(u, v[i + 4], w[i + 3]);
-        b[i] = c2{u.re * 2.0f - a[i].re, u.im * 2.0f - a[i].im};
+        b[i] = c2{pk_fma(u.re, make_float2(2.0f, 2.0f), pk_neg(a[i].re)), pk_fma(u.im, make_float2(2.0f, 2.0f), pk_neg(a[i].im))};
     }
     dft4<S>(a[0], a[1], a[2], a[3]);
     dft8_odd<S>(b[0], b[1], b[2], b[3]);
@@ -852,6 +864,28 @@ template <int NTP, int R> DEV void fir_block(const cf *__restrict__ lane, const 
 }
 
 // ---------------------------------------------------------------------------
+// f-2 fused into the chain's last store: cf32 -> s16 with FormatConverter's range test, truncation toward zero and
+// clipped-component count (reference src/FormatConverter.cpp:111-143), one 4-byte word per complex sample.
+DEV int s16_one(float x, unsigned &clipped)
+{
+    if (x < -32768.0f) { ++clipped; return -32768; }
+    if (x > 32767.0f) { ++clipped; return 32767; }
+    return (int)x;                        // v_cvt_i32_f32: toward zero, NaN -> 0
+}
+DEV uint32_t s16_pack(cf y, unsigned &clipped)
+{
+    const int re = s16_one(y.x, clipped), im = s16_one(y.y, clipped);
+    return (uint32_t)(re & 0xffff) | ((uint32_t)im << 16);
+}
+// per-workgroup epilogue of a kernel that stored s16: the lanes' clip counts, summed per wave, onto the call's counter
+DEV void s16_flush_count(unsigned nclip, unsigned long long *total)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) nclip += __shfl_xor(nclip, o, 64);
+    if ((threadIdx.x & 63) == 0 && nclip) atomicAdd(total, (unsigned long long)nclip);
+}
+
+// ---------------------------------------------------------------------------
 // cos/sin of p*45deg as {-1,0,+1} codes: (CX >> 2p) & 3 = value + 1
 constexpr unsigned kCX = 0x901Au;
 #ifndef DABGPU_KBND
@@ -888,8 +922,10 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // ZONLY (Mode I with the fused FIR and no gain statistics over the time domain: the coded-bits path with gain fix / var,
 // the carriers path with gain var or none): the unfiltered transform is formed only where
 // the boundary FIR reads it (Fft::run_dual_zonly).
+// OFMT = 1: the output is s16 (4 bytes per sample, FormatConverter semantics) instead of cf32 -- instantiated for the
+// production variants only (Mode I coded-bits chain, default filter); everything else converts in format_kernel.
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
-          bool ZONLY = false>
+          bool ZONLY = false, int OFMT = 0>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
                              (!FIR || CFR) ? 2 : (GVAR ? DABGPU_GVAR_WAVES
                                                   : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2 : DABGPU_TF_WAVES)))
@@ -1012,6 +1048,11 @@ void tf_kernel(const TfArgs a)
     const cf *fcar = FROM_BITS ? nullptr
                                : a.carriers + (size_t)frame * (size_t)nsym * (size_t)K;
     cf *fout = a.out + (size_t)frame * a.out_stride;
+    uint32_t *fout16 = reinterpret_cast<uint32_t *>(a.out) + (size_t)frame * a.out_stride;   // OFMT = 1
+    unsigned nclip = 0;
+    auto put = [&](size_t idx, cf y) __attribute__((always_inline)) {
+        if (OFMT == 1) fout16[idx] = s16_pack(y, nclip); else fout[idx] = y;
+    };
 
     // advance the differential state over one data block (K/4 bytes: I bits, then Q bits)
     // held in LDS or in global memory; the 12 byte reads are issued together
@@ -1311,7 +1352,7 @@ void tf_kernel(const TfArgs a)
             }
             acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);   // the 4 lanes of an output
             acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);   // are one DPP quad
-            if (i < C && q == 0) fout[prev_pos + (size_t)(prev_seg - C + i)] = acc;
+            if (i < C && q == 0) put(prev_pos + (size_t)(prev_seg - C + i), acc);
         }
     };
 
@@ -1328,7 +1369,7 @@ void tf_kernel(const TfArgs a)
     int s_loop = s_begin;
     if (FROM_BITS && s_begin == 0) {
         const int nz = len0 - C;                      // the last C outputs belong to `boundary`
-        for (int i = t; i < nz; i += (int)blockDim.x) fout[i] = mk(0.f, 0.f);
+        for (int i = t; i < nz; i += (int)blockDim.x) put((size_t)i, mk(0.f, 0.f));
         if (FIR) {
             for (int i = t; i < KB; i += (int)blockDim.x) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
             have_prev = true;
@@ -1544,8 +1585,8 @@ void tf_kernel(const TfArgs a)
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
                 const cf y = scaled(v[m]);
-                if (!FIR || n < N - C) fout[pos + cpl + n] = y;            // FIR: the last C belong to `boundary`
-                if (m > m_cp || (m == m_cp && n >= N - cpl)) fout[pos + n - (N - cpl)] = y;
+                if (!FIR || n < N - C) put(pos + cpl + n, y);              // FIR: the last C belong to `boundary`
+                if (m > m_cp || (m == m_cp && n >= N - cpl)) put(pos + n - (N - cpl), y);
             }
         }
         have_prev = true;
@@ -1560,6 +1601,7 @@ void tf_kernel(const TfArgs a)
         lds_barrier();
         boundary(bnd + cur * 2 * KB);
     }
+    if (OFMT == 1) s16_flush_count(nclip, a.clipped);
 }
 
 template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)
@@ -1580,6 +1622,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
+    if ((flags & TF_OUT_S16) && !tf_has_s16(a, flags)) return hipErrorInvalidValue;
     if (flags & TF_CFR) {
         // with the whole fused epilogue (guard + FIR) or with none of it
         if (gd != fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
@@ -1609,10 +1652,17 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     }
     if (LOGN == 11 && NT == 45 && fb && fr && gd && DABGPU_ZONLY && (!gn || a.gain.mode != 1)) {
         // Mode I, default filter length, gain fix / var (or none): the variant that prunes the unfiltered transform
+        if (flags & TF_OUT_S16) {
+            if (!a.clipped) return hipErrorInvalidValue;
+            if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true, 1>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true, 1>), grid, block, lds, s, a);
+            return hipGetLastError();
+        }
         if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true>), grid, block, lds, s, a);
         else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
         return hipGetLastError();
     }
+    if (flags & TF_OUT_S16) return hipErrorInvalidValue;         // (callers ask tf_has_s16 first)
     if (fb) {
         if (gn) { if (fr) TF_LAUNCH(true, true, true, true); else if (gd) TF_LAUNCH(true, true, true, false); else TF_LAUNCH(true, true, false, false); }
         else    { if (fr) TF_LAUNCH(true, false, true, true); else if (gd) TF_LAUNCH(true, false, true, false); else TF_LAUNCH(true, false, false, false); }
@@ -1648,6 +1698,15 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
 }
 
 int tf_max_fused_taps() { return DABGPU_KBND < kMaxTaps ? DABGPU_KBND : kMaxTaps; }
+
+// the frame-kernel variants that store s16 themselves: Mode I coded-bits chain, guard + default-length filter,
+// gain none / fix / var, no CFR
+bool tf_has_s16(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
+    return DABGPU_ZONLY && a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & TF_CFR) &&
+           (!(flags & TF_GAIN) || a.gain.mode != 1);
+}
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
 {
@@ -2336,22 +2395,26 @@ DEV cf poly_apply(cf x, const PolyCoef &c)
 // two samples at a time: every operation is a packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32)
 DEV void poly_apply2(cf &s0, cf &s1, const PolyCoef &c)
 {
+    // (every multiply-add spelled as an explicit packed FMA: see pk_fma)
+    auto k = [](float v) __attribute__((always_inline)) { return make_float2(v, v); };
     const float2 x = make_float2(s0.x, s1.x), y = make_float2(s0.y, s1.y);
-    const float2 m = x * x + y * y;
-    const float2 a = c.a0 + m * (c.a1 + m * (c.a2 + m * (c.a3 + m * c.a4)));
-    const float2 p = -1.0f * (c.p0 + m * (c.p1 + m * (c.p2 + m * (c.p3 + m * c.p4))));
+    const float2 m = pk_fma(x, x, y * y);
+    const float2 a = pk_fma(m, pk_fma(m, pk_fma(m, pk_fma(m, k(c.a4), k(c.a3)), k(c.a2)), k(c.a1)), k(c.a0));
+    const float2 p = pk_neg(pk_fma(m, pk_fma(m, pk_fma(m, pk_fma(m, k(c.p4), k(c.p3)), k(c.p2)), k(c.p1)), k(c.p0)));
     const float2 q = p * p;
-    const float2 cr = (1.0f - q * (-0.5f + q * (0.486666f + q * (-0.00138888f))));
-    const float2 ci = p * (1.0f + q * (0.166666f + q * (0.00833333f)));
+    const float2 cr = pk_fma(pk_neg(q), pk_fma(q, pk_fma(q, k(-0.00138888f), k(0.486666f)), k(-0.5f)), k(1.0f));
+    const float2 ci = p * pk_fma(q, pk_fma(q, k(0.00833333f), k(0.166666f)), k(1.0f));
     const float2 sr = x * a, si = y * a;
-    const float2 re = sr * cr - si * ci, im = sr * ci + si * cr;
+    const float2 re = pk_fma(sr, cr, pk_neg(si * ci)), im = pk_fma(sr, ci, si * cr);
     s0 = mk(re.x, im.x);
     s1 = mk(re.y, im.y);
 }
 
-template <int LOGNIN, int Q, bool POLY> __global__ __launch_bounds__((1 << LOGNIN) / 8)
+// S16: FormatConverter fused into the store (4-byte s16 pairs, clipped components counted into *a.clipped)
+template <int LOGNIN, int Q, bool POLY, bool S16 = false> __global__ __launch_bounds__((1 << LOGNIN) / 8)
 void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 {
+    unsigned nclip = 0;
     typedef Fft<LOGNIN> F;
     constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q, NOUT = NIN * Q;
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -2465,8 +2528,9 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
                     const float2 wr = make_float2(wp[pa].x, wp[pb < Q ? pb : 0].x), wi = make_float2(wp[pa].y, wp[pb < Q ? pb : 0].y);
                     const cf ra = branch_rot(pa, m), rb = branch_rot(pb, m);
                     const float2 rr = make_float2(ra.x, rb.x), ri = make_float2(ra.y, rb.y);
-                    const float2 yr = G[m].x * wr - G[m].y * wi, yi = G[m].x * wi + G[m].y * wr;
-                    v2[m] = c2{yr * rr - yi * ri, yr * ri + yi * rr};
+                    const float2 gx = make_float2(G[m].x, G[m].x), gy = make_float2(G[m].y, G[m].y);
+                    const float2 yr = pk_fma(gx, wr, pk_neg(gy * wi)), yi = pk_fma(gx, wi, gy * wr);
+                    v2[m] = c2{pk_fma(yr, rr, pk_neg(yi * ri)), pk_fma(yr, ri, yi * rr)};
                     if (m == HIN / T && t == 0) {
                         const float2 ny2 = make_float2(nyq_scale(pa), nyq_scale(pb));
                         v2[m] = c2{G[m].x * ny2, G[m].y * ny2};
@@ -2534,17 +2598,26 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
         // slot, so HBM sees whole 32-byte sectors (16-byte pairs stored a transform apart cost 1.5x
         // the write traffic)
         cf *dst = a.out + (size_t)h * HOUT;
+        uint32_t *dst16 = reinterpret_cast<uint32_t *>(a.out) + (size_t)h * HOUT;
 #pragma unroll
         for (int m = 0; m < 4; ++m) {
             float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m));
+            uint32_t w16[Q];
 #pragma unroll
             for (int p = 0; p < Q; p += 2) {
                 cf a0 = o[m * Q + p], a1 = o[m * Q + p + 1];
                 if (POLY) poly_apply2(a0, a1, pc);
-                d4[p / 2] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                if (S16) { w16[p] = s16_pack(a0, nclip); w16[p + 1] = s16_pack(a1, nclip); }
+                else d4[p / 2] = make_float4(a0.x, a0.y, a1.x, a1.y);
+            }
+            if (S16) {
+                uint32_t *d = dst16 + (size_t)Q * (t + T * m);
+                if (Q == 4) *reinterpret_cast<uint4 *>(d) = make_uint4(w16[0], w16[1], w16[2 % Q], w16[3 % Q]);
+                else *reinterpret_cast<uint2 *>(d) = make_uint2(w16[0], w16[1]);
             }
         }
     }
+    if (S16) s16_flush_count(nclip, a.clipped);
 }
 
 // ---------------------------------------------------------------------------
@@ -3147,10 +3220,26 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
     const bool poly = a.poly != nullptr;
     switch (Q) {
         case 2:
+            if (a.clipped) {
+                if constexpr (LOGNIN == 12) {
+                    if (poly) hipLaunchKernelGGL((resampler_kernel<12, 2, true, true>), grid, block, lds, s, a, hpr);
+                    else hipLaunchKernelGGL((resampler_kernel<12, 2, false, true>), grid, block, lds, s, a, hpr);
+                    break;
+                }
+                return hipErrorInvalidValue;
+            }
             if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, true>), grid, block, lds, s, a, hpr);
             else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
             break;
         case 4:
+            if (a.clipped) {
+                if constexpr (LOGNIN == 12) {
+                    if (poly) hipLaunchKernelGGL((resampler_kernel<12, 4, true, true>), grid, block, lds, s, a, hpr);
+                    else hipLaunchKernelGGL((resampler_kernel<12, 4, false, true>), grid, block, lds, s, a, hpr);
+                    break;
+                }
+                return hipErrorInvalidValue;
+            }
             if (LOGNIN == 12 && DABGPU_RS4_WIDE) {
                 // two 256-lane workgroups per CU (74 KB of LDS each) instead of one 512-lane workgroup
                 const size_t lds4 = (size_t)Fft<12>::LDS_ELEMS * 16 + (2 + 56 + 448) * sizeof(float2);
@@ -3171,9 +3260,16 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
 
 }  // namespace
 
+// the kernels that store s16 themselves: x2 and x4 at nin = 4096 (Mode I)
+bool resampler_has_s16(const ResamplerArgs &a)
+{
+    return a.nin == 4096 && a.nout % a.nin == 0 && (a.nout / a.nin == 2 || a.nout / a.nin == 4);
+}
+
 hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s)
 {
     if (a.nhops == 0) return hipSuccess;
+    if (a.clipped && !resampler_has_s16(a)) return hipErrorInvalidValue;
     if (a.nout == a.nin || a.nout < 2 || (a.nout & 1)) return hipErrorInvalidValue;
     const bool fast = a.nout % a.nin == 0 && (a.nout / a.nin == 2 || a.nout / a.nin == 4);
     if (!fast && a.poly) return hipErrorInvalidValue;        // the general kernel has no fused predistorter

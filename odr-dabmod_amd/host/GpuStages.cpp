@@ -819,6 +819,11 @@ DabGpuChain::DabGpuChain(const Settings &s) : m_ctx(static_cast<int>(s.dabMode),
             m_ctx.check(dabgpu_set_fir_taps(m_ctx.get(), taps.data(), taps.size()));
         }
     }
+    if (s.outputFormat != "complexf") {
+        const int code = format_code(s.outputFormat);
+        if (!code) throw std::runtime_error("FormatConverter: Invalid format " + s.outputFormat);
+        m_ctx.check(dabgpu_set_output_format(m_ctx.get(), code));
+    }
     if (s.outputRate != 2048000) {
         m_mask |= DABGPU_STAGE_RESAMPLE;
         m_ctx.check(dabgpu_set_resampler(m_ctx.get(), 2048000, s.outputRate));
@@ -846,6 +851,13 @@ DabGpuChain::DabGpuChain(const Settings &s) : m_ctx(static_cast<int>(s.dabMode),
             throw std::runtime_error("MemlessPoly: coef file has unknown format");
         }
     }
+}
+
+size_t DabGpuChain::get_num_clipped_samples() const
+{
+    size_t n = 0;
+    m_ctx.check(dabgpu_get_num_clipped(m_ctx.get(), &n));
+    return n;
 }
 
 int DabGpuChain::process(Buffer *const dataIn, Buffer *dataOut)

@@ -308,10 +308,15 @@ public:
         tii_config_t tiiConfig;           // TII on every other frame of the stream (modes I and II)
         bool enableCfr = false;           // crest-factor reduction inside OfdmGenerator
         float cfrClip = 1.0f, cfrErrorClip = 1.0f;
+        // "complexf" (default), "s16", "u8" or "s8": FormatConverter as the chain's last step
+        // (src/DabModulator.cpp:270-276, :407) -- for s16 the last kernel stores the integers itself
+        std::string outputFormat = "complexf";
     };
     explicit DabGpuChain(const Settings &s);
     int process(Buffer *const dataIn, Buffer *dataOut) override;
     const char *name() override { return "DabGpuChain"; }
+    // FormatConverter::get_num_clipped_samples of the most recent frame (src/FormatConverter.cpp:56-59)
+    size_t get_num_clipped_samples() const;
 
 private:
     dabgpu_host::Context m_ctx;

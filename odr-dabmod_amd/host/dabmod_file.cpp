@@ -44,6 +44,7 @@ int main(int argc, char **argv)
     DabGpuChain::Settings gs;
     gs.dabMode = 0;
     std::string format = "complexf";
+    bool separate_converter = false;
     int loops = 1;
     bool bits_only = false;
     try {
@@ -55,6 +56,7 @@ int main(int argc, char **argv)
             };
             if (a == "--mode") gs.dabMode = static_cast<unsigned>(std::stoul(val()));
             else if (a == "--format") format = val();
+            else if (a == "--separate-converter") separate_converter = true;
             else if (a == "--gainmode") {
                 const std::string m = val();
                 gs.gainMode = m == "fix" ? GainMode::GAIN_FIX : m == "max" ? GainMode::GAIN_MAX : GainMode::GAIN_VAR;
@@ -117,8 +119,11 @@ int main(int argc, char **argv)
                     continue;
                 }
                 if (!chain) {
+                    // the output format is the chain's own last step (stored by its last kernel for s16); the
+                    // stand-alone FormatConverter plugin stays available with --separate-converter
+                    if (!separate_converter) gs.outputFormat = format;
                     chain.reset(new DabGpuChain(gs));
-                    if (format != "complexf") converter.reset(new FormatConverter(false, format));
+                    if (separate_converter && format != "complexf") converter.reset(new FormatConverter(false, format));
                 }
                 chain->process(&bits, &iq);
                 const Buffer *o = &iq;
@@ -126,6 +131,8 @@ int main(int argc, char **argv)
                     converter->process(&iq, &converted);
                     clipped += converter->get_num_clipped_samples();
                     o = &converted;
+                } else if (format != "complexf") {
+                    clipped += chain->get_num_clipped_samples();
                 }
                 out.write(static_cast<const char *>(o->getData()), static_cast<std::streamsize>(o->getLength()));
             }
@@ -135,7 +142,7 @@ int main(int argc, char **argv)
             }
         }
         std::fprintf(stderr, "dabmod_file: %zu ETI frames -> %zu transmission frames (mode %u)", n_eti, n_tf, gs.dabMode);
-        if (converter) std::fprintf(stderr, ", %zu clipped components", clipped);
+        if (format != "complexf") std::fprintf(stderr, ", %zu clipped components", clipped);
         std::fprintf(stderr, "\n");
         std::printf("%zu %zu\n", n_eti, n_tf);
         return 0;

@@ -1022,3 +1022,95 @@ def test_async_host_path_zero_copy_buffer_lifetime(pkg):
     finally:
         sync.close()
         asyn.close()
+
+
+# --------------------------------------------------------------------------- f-2 fused into the chain
+def _chain_formats_case(pkg, mode, stages, fmt, setup, n_frames=2, seed=1900):
+    """The chain with an integer output format against FormatConverter applied to the chain's own complexf output:
+    the conversion is integer work on identical floats, so the bytes and the clip count must be equal."""
+    md = pkg.Modulator(mode=mode, max_frames=n_frames)
+    try:
+        setup(md)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=seed + i) for i in range(n_frames)])
+        yf = md.chain(bits, stages)                       # complexf
+        want, clipped = md.format_convert(yf.reshape(-1), fmt)
+        md.set_resampler(2048000, 2048000 if not (stages & pkg.STAGE_RESAMPLE) else md._rs_out)   # fresh resampler state
+        md.set_output_format(fmt)
+        yi = md.chain(bits, stages)
+        assert yi.dtype == want.dtype and yi.size == want.size
+        assert np.array_equal(yi.reshape(-1), want)
+        assert md.num_clipped() == clipped
+        return clipped
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("gain", [(2, 1.0), (2, 2.5), (0, 1.0), (None, 0)])
+def test_chain_s16_stored_by_the_frame_kernel(pkg, gain):
+    """cfg 3 with s16 output: tf_kernel<..., OFMT = 1> stores the integers itself (half the bytes written)."""
+    def setup(md):
+        md._rs_out = 2048000
+        if gain[0] is not None:
+            md.set_gain(gain[0], gain[1], 1.0, 4.0)      # file normalisation: samples up to ~ +-40000 at digital 2.5
+    stages = pkg.STAGE_FIR | (pkg.STAGE_GAIN if gain[0] is not None else 0)
+    clipped = _chain_formats_case(pkg, 1, stages, "s16", setup)
+    if gain == (2, 2.5):
+        assert clipped > 0                                # the clip counter is exercised
+
+
+@pytest.mark.parametrize("out_rate,poly", [(8192000, True), (8192000, False), (4096000, True)])
+def test_chain_s16_stored_by_the_resampler(pkg, out_rate, poly):
+    """cfg 4 with s16 output: the x2 / x4 resampler converts in its store (polynomial predistorter before it)."""
+    def setup(md):
+        md._rs_out = out_rate
+        md.set_gain(2, 1.0, 30000.0 / 50000.0, 4.0)      # |x| < 1 for the polynomial, then a visible integer range
+        md.set_resampler(2048000, out_rate)
+        if poly:
+            md.set_poly(POLY_AM, POLY_PM)
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | (pkg.STAGE_POLY if poly else 0)
+    _chain_formats_case(pkg, 1, stages, "s16", setup)
+
+
+@pytest.mark.parametrize("case", ["mode2", "u8", "s8", "tii", "windowed", "rational", "nofir"])
+def test_chain_output_format_on_every_other_path(pkg, case):
+    """Where no kernel variant stores the format itself the chain converts in format_kernel: same bytes."""
+    mode = 2 if case == "mode2" else 1
+    fmt = case if case in ("u8", "s8") else "s16"
+
+    def setup(md):
+        md._rs_out = 2048000
+        md.set_gain(2, 1.0, 1.0 if fmt == "s16" else 1.0 / 256.0, 4.0)
+        if case == "tii":
+            md.set_tii(True, 3, 5)
+        if case == "windowed":
+            md.set_window_overlap(10)
+        if case == "rational":
+            md._rs_out = 3072000
+            md.set_resampler(2048000, 3072000)
+    stages = pkg.STAGE_GAIN | (0 if case == "nofir" else pkg.STAGE_FIR) | (pkg.STAGE_RESAMPLE if case == "rational" else 0)
+    _chain_formats_case(pkg, mode, stages, fmt, setup)
+
+
+def test_async_host_path_with_s16_output(pkg):
+    """submit / collect with the fused s16 store: half the bytes cross PCIe; same integers as the synchronous call."""
+    per = O.tf_input_bytes(1)
+    batches = [np.stack([synth_bits(per, seed=2100 + 2 * b + i) for i in range(2)]) for b in range(3)]
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR
+    sync, asyn = pkg.Modulator(mode=1, max_frames=2), pkg.Modulator(mode=1, max_frames=2)
+    try:
+        for md in (sync, asyn):
+            md.set_gain(2, 1.0, 1.0, 4.0)
+            md.set_output_format("s16")
+        want = [sync.chain(b, stages).reshape(-1) for b in batches]
+        assert want[0].dtype == np.int16 and want[0].size == 2 * 2 * 196608
+        for b in batches[:2]:
+            asyn.submit(b, stages)
+        got = [asyn.collect()]
+        asyn.submit(batches[2], stages)
+        got += [asyn.collect(), asyn.collect()]
+        for g, w in zip(got, want):
+            assert np.array_equal(g, w)
+    finally:
+        sync.close()
+        asyn.close()

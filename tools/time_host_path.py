@@ -6,9 +6,13 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import numpy as np
 P = importlib.import_module("odr-dabmod_amd")
+FMT = sys.argv[1] if len(sys.argv) > 1 else None       # e.g. s16: FormatConverter fused into the chain's last store
+BPS = 8 if FMT is None else 4
+print("output format:", FMT or "complexf")
 for B in (1, 8, 64):
     md = P.Modulator(mode=1, max_frames=B)
-    md.set_gain(2, 1.0, 1 / 50000., 4.0)
+    md.set_gain(2, 1.0, 1 / 50000. if FMT is None else 1.0, 4.0)
+    md.set_output_format(FMT)
     bits = np.frombuffer(np.random.RandomState(1).bytes(B * 28800), np.uint8).reshape(B, 28800)
     for _ in range(3): md.chain(bits, 3)
     n = max(3, 256 // B)
@@ -16,12 +20,13 @@ for B in (1, 8, 64):
     for _ in range(n): md.chain(bits, 3)
     dt = time.perf_counter() - t0
     print("B=%3d  %8.0f frames/s  (%.2f ms per call, %.2f GB/s of IQ to the host)"
-          % (B, B * n / dt, dt / n * 1e3, B * n * 1572864 / dt / 1e9), flush=True)
+          % (B, B * n / dt, dt / n * 1e3, B * n * 196608 * BPS / dt / 1e9), flush=True)
     md.close()
 print("asynchronous (submit / collect, two batches in flight, pinned output handed out without a copy):")
-for B in (1, 8):
+for B in (1, 8, 32):
     md = P.Modulator(mode=1, max_frames=B)
-    md.set_gain(2, 1.0, 1 / 50000., 4.0)
+    md.set_gain(2, 1.0, 1 / 50000. if FMT is None else 1.0, 4.0)
+    md.set_output_format(FMT)
     bits = np.frombuffer(np.random.RandomState(1).bytes(B * 28800), np.uint8).reshape(B, 28800)
     md.submit(bits, 3)
     for _ in range(4):
@@ -34,5 +39,5 @@ for B in (1, 8):
     dt = time.perf_counter() - t0
     md.collect(copy=False)
     print("B=%3d  %8.0f frames/s  (%.2f ms per batch, %.2f GB/s of IQ to the host)"
-          % (B, B * n / dt, dt / n * 1e3, B * n * 1572864 / dt / 1e9), flush=True)
+          % (B, B * n / dt, dt / n * 1e3, B * n * 196608 * BPS / dt / 1e9), flush=True)
     md.close()
