@@ -48,10 +48,22 @@ def pkg():
     return mod
 
 
-def cpu_baseline(workload, seconds_budget=12.0):
-    """The oracle's chain (kind "port": -O3 -march=native build of oracle/dab_oracle.c) timed on a
-    bounded sample of the same workload: one independent stream per host core (the oracle is plain C
-    behind ctypes, which releases the GIL), and the single-core figure beside it."""
+def cpu_model():
+    try:
+        for l in open("/proc/cpuinfo"):
+            if l.startswith("model name"):
+                return l.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(workload, seconds_budget=14.0):
+    """The oracle's chain (kind "port": the -O3 -march=native build of oracle/dab_oracle.c with fp32 radix-4
+    transforms, liboracle_fast.so) timed on a bounded sample of the same workload, in the shape SURVEY 8(d) asks for:
+    (i) ONE stream in the reference's threading model -- modulator thread + one thread per PipelinedModCodec
+    (GainControl, FIRFilter, MemlessPoly), MemlessPoly split over further workers (src/ModPlugin.cpp:90-154);
+    (ii) S = cores / 4 such streams side by side (`value`); and the plain single-thread figure."""
     import threading
     import numpy as np
     import oracle as O
@@ -64,7 +76,8 @@ def cpu_baseline(workload, seconds_budget=12.0):
     else:
         kw.update(stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000,
                   am=(1.0, 0.05, -0.01, 0.002, 0.0), pm=(0.0, 0.02, 0.003, 0.0, 0.0))
-    bits = np.stack([synth_bits(28800, seed=500 + i) for i in range(4)])
+    nb = 8
+    bits = np.stack([synth_bits(28800, seed=500 + i) for i in range(nb)])
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     try:                                   # a container's CPU quota, when there is one (cgroup v2)
         quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
@@ -72,11 +85,13 @@ def cpu_baseline(workload, seconds_budget=12.0):
             cores = max(1, min(cores, -(-int(quota) // int(period))))
     except (OSError, ValueError):
         pass
+    nstreams = max(1, cores // 4)
+    poly_threads = 0 if workload != "cfg4" else max(1, min(8, cores // nstreams - 3))
 
-    def timed_run(nthreads, seconds):
-        """nthreads independent streams, each looping 4-frame calls until the deadline; frames / elapsed."""
+    def timed_run(nthreads, seconds, pipelined):
+        """nthreads independent streams, each looping 8-frame calls until the deadline; frames in / elapsed."""
         chains = [O.Chain(**kw) for _ in range(nthreads)]
-        outs = [np.empty((4, c.out_samples_per_tf), np.complex64) for c in chains]
+        outs = [np.empty((nb, c.out_samples_per_tf), np.complex64) for c in chains]
         for c, o in zip(chains, outs):
             c.process(bits[:1], o[:1])                    # touch the pages before the clock starts
         done = [0] * nthreads
@@ -86,8 +101,11 @@ def cpu_baseline(workload, seconds_budget=12.0):
         def worker(i):
             start.wait()
             while time.perf_counter() < deadline[0]:
-                chains[i].process(bits, outs[i])
-                done[i] += 4
+                if pipelined:
+                    chains[i].process_pipelined(bits, poly_threads, outs[i])
+                else:
+                    chains[i].process(bits, outs[i])
+                done[i] += nb
 
         threads = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
         for t in threads:
@@ -100,13 +118,18 @@ def cpu_baseline(workload, seconds_budget=12.0):
         dt = time.perf_counter() - t0
         return sum(done), dt
 
-    n1, dt1 = timed_run(1, 0.35 * seconds_budget)
-    nn, dtn = timed_run(cores, 0.65 * seconds_budget)
+    n1, dt1 = timed_run(1, 0.2 * seconds_budget, False)
+    np1, dtp1 = timed_run(1, 0.3 * seconds_budget, True)
+    nn, dtn = timed_run(nstreams, 0.5 * seconds_budget, True)
     return {"value": round(nn / dtn, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "single_core_value": round(n1 / dt1, 3),
-            "sample": "%d threads, one independent stream each: %d Mode-I frames of the %s chain in %.1f s "
-                      "(oracle/dab_oracle.c -O3 -march=native); 1 thread: %d frames in %.1f s"
-                      % (cores, nn, workload, dtn, n1, dt1)}
+            "streams": nstreams, "one_stream_reference_threading": round(np1 / dtp1, 3),
+            "single_thread_value": round(n1 / dt1, 3), "cpu_model": cpu_model(),
+            "sample": "%d streams of the %s chain side by side, each in the reference's threading model (modulator "
+                      "thread + one thread per pipelined stage%s): %d Mode-I frames in %.1f s; one such stream: %d "
+                      "frames in %.1f s; one plain thread: %d frames in %.1f s (oracle/dab_oracle.c, "
+                      "-O3 -march=native, fp32 radix-4 transforms)"
+                      % (nstreams, workload, ", %d MemlessPoly workers" % poly_threads if poly_threads else "",
+                         nn, dtn, np1, dtp1, n1, dt1)}
 
 
 def main():
@@ -134,9 +157,11 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
-    def run_workload(workload, B, steps, warmup):
+    def run_workload(workload, B, steps, warmup, fmt=None):
         md = P.Modulator(mode=1, device=local_rank, max_frames=B, chunks_per_frame=args.chunks)
-        md.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        # (s16: file-style normalisation for the native-rate chain, 30000/50000 where the polynomial needs |x| < 1)
+        md.set_gain(P.GAIN_VAR, 1.0, (1.0 if workload != "cfg4" else 0.6) if fmt else 1.0 / 50000.0, 4.0)
+        md.set_output_format(fmt)
         if workload == "cfg2":
             stages, from_bits = 0, False
         elif workload == "ifft_fir_stage":
@@ -166,7 +191,7 @@ def main():
                     ang = (q.float() * 2 + 1) * (np.pi / 4)
                     d_in[f0:f1, 1536:] = torch.polar(torch.ones_like(ang), ang)
                     del q, ang
-            d_out = torch.empty((B, ns), dtype=torch.complex64, device=dev)
+            d_out = torch.empty((B, ns), dtype=torch.complex64 if fmt is None else torch.int32, device=dev)
             h = stream.cuda_stream
 
             def step():
@@ -202,17 +227,45 @@ def main():
     algo = ALGO_BYTES[args.workload]
     achieved = algo * B / (kern_ms * 1e-3) / 1e9  # GB/s per GPU, per-launch HIP-event time
 
-    traffic, busy = None, {}
+    # Profiler counters are not collected by this run: they are REPLAYED from profiles/traffic.json (rocprofv3 PMC passes
+    # of the same workload and batch, tools/profile_all.sh) -- and only while the device sources are the ones those
+    # counters were collected on (source hash); after any kernel change they are dropped until re-profiled.
+    traffic, busy, replay = None, {}, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
         try:
-            t = json.load(open(tp)).get(args.workload)
-            if t and t.get("frames") == B:
+            tj = json.load(open(tp))
+            t = tj.get(args.workload)
+            if tj.get("source_hash") != P.source_hash():
+                replay = "dropped: profiles/traffic.json was collected on other device sources (%s)" % tj.get("source_hash")
+            elif t and t.get("frames") == B:
                 traffic = t.get("hbm_bytes_per_launch")
-                # the kernel is VALU / LDS bound, not HBM bound: utilisation of both from the same rocprofv3 counter runs
                 busy = {k: t[k] for k in ("valu_busy", "lds_busy") if k in t}
+                replay = "profiles/traffic.json (%s, source hash %s)" % (tj.get("profile_dir"), tj.get("source_hash"))
+            else:
+                replay = "dropped: no counters for %d frames per launch" % B
         except Exception:
-            traffic, busy = None, {}
+            traffic, busy, replay = None, {}, "dropped: unreadable profiles/traffic.json"
+
+    # this box's own ceilings next to the nominal 8 TB/s: a fill (write only) and a copy (read + write) over 4 GiB
+    def measured_peaks():
+        n = 1 << 30
+        a = torch.empty(n, dtype=torch.float32, device=dev)
+        b = torch.empty(n, dtype=torch.float32, device=dev)
+        res = {}
+        for name, fn, nbytes in (("fill_GBps", lambda: a.fill_(1.0), 4 * n), ("copy_GBps", lambda: b.copy_(a), 8 * n)):
+            fn()
+            torch.cuda.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            for _ in range(5):
+                fn()
+            e1.record()
+            torch.cuda.synchronize()
+            res[name] = round(nbytes * 5 / (e0.elapsed_time(e1) * 1e-3) / 1e9, 1)
+        del a, b
+        torch.cuda.empty_cache()
+        return res
 
     line = {
         "metric": "Mode-I TX frames/sec (196608 IQ/frame)",
@@ -235,12 +288,23 @@ def main():
                                 "cfg4": "Mode I cfg3 + Resampler 2.048->8.192 Msps + MemlessPoly "
                                         "(BASELINE config 4)"}[args.workload],
                    "frames_per_step_per_gpu": B, "mode": 1, "prewarm_steps": PREWARM, "parallelism": "%d independent streams" % world,
-                   "realtime_multiple": round(value / 10.4167, 1)},
+                   "realtime_multiple": round(value / 10.4167, 1),
+                   "residency": "input and output device-resident (no PCIe in the timed region); the host entry points "
+                                "are PCIe-bound, see DESIGN.md section 6"},
+        # "bound": the roofline the fraction is priced against (HBM).  "limiter": what the counters say
+        # actually limits the kernel -- VALU issue and LDS traffic, both about half busy, not HBM.
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "kernel": "tf_kernel" if args.workload != "cfg4" else "tf_kernel+resampler_kernel",
-                     "algorithmic_bytes_per_frame": algo, "kernel_ms_per_launch": round(kern_ms, 4), **busy},
+                     "algorithmic_bytes_per_frame": algo, "kernel_ms_per_launch": round(kern_ms, 4), **busy,
+                     "limiter": "valu+lds (latency-bound mix; see valu_busy / lds_busy)" if busy else "not profiled for this build",
+                     "counters_source": replay},
     }
+    if rank == 0 and world == 1 and not args.no_extra:
+        try:
+            line["roofline"]["peak_measured_GBps"] = measured_peaks()
+        except Exception as ex:
+            line["roofline"]["peak_measured_GBps"] = {"error": str(ex)[:120]}
 
     if rank == 0 and world == 1:
         if not args.no_extra:
@@ -248,14 +312,19 @@ def main():
             # the other BASELINE configs, and the headline workload one frame at a time (B = 1:
             # what a single real-time stream sees; the frame is split over 11 workgroups)
             bs = min(B, 16384)     # (carrier inputs: 0.95 MB per frame on top of the 1.57 MB of output)
+            # (batch B in {1, 16, 256} next to the best; "_s16": FormatConverter fused into the last store)
             for wl, b2 in (("cfg2", bs), ("ifft_fir_stage", bs), ("cfg4", max(64, bs // 4)),
-                           (args.workload + "_B1", 1)):
+                           (args.workload + "_B1", 1), (args.workload + "_B16", 16), (args.workload + "_B256", 256),
+                           ("cfg3_s16", B), ("cfg4_s16", max(64, bs // 4))):
                 if wl == args.workload:
                     continue
                 try:
-                    k = max(3, args.steps // 4) if b2 > 1 else 200
-                    w2, k2 = run_workload(wl.replace("_B1", ""), b2, k, 1)
-                    gbps = ALGO_BYTES[wl.replace("_B1", "")] * b2 / (k2 * 1e-3) / 1e9
+                    base = wl.split("_B")[0].replace("_s16", "")
+                    k = max(3, args.steps // 4) if b2 > 256 else (200 if b2 == 1 else 50)
+                    w2, k2 = run_workload(base, b2, k, 1, fmt="s16" if wl.endswith("_s16") else None)
+                    algo2 = ALGO_BYTES[base] if not wl.endswith("_s16") else \
+                        28800 + (ALGO_BYTES[base] - 28800) // 2                 # 4 bytes per sample written
+                    gbps = algo2 * b2 / (k2 * 1e-3) / 1e9
                     extra[wl] = {"frames_per_s": round(b2 * k / w2, 2), "frames_per_step": b2,
                                  "achieved_GBps": round(gbps, 2), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4)}
                 except Exception as ex:  # secondary numbers must never break the contract line

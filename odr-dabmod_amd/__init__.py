@@ -42,6 +42,17 @@ class DabGpuError(RuntimeError):
     pass
 
 
+def source_hash():
+    """SHA-256 (first 16 hex digits) over the sources libdabgpu.so is built from: ties a set of profiler counters
+    (profiles/traffic.json) to the kernels they were collected on."""
+    import hashlib
+    h = hashlib.sha256()
+    for name in ("dabgpu_kernels.hip", "dabgpu_api.hip", "dabgpu_internal.h", "Makefile"):
+        h.update(open(os.path.join(_CSRC, name), "rb").read())
+    h.update(open(os.path.join(os.path.dirname(_CSRC), "..", "include", "dabgpu.h"), "rb").read())
+    return h.hexdigest()[:16]
+
+
 def build(verbose=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
     cmd = ["make", "-C", _CSRC, "-j2"]

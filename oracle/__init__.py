@@ -121,6 +121,9 @@ def _load(name):
     lib.dabo_chain_cfr_stats.restype = C.POINTER(_CfrStats)
     lib.dabo_dft_f64.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int]
     lib.dabo_dft_f64.restype = None
+    if hasattr(lib, "dabo_chain_process_pipelined"):      # the baseline build only (-DDABO_FAST)
+        lib.dabo_chain_process_pipelined.argtypes = [C.c_void_p, _U8P, C.c_size_t, C.c_int, _FP,
+                                                     C.POINTER(C.c_size_t)]
     return lib
 
 
@@ -407,6 +410,19 @@ class Chain:
         assert out.dtype == np.complex64 and out.size == n * self.out_samples_per_tf and out.flags.c_contiguous
         _chk(self._l.dabo_chain_process(self._h, bits.ctypes.data_as(_U8P), n, _fp(out)), "chain")
         return out.reshape(n, self.out_samples_per_tf)
+
+    def process_pipelined(self, bits, poly_threads=0, out=None):
+        """CPU-baseline build only (fast=True): the same frames in the reference's threading model -- the caller as
+        modulator thread, GainControl / FIRFilter / MemlessPoly on threads of their own with one frame of latency
+        each (src/ModPlugin.cpp:90-154).  Returns the frames that reached the output (n - pipelined stages)."""
+        bits = _u8(bits).reshape(-1)
+        n = bits.size // self.in_bytes_per_tf
+        if out is None:
+            out = np.empty((n, self.out_samples_per_tf), np.complex64)
+        got = C.c_size_t()
+        _chk(self._l.dabo_chain_process_pipelined(self._h, bits.ctypes.data_as(_U8P), n, poly_threads, _fp(out),
+                                                  C.byref(got)), "chain (pipelined)")
+        return out[:got.value]
 
     def cfr_stats(self, frame):
         """CFR statistics of frame `frame` of the last process() call: (dict, papr[nsym][4]) or None."""

@@ -295,8 +295,111 @@ static void dft_pow2_f64(const double *in, double *out, size_t n, int sign)
     }
 }
 
+#ifdef DABO_FAST
+/* CPU-BASELINE BUILD ONLY (liboracle_fast.so, bench.py's cpu_baseline leg; never the parity oracle): the
+ * power-of-two transforms in fp32, Stockham autosort radix 4 (one radix-2 step when log2 n is odd) with table
+ * twiddles -- the arithmetic class of the reference's FFTW3f plans, so that the timed baseline is not the
+ * float64 radix-2 evaluation the oracle proper uses to define the result. */
+static float *g_ftw[32];   /* per log2 n: n pairs exp(+2 pi i k / n) */
+static const float *fast_twiddles(size_t n)
+{
+    int lg = 0;
+    while (((size_t)1 << lg) < n) ++lg;
+    if (!g_ftw[lg]) {
+        float *t = (float *)malloc(sizeof(float) * 2 * n);
+        for (size_t k = 0; k < n; ++k) {
+            t[2 * k] = (float)cos(2.0 * M_PI * (double)k / (double)n);
+            t[2 * k + 1] = (float)sin(2.0 * M_PI * (double)k / (double)n);
+        }
+        g_ftw[lg] = t;                 /* (a racing second writer computes the same table: one copy leaks) */
+    }
+    return g_ftw[lg];
+}
+
+static void dft_f32_fast(const float *in, float *out, size_t n, int sign, float *work)
+{
+    const float *tw = fast_twiddles(n);
+    const float sg = sign > 0 ? 1.0f : -1.0f;
+    int lg = 0;
+    while (((size_t)1 << lg) < n) ++lg;
+    /* ping-pong so that the last stage lands in `out` */
+    const int nst = lg / 2 + (lg & 1);
+    const float *src = in;
+    float *dst = (nst & 1) ? out : work;
+    size_t ns = 1;
+    if (lg & 1) {
+        for (size_t j = 0; j < n / 2; ++j) {
+            const float ar = src[2 * j], ai = src[2 * j + 1], br = src[2 * (j + n / 2)], bi = src[2 * (j + n / 2) + 1];
+            dst[4 * j] = ar + br; dst[4 * j + 1] = ai + bi;
+            dst[4 * j + 2] = ar - br; dst[4 * j + 3] = ai - bi;
+        }
+        ns = 2;
+        src = dst;
+        dst = (dst == out) ? work : out;
+    }
+    for (; ns < n; ns *= 4) {
+        const size_t q = n / 4, step = n / (4 * ns);
+        if (ns < 16) {
+            /* few butterflies per block: twiddles outermost, the long loop runs over the blocks */
+            for (size_t k = 0; k < ns; ++k) {
+                const float w1r = tw[2 * k * step], w1i = sg * tw[2 * k * step + 1];
+                const float w2r = tw[4 * k * step], w2i = sg * tw[4 * k * step + 1];
+                const float w3r = tw[6 * k * step], w3i = sg * tw[6 * k * step + 1];
+                const float *x0 = src + 2 * k, *x1 = x0 + 2 * q, *x2 = x1 + 2 * q, *x3 = x2 + 2 * q;
+                float *y = dst + 2 * k;
+                const size_t nb = q / ns;
+                for (size_t blk = 0; blk < nb; ++blk) {
+                    const size_t i = 2 * blk * ns, o = 8 * blk * ns;
+                    const float ar = x0[i], ai = x0[i + 1];
+                    const float br = x1[i] * w1r - x1[i + 1] * w1i, bi = x1[i] * w1i + x1[i + 1] * w1r;
+                    const float cr = x2[i] * w2r - x2[i + 1] * w2i, ci = x2[i] * w2i + x2[i + 1] * w2r;
+                    const float dr = x3[i] * w3r - x3[i + 1] * w3i, di = x3[i] * w3i + x3[i + 1] * w3r;
+                    const float s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
+                    const float s2r = br + dr, s2i = bi + di, s3r = -sg * (bi - di), s3i = sg * (br - dr);
+                    y[o] = s0r + s2r; y[o + 1] = s0i + s2i;
+                    y[o + 2 * ns] = s1r + s3r; y[o + 2 * ns + 1] = s1i + s3i;
+                    y[o + 4 * ns] = s0r - s2r; y[o + 4 * ns + 1] = s0i - s2i;
+                    y[o + 6 * ns] = s1r - s3r; y[o + 6 * ns + 1] = s1i - s3i;
+                }
+            }
+            src = dst;
+            dst = (dst == out) ? work : out;
+            continue;
+        }
+        for (size_t blk = 0; blk < q / ns; ++blk) {
+            const float *x0 = src + 2 * (blk * ns), *x1 = x0 + 2 * q, *x2 = x1 + 2 * q, *x3 = x2 + 2 * q;
+            float *y = dst + 2 * (blk * 4 * ns);
+            for (size_t k = 0; k < ns; ++k) {
+                const float w1r = tw[2 * k * step], w1i = sg * tw[2 * k * step + 1];
+                const float w2r = tw[4 * k * step], w2i = sg * tw[4 * k * step + 1];
+                const float w3r = tw[6 * k * step], w3i = sg * tw[6 * k * step + 1];
+                const float ar = x0[2 * k], ai = x0[2 * k + 1];
+                const float br = x1[2 * k] * w1r - x1[2 * k + 1] * w1i, bi = x1[2 * k] * w1i + x1[2 * k + 1] * w1r;
+                const float cr = x2[2 * k] * w2r - x2[2 * k + 1] * w2i, ci = x2[2 * k] * w2i + x2[2 * k + 1] * w2r;
+                const float dr = x3[2 * k] * w3r - x3[2 * k + 1] * w3i, di = x3[2 * k] * w3i + x3[2 * k + 1] * w3r;
+                const float s0r = ar + cr, s0i = ai + ci, s1r = ar - cr, s1i = ai - ci;
+                const float s2r = br + dr, s2i = bi + di, s3r = -sg * (bi - di), s3i = sg * (br - dr);   /* +-i (b - d) */
+                y[2 * k] = s0r + s2r; y[2 * k + 1] = s0i + s2i;
+                y[2 * (k + ns)] = s1r + s3r; y[2 * (k + ns) + 1] = s1i + s3i;
+                y[2 * (k + 2 * ns)] = s0r - s2r; y[2 * (k + 2 * ns) + 1] = s0i - s2i;
+                y[2 * (k + 3 * ns)] = s1r - s3r; y[2 * (k + 3 * ns) + 1] = s1i - s3i;
+            }
+        }
+        src = dst;
+        dst = (dst == out) ? work : out;
+    }
+    if (src != out) memcpy(out, src, sizeof(float) * 2 * n);
+}
+#endif
+
 static void dft_f32_via_f64(const float *in, float *out, size_t n, int sign, double *w0, double *w1)
 {
+#ifdef DABO_FAST
+    if ((n & (n - 1)) == 0 && n >= 4) {
+        dft_f32_fast(in, out, n, sign, (float *)w0);          /* w0 holds 2 n doubles: room for 2 n floats */
+        return;
+    }
+#endif
     for (size_t k = 0; k < 2 * n; ++k) w0[k] = (double)in[k];
     dabo_dft_f64(w0, w1, n, sign);
     for (size_t k = 0; k < 2 * n; ++k) out[k] = (float)w1[k];
@@ -316,6 +419,22 @@ int dabo_ofdm_generate(const float *in, int nsym, int carriers, int spacing, flo
     double *x = (double *)calloc(2 * N, sizeof(double));
     double *y = (double *)malloc(2 * N * sizeof(double));
     if (!x || !y) { free(x); free(y); return -1; }
+#ifdef DABO_FAST
+    {
+        /* (baseline build: fp32 transform, see dft_f32_fast) */
+        float *xf = (float *)x, *wf = (float *)y;
+        for (int s = 0; s < nsym; ++s) {
+            const float *i = in + 2 * (size_t)s * K;
+            memset(xf, 0, 2 * N * sizeof(float));
+            memcpy(xf + 2 * pos_dst, i, 2 * pos_n * sizeof(float));
+            memcpy(xf + 2 * neg_dst, i + 2 * pos_n, 2 * neg_n * sizeof(float));
+            dft_f32_fast(xf, out + 2 * (size_t)s * N, N, +1, wf);
+        }
+        free(x);
+        free(y);
+        return 0;
+    }
+#endif
     for (int s = 0; s < nsym; ++s) {
         const float *i = in + 2 * (size_t)s * K;
         memset(x, 0, 2 * N * sizeof(double));
@@ -649,7 +768,24 @@ const float *dabo_fir_default_taps(int *ntaps)
 void dabo_fir_filter(const float *in, size_t nsamples, const float *taps, int ntaps, float *out)
 {
     const size_t nf = 2 * nsamples;
-    for (size_t i = 0; i < nf; ++i) {
+    size_t i0 = 0;
+#ifdef DABO_FAST
+    /* baseline build: the main loop 16 outputs at a time (the reference's runs 4 at a time in SSE registers,
+     * src/FIRFilter.cpp:168-184), same order of accumulation per output */
+    if (nf > 2 * (size_t)ntaps + 16) {
+        for (; i0 + 16 <= nf - 2 * (size_t)ntaps; i0 += 16) {
+            float acc[16];
+            for (int v = 0; v < 16; ++v) acc[v] = 0.0f;
+            for (int j = 0; j < ntaps; ++j) {
+                const float tp = taps[j];
+                const float *x = in + i0 + 2 * (size_t)j;
+                for (int v = 0; v < 16; ++v) acc[v] += x[v] * tp;
+            }
+            for (int v = 0; v < 16; ++v) out[i0 + v] = acc[v];
+        }
+    }
+#endif
+    for (size_t i = i0; i < nf; ++i) {
         float acc = 0.0f;
         for (int j = 0; j < ntaps && i + 2 * (size_t)j < nf; ++j) {
             const float p = in[i + 2 * (size_t)j] * taps[j];
@@ -932,6 +1068,178 @@ int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float
     }
     return 0;
 }
+
+#ifdef DABO_FAST
+/* ---------------------------------------------------------------------------
+ * CPU-BASELINE BUILD ONLY: one stream in the reference's THREADING MODEL (src/ModPlugin.cpp:90-154).  The caller is
+ * the modulator thread and runs every plain ModCodec (mapper, interleaver, differential modulator, OfdmGenerator,
+ * GuardIntervalInserter, Resampler); GainControl, FIRFilter and MemlessPoly are PipelinedModCodecs: process() hands
+ * the frame to the stage's own thread and returns the PREVIOUS frame's result (nothing on the first call, which
+ * stops the flowgraph walk for that round, src/Flowgraph.cpp:325-337), and MemlessPoly splits every frame over
+ * `poly_threads` workers (src/MemlessPoly.cpp:352-391).  Returns the frames that reached the output. */
+#include <pthread.h>
+
+typedef struct pstage {
+    pthread_t th;
+    pthread_mutex_t mu;
+    pthread_cond_t cv;
+    int busy, has_out, quit;
+    float *in, *out;
+    size_t n;
+    int kind;                 /* 0 gain, 1 fir, 2 poly */
+    dabo_chain *c;
+    int poly_threads;
+} pstage;
+
+typedef struct { const float *in; float *out; size_t n; const dabo_chain *c; } poly_job;
+static void *poly_part(void *p)
+{
+    poly_job *j = (poly_job *)p;
+    dabo_memless_poly(j->in, j->n, j->c->cfg.am, j->c->cfg.pm, j->out);
+    return NULL;
+}
+
+static void pstage_run(pstage *st)
+{
+    dabo_chain *c = st->c;
+    const dabo_mode_t *m = &c->m;
+    if (st->kind == 0) {
+        dabo_gain_control(st->in, st->n, m->spacing, c->cfg.gain_mode, c->cfg.dig_gain, c->cfg.normalise,
+                          c->cfg.var_variance, st->out, NULL);
+    } else if (st->kind == 1) {
+        dabo_fir_filter(st->in, st->n, c->taps, c->cfg.ntaps, st->out);
+    } else {
+        /* worker t handles [t step, (t + 1) step), the stage's own thread the remainder */
+        const int nt = st->poly_threads > 0 ? st->poly_threads : 0;
+        const size_t step = nt ? st->n / (size_t)nt : 0;
+        pthread_t th[64];
+        poly_job job[64];
+        for (int t = 0; t < nt && t < 64; ++t) {
+            job[t].in = st->in + 2 * (size_t)t * step; job[t].out = st->out + 2 * (size_t)t * step;
+            job[t].n = step; job[t].c = c;
+            pthread_create(&th[t], NULL, poly_part, &job[t]);
+        }
+        const size_t done = (size_t)(nt < 64 ? nt : 64) * step;
+        dabo_memless_poly(st->in + 2 * done, st->n - done, c->cfg.am, c->cfg.pm, st->out + 2 * done);
+        for (int t = 0; t < nt && t < 64; ++t) pthread_join(th[t], NULL);
+    }
+}
+
+static void *pstage_main(void *p)
+{
+    pstage *st = (pstage *)p;
+    pthread_mutex_lock(&st->mu);
+    for (;;) {
+        while (!st->busy && !st->quit) pthread_cond_wait(&st->cv, &st->mu);
+        if (st->quit) break;
+        pthread_mutex_unlock(&st->mu);
+        pstage_run(st);
+        pthread_mutex_lock(&st->mu);
+        st->busy = 0;
+        st->has_out = 1;
+        pthread_cond_broadcast(&st->cv);
+    }
+    pthread_mutex_unlock(&st->mu);
+    return NULL;
+}
+
+/* hand `in` (n samples) to the stage with `spare` as its next output buffer; returns the previous result (the
+ * caller owns it now) or NULL on the first call, and *freed = the input buffer the stage has finished with */
+static float *pstage_swap(pstage *st, float *in, size_t n, float *spare, float **freed)
+{
+    pthread_mutex_lock(&st->mu);
+    while (st->busy) pthread_cond_wait(&st->cv, &st->mu);
+    float *res = st->has_out ? st->out : NULL;
+    *freed = st->has_out ? st->in : NULL;
+    st->in = in; st->out = spare; st->n = n; st->has_out = 0; st->busy = 1;
+    pthread_cond_broadcast(&st->cv);
+    pthread_mutex_unlock(&st->mu);
+    return res;
+}
+
+int dabo_chain_process_pipelined(dabo_chain *c, const uint8_t *bits, size_t nframes, int poly_threads, float *out,
+                                 size_t *frames_out)
+{
+    const dabo_mode_t *m = &c->m;
+    const size_t K = (size_t)m->carriers, N = (size_t)m->spacing;
+    const size_t ndata = (size_t)(m->nb_symbols - 1) * K, nsym = (size_t)m->nb_symbols + 1;
+    const size_t tf = dabo_tf_samples(m), inb = dabo_tf_input_bytes(m);
+    const size_t big = (c->out_per_tf > tf ? c->out_per_tf : tf) + 4 * N;
+    float *pool[16];
+    int npool = 0;
+#define GETBUF() (npool ? pool[--npool] : (float *)malloc(sizeof(float) * 2 * big))
+#define PUTBUF(b) do { if (b) pool[npool++] = (b); } while (0)
+    pstage st[3];
+    const int use[3] = {!!(c->cfg.stages & DABO_STAGE_GAIN), !!(c->cfg.stages & DABO_STAGE_FIR),
+                        !!(c->cfg.stages & DABO_STAGE_POLY)};
+    for (int i = 0; i < 3; ++i) {
+        memset(&st[i], 0, sizeof st[i]);
+        if (!use[i]) continue;
+        st[i].kind = i; st[i].c = c; st[i].poly_threads = poly_threads;
+        pthread_mutex_init(&st[i].mu, NULL);
+        pthread_cond_init(&st[i].cv, NULL);
+        pthread_create(&st[i].th, NULL, pstage_main, &st[i]);
+    }
+    size_t nout = 0;
+    int rc = 0;
+    for (size_t f = 0; f < nframes && !rc; ++f) {
+        float *a = GETBUF(), *b = GETBUF(), *freed = NULL, *t;
+        rc |= dabo_qpsk_map(bits + f * inb, inb, m->carriers, a);
+        rc |= dabo_freq_interleave(a, ndata, m->mode, b);
+        memset(a, 0, K * 2 * sizeof(float));
+        rc |= dabo_diff_mod(c->phase, b, ndata, m->carriers, a + 2 * K);
+        rc |= dabo_ofdm_generate(a, (int)nsym, m->carriers, m->spacing, b);
+        PUTBUF(a);
+        float *cur = b;                                           /* OfdmGenerator output */
+        if (use[0]) {
+            t = pstage_swap(&st[0], cur, nsym * N, GETBUF(), &freed);
+            PUTBUF(freed);
+            if (!(cur = t)) continue;
+        }
+        a = GETBUF();
+        rc |= dabo_guard_interval(cur, m->nb_symbols, m->spacing, m->null_size, m->sym_size, c->cfg.window_overlap, a);
+        PUTBUF(cur);
+        cur = a;
+        if (use[1]) {
+            t = pstage_swap(&st[1], cur, tf, GETBUF(), &freed);
+            PUTBUF(freed);
+            if (!(cur = t)) continue;
+        }
+        size_t n = tf;
+        if (c->cfg.stages & DABO_STAGE_RESAMPLE) {
+            a = GETBUF();
+            rc |= dabo_resampler_process(c->rs, cur, tf, a);
+            PUTBUF(cur);
+            cur = a;
+            n = c->out_per_tf;
+        }
+        if (use[2]) {
+            t = pstage_swap(&st[2], cur, n, GETBUF(), &freed);
+            PUTBUF(freed);
+            if (!(cur = t)) continue;
+        }
+        memcpy(out + 2 * nout * c->out_per_tf, cur, n * 2 * sizeof(float));
+        ++nout;
+        PUTBUF(cur);
+    }
+    for (int i = 0; i < 3; ++i) {
+        if (!use[i]) continue;
+        pthread_mutex_lock(&st[i].mu);
+        while (st[i].busy) pthread_cond_wait(&st[i].cv, &st[i].mu);
+        st[i].quit = 1;
+        pthread_cond_broadcast(&st[i].cv);
+        pthread_mutex_unlock(&st[i].mu);
+        pthread_join(st[i].th, NULL);
+        free(st[i].in);
+        free(st[i].out);
+    }
+    while (npool) free(pool[--npool]);
+#undef GETBUF
+#undef PUTBUF
+    if (frames_out) *frames_out = nout;
+    return rc ? -1 : 0;
+}
+#endif
 
 /* ---------------------------------------------------------------------------
  * f-4 TII (reference src/TII.cpp).  The 70 patterns of EN 300 401 table 64 are the 8-bit
