@@ -143,6 +143,9 @@ def main():
     ap.add_argument("--chunks", type=int, default=0, help="workgroups per frame (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
+    ap.add_argument("--gather", type=int, default=0, metavar="FRAMES",
+                    help="after the timed region, gather FRAMES frames of IQ from every rank on rank 0 (the optional "
+                         "final IQ gather over RCCL / xGMI) and report its time separately; 0 = off")
     args = ap.parse_args()
 
     import numpy as np
@@ -216,12 +219,31 @@ def main():
             # barrier + synchronize | K steps | synchronize + barrier, MAX over ranks
             wall = grp.timed(timed_steps, 1, torch.cuda.synchronize)
             ev_ms = e0.elapsed_time(e1)
+            if args.gather > 0 and workload == args.workload:
+                # the optional final IQ gather, OUTSIDE the timed region and reported on its own
+                ng = min(B, args.gather)
+                piece = d_out[:ng].contiguous()
+                stream.synchronize()
+                grp.gather_to_root(piece)                         # communicator warm-up
+                torch.cuda.synchronize()
+                grp.barrier()
+                t0 = time.perf_counter()
+                got = grp.gather_to_root(piece)
+                torch.cuda.synchronize()
+                grp.barrier()
+                dt = grp.max_over_ranks(time.perf_counter() - t0)
+                nbytes = piece.numel() * piece.element_size()
+                gather_info.update({"frames_per_rank": ng, "bytes_per_rank": nbytes, "ms": round(dt * 1e3, 3),
+                                    "GBps_into_rank0": round((world - 1) * nbytes / dt / 1e9, 2) if world > 1 else None,
+                                    "ranks": world})
+                del got, piece
         md.close()
         del d_out, d_in, d_bits
         torch.cuda.empty_cache()
         return wall, ev_ms / steps
 
     B = args.frames
+    gather_info = {}
     wall, kern_ms = run_workload(args.workload, B, args.steps, args.warmup)
     value = grp.job_frames_per_second(B, args.steps, wall)
     algo = ALGO_BYTES[args.workload]
@@ -332,8 +354,10 @@ def main():
             line["other_workloads"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
+    if gather_info:
+        line["iq_gather"] = gather_info
     if rank == 0:
-        print(json.dumps(line), flush=True)
+        grp.emit(json.dumps(line))
     grp.close()
 
 

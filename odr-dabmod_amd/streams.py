@@ -3,25 +3,9 @@ stream of transmission frames (frames are independent units, so the
 path shards with NO data-path collective).  torch.distributed (backend "nccl" =
 RCCL on ROCm, "gloo" in CPU tests) is used only to bracket the timed region and
 to combine the ranks' clocks."""
-import contextlib
 import os
 import sys
 import time
-
-
-@contextlib.contextmanager
-def _stdout_to_stderr():
-    """RCCL prints a version banner on the C-level stdout when a communicator is created; the bench's
-    stdout carries exactly one JSON line, so the banner is sent to stderr."""
-    sys.stdout.flush()
-    saved = os.dup(1)
-    os.dup2(2, 1)
-    try:
-        yield
-    finally:
-        sys.stdout.flush()
-        os.dup2(saved, 1)
-        os.close(saved)
 
 
 class StreamGroup:
@@ -44,9 +28,23 @@ class StreamGroup:
             kw = {}
             if backend == "nccl":
                 kw["device_id"] = torch.device("cuda", self.local_rank)
-            with _stdout_to_stderr():
-                dist.init_process_group(backend, **kw)
-                dist.barrier()                    # communicator creation (and its banner) happens here at the latest
+            # RCCL prints its version banner on the C-level stdout whenever it first creates a communicator -- at
+            # init, at the first collective of a kind, or as late as teardown.  The bench's stdout carries exactly
+            # one JSON line, so for the life of the group file descriptor 1 points at stderr and the line goes out
+            # through a private duplicate of the real stdout (emit()).
+            sys.stdout.flush()
+            self._out_fd = os.dup(1)
+            os.dup2(2, 1)
+            dist.init_process_group(backend, **kw)
+            dist.barrier()
+
+    def emit(self, text):
+        """Write one line to the process's real stdout (see __init__)."""
+        fd = getattr(self, "_out_fd", None)
+        if fd is None:
+            print(text, flush=True)
+        else:
+            os.write(fd, (text + "\n").encode())
 
     def barrier(self):
         if self._collective:
@@ -80,6 +78,26 @@ class StreamGroup:
         """Whole-job throughput: every rank processed frames_per_step_per_gpu * steps frames."""
         return self.world * frames_per_step_per_gpu * steps / seconds
 
+    def gather_to_root(self, t, root=0):
+        """OPTIONAL final gather of the ranks' IQ (north_star: "RCCL over xGMI only for an optional
+        final IQ gather"): every rank's tensor `t` lands on `root`, in rank order.  Never on the modulation path --
+        frames are independent and each stream's sink may just as well sit behind its own GPU.  Over xGMI every
+        non-root rank owns one point-to-point link to the root (~153 GB/s each way), so the root receives
+        (N - 1) * t.nbytes over N - 1 links in parallel: the gather is bound per link by t.nbytes / 153 GB/s, and
+        on the root by its HBM write rate only.  Returns the list of N tensors on the root, None elsewhere."""
+        torch, dist = self._torch, self._dist
+        if not self._collective:
+            return [t]
+        cplx = t.is_complex()
+        if cplx:
+            t = torch.view_as_real(t)            # (RCCL has no complex element type: the same bytes as float pairs)
+        out = [torch.empty_like(t) for _ in range(self.world)] if self.rank == root else None
+        dist.gather(t.contiguous(), out, dst=root)
+        if out is not None and cplx:
+            out = [torch.view_as_complex(o) for o in out]
+        return out
+
     def close(self):
         if self._collective and self._dist.is_initialized():
             self._dist.destroy_process_group()
+        # (fd 1 stays on stderr until the process exits: RCCL may still print while it unloads)

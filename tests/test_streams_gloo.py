@@ -20,7 +20,7 @@ WORKER = textwrap.dedent("""
     calls = []
     el = g.timed(lambda: (calls.append(1), time.sleep(delay)), steps=3, sync=lambda: None)
     fps = g.job_frames_per_second(frames_per_step_per_gpu=100, steps=3, seconds=el)
-    print(json.dumps({"rank": g.rank, "elapsed": el, "fps": fps, "seed": g.stream_seed(), "calls": len(calls)}))
+    g.emit(json.dumps({"rank": g.rank, "elapsed": el, "fps": fps, "seed": g.stream_seed(), "calls": len(calls)}))
     g.close()
 """) % ROOT
 
@@ -57,3 +57,57 @@ def test_two_rank_harness_over_gloo(tmp_path):
     assert abs(outs[0]["fps"] - 600 / outs[0]["elapsed"]) < 1e-6
     assert outs[0]["seed"] != outs[1]["seed"]
     assert outs[0]["calls"] == outs[1]["calls"] == 3
+
+
+WORKER2 = textwrap.dedent("""
+    import importlib, json, os, sys, hashlib
+    sys.path.insert(0, %r)
+    import numpy as np, torch
+    streams = importlib.import_module("odr-dabmod_amd.streams")
+    fe = importlib.import_module("odr-dabmod_amd.frontend")
+    from tests.golden.synth import synth_eti
+    g = streams.StreamGroup(backend="gloo")
+    # one modulator-shaped worker per rank, CPU half: its OWN ETI stream (seeded by the rank) through its own
+    # front-end instance -> the hot path's coded-bits input (on a GPU rank this is what chain_dev consumes)
+    eti = synth_eti(16, seed=g.stream_seed(1234))
+    bits = fe.Frontend().eti_to_bits(eti, 1)
+    assert bits.shape == (4, 28800)
+    mine = hashlib.sha256(bits.tobytes()).hexdigest()
+    # the optional final gather (here: of the coded bits, standing in for the IQ) lands on rank 0 in rank order
+    got = g.gather_to_root(torch.from_numpy(bits.copy()))
+    res = {"rank": g.rank, "sha": mine, "seed": g.stream_seed(1234)}
+    if g.rank == 0:
+        assert len(got) == 2
+        res["gathered"] = [hashlib.sha256(t.numpy().tobytes()).hexdigest() for t in got]
+    else:
+        assert got is None
+    el = g.timed(lambda: fe.Frontend().eti_to_bits(eti, 1), steps=2, sync=lambda: None)
+    res["fps"] = g.job_frames_per_second(4, 2, el)
+    g.emit(json.dumps(res))
+    g.close()
+""") % ROOT
+
+
+def test_two_ranks_modulate_their_own_streams_and_gather(tmp_path):
+    """World size 2 over gloo with real per-rank workers: each rank builds its own front-end on its own seeded ETI
+    stream (distinct input, as on N GPUs), the harness times them, and the optional gather delivers both ranks'
+    frames to rank 0 in order."""
+    import json
+    script = tmp_path / "worker2.py"
+    script.write_text(WORKER2)
+    port = free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2",
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.PIPE, text=True))
+    outs = []
+    for p in procs:
+        o, e = p.communicate(timeout=180)
+        assert p.returncode == 0, e[-2000:]
+        outs.append(json.loads(o.strip().splitlines()[-1]))
+    outs.sort(key=lambda d: d["rank"])
+    assert outs[0]["seed"] != outs[1]["seed"] and outs[0]["sha"] != outs[1]["sha"]      # two different streams
+    assert outs[0]["gathered"] == [outs[0]["sha"], outs[1]["sha"]]                      # rank order on the root
+    assert abs(outs[0]["fps"] - outs[1]["fps"]) < 1e-6 and outs[0]["fps"] > 0
