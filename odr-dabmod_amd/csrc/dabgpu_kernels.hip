@@ -74,6 +74,14 @@
 #ifndef DABGPU_ZONLY
 #define DABGPU_ZONLY 1         // Mode I coded-bits chain with FIR: prune the unfiltered transform to the boundary samples
 #endif
+#ifndef DABGPU_SPLIT_W128
+#define DABGPU_SPLIT_W128 0     // 16-byte exchange elements scattered as two ds_write_b64 (12 LDS-path cycles) instead of one
+                               // ds_write_b128 (13): measured, see DESIGN.md
+#endif
+#ifndef DABGPU_TF_LEAN
+#define DABGPU_TF_LEAN 0        // cfg 3 kernel (Mode I coded-bits chain, ZONLY): LDS trimmed to 40 KB and 128 registers asked for,
+                               // i.e. FOUR workgroups (16 waves) per CU instead of three
+#endif
 #ifndef DABGPU_FFT_DBUF
 #define DABGPU_FFT_DBUF 0      // FIR variants: 1 = two LDS exchange buffers (one barrier per exchange), 0 = one buffer,
                                // two barriers (36 KB of LDS per workgroup -> three workgroups per CU); the
@@ -94,6 +102,9 @@ constexpr float kSqrtHalf = 0.70710678118654752440f;
 // barrier would wait for HBM write acknowledgements.  Nothing in these kernels
 // communicates between waves through global memory, so LDS ordering is all we need.
 DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// (the variant for data that came through a global load on its way into LDS: the compiler's own wait for the load
+// precedes the ds_write, this only orders the write against the other waves)
+DEV void lds_barrier_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 // timing experiments (wrong results): elements per lane that an FFT exchange really moves through LDS
 #ifndef DABGPU_EXPERIMENT_XR
 #define DABGPU_EXPERIMENT_XR 8
@@ -331,6 +342,21 @@ template <int LOGN> struct Fft {
     static constexpr bool X1_ROWS = DABGPU_X1_ROWS && T >= 32;      // (8 (T + 4) elements must fit in LDS_ELEMS)
     template <int NS, typename V> static DEV void xwrite(const V *v, V *lds, int t)
     {
+        if (DABGPU_SPLIT_W128 && sizeof(V) == 16) {
+            // the same image, every element as two 8-byte stores
+            constexpr int PS2 = DABGPU_C2_PAD_SHIFT, P2 = 1 << PS2;
+            constexpr bool PAD2 = (T % P2 == 0) && NS == 1 && !X1_ROWS;
+            const int j0 = (t / NS) * NS * 8 + (t % NS);
+            float2 *wp = reinterpret_cast<float2 *>(lds + ((NS == 1 && X1_ROWS) ? t : (PAD2 ? j0 + (j0 >> PS2) : j0)));
+#pragma unroll
+            for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) {
+                const int e = (NS == 1 && X1_ROWS) ? r * X1_PITCH : (PAD2 ? r * NS + (r * NS) / P2 : r * NS);
+                const float2 *src = reinterpret_cast<const float2 *>(&v[r]);
+                wp[2 * e] = src[0];
+                wp[2 * e + 1] = src[1];
+            }
+            return;
+        }
         if (NS == 1 && X1_ROWS) {
             V *wp = lds + t;
 #pragma unroll
@@ -493,8 +519,9 @@ template <int LOGN> struct Fft {
     //   sample t + 7T (slot 7 = butterfly 1, output 3) reads positions t + 256 + 512 q = stage output 7 of lane (q, t - 192)
     // and the final radix-4 stage runs on the second half (z, natural order) and on that one sample (uedge;
     // meaningful in waves 0 and 3).
-    template <int S, int U8>
-    static DEV void run_dual_zonly(c2 *v, c2 *lds, const cf *tw, int t, const cf *tw8, cf *z, cf &uedge)
+    template <int S, int U8, int U64 = 0>
+    static DEV void run_dual_zonly(c2 *v, c2 *lds, const cf *tw, int t, const cf *tw8, cf *z, cf &uedge,
+                                   const cf *tw64 = nullptr)
     {
         static_assert(LOGN == 11, "geometry of transmission mode I");
         int n = 0;
@@ -508,7 +535,13 @@ template <int LOGN> struct Fft {
         if (U8 == 1) n += 7; else stage_twiddles<S>(tw, n, w);
         twiddle_dft8<S>(v, w);
         exchange<8, false, c2>(v, lds, t);
-        stage_twiddles<S>(tw, n, w);
+        if (U64 == 1) {
+#pragma unroll
+            for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw64[r * 64 + (t & 63)]);
+            n += 7;
+        } else {
+            stage_twiddles<S>(tw, n, w);
+        }
         twiddle_dft8<S>(v, w);
         // third exchange: second half alone, first half's outputs 0 and 7 beside it.  Real and imaginary parts go to
         // separate planes (N floats each, 32 x 256 bytes apart) with ds_write2st64_b32 / ds_read2st64_b32: those take their
@@ -562,9 +595,24 @@ template <int LOGN> struct Fft {
         cf wb[2][3];
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
+            // (U64 = 1, the register-lean build: butterfly 1 takes butterfly 0's twiddles and three fixed rotations
+            // on the products -- W^{r (t + T)} = W^{r t} exp(S i r pi/4) -- instead of six more resident registers)
+            const int bw = U64 == 1 ? 0 : b;
+            if (U64 == 1) {
+                // ... and W^{2t}, W^{3t} as products of the resident W^{t} (one rounding more on two of three twiddles)
+                wb[0][0] = twid<S>(tw[n]);
+                wb[0][1] = cmul(wb[0][0], wb[0][0]);
+                wb[0][2] = cmul(wb[0][1], wb[0][0]);
+            } else {
 #pragma unroll
-            for (int r = 0; r < 3; ++r) wb[b][r] = twid<S>(tw[n + 3 * b + r]);
-            cf x0 = z[b], x1 = cmul(z[b + 2], wb[b][0]), x2 = cmul(z[b + 4], wb[b][1]), x3 = cmul(z[b + 6], wb[b][2]);
+                for (int r = 0; r < 3; ++r) wb[bw][r] = twid<S>(tw[n + 3 * bw + r]);
+            }
+            cf x0 = z[b], x1 = cmul(z[b + 2], wb[bw][0]), x2 = cmul(z[b + 4], wb[bw][1]), x3 = cmul(z[b + 6], wb[bw][2]);
+            if (U64 == 1 && b == 1) {
+                x1 = rot1<S>(x1);
+                x2 = mul_i<S>(x2);
+                x3 = rot3<S>(x3);
+            }
             dft4<S>(x0, x1, x2, x3);
             z[b] = x0; z[b + 2] = x1; z[b + 4] = x2; z[b + 6] = x3;
         }
@@ -928,9 +976,11 @@ template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, boo
           bool ZONLY = false, int OFMT = 0>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
                              (!FIR || CFR) ? 2 : (GVAR ? DABGPU_GVAR_WAVES
-                                                  : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2 : DABGPU_TF_WAVES)))
+                                                  : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2
+                                                     : ((DABGPU_TF_LEAN && ZONLY && FROM_BITS) ? 4 : DABGPU_TF_WAVES))))
 void tf_kernel(const TfArgs a)
 {
+    constexpr bool LEAN = DABGPU_TF_LEAN && ZONLY && FROM_BITS;
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
     static_assert(!CFR || (GUARD == FIR), "CFR variants: the full fused epilogue, or none of it");
     static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR && DABGPU_DUAL_FFT && !DABGPU_FFT_DBUF),
@@ -949,15 +999,20 @@ void tf_kernel(const TfArgs a)
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
     int fpar = 0;                                                       // which half the next exchange uses
     // packed dual transforms (FIR variants) exchange 16-byte elements (LDS_ELEMS2 of them with DABGPU_C2_PAD_SHIFT = 4)
-    constexpr int kXElems = (FIR && DABGPU_DUAL_FFT) ? ((!DBUF && DABGPU_C2_PAD_SHIFT == 4) ? 2 * F::LDS_ELEMS2 : 2 * (DBUF ? 2 : 1) * F::LDS_ELEMS)
+    // (LEAN: the row layout of the first exchange, 8 x (T + 4) elements, is the largest image the pruned dual
+    // transform keeps in the buffer -- the padded size below is never used)
+    constexpr int kXElems = LEAN ? 2 * 8 * F::X1_PITCH
+                          : (FIR && DABGPU_DUAL_FFT) ? ((!DBUF && DABGPU_C2_PAD_SHIFT == 4) ? 2 * F::LDS_ELEMS2 : 2 * (DBUF ? 2 : 1) * F::LDS_ELEMS)
                                                       : (DBUF ? 2 : 1) * F::LDS_ELEMS;
+    static_assert(!LEAN || (F::X1_ROWS && 8 * F::X1_PITCH >= N && 2 * 8 * F::X1_PITCH * 8 >= (2 * N + 4 * T) * 4), "LEAN buffer");
     double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
     // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
     // that the boundary outputs read in[i + j] without a tail/head case split
     // frequency-domain gain statistics (coded-bits path): one packed word of phases per lane
     uint32_t *phw = reinterpret_cast<uint32_t *>(red + 16);          // [T]
     // (carriers path: three complex bins per lane instead -- the general form of the same statistic)
-    cf *bnd = reinterpret_cast<cf *>(phw + (GAIN ? (FROM_BITS ? T : 6 * T) : 0));
+    uint16_t *phw16 = reinterpret_cast<uint16_t *>(phw);              // LEAN: the 12 bits that are exchanged, as 16-bit words
+    cf *bnd = reinterpret_cast<cf *>(phw + (GAIN ? (FROM_BITS ? (LEAN ? T / 2 : T) : 6 * T) : 0));
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     constexpr int KB = NT ? NT - 1 : kBnd;      // slots per half buffer: the look-ahead C when it is a compile-time constant
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * KB : 0));
@@ -967,17 +1022,18 @@ void tf_kernel(const TfArgs a)
     // vector loads (the output stores may alias them), and every such load drags an
     // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
     float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
-    float *mag_l = taps_l + kMaxTaps;
+    constexpr int kTapsL = LEAN ? NT + 3 : kMaxTaps, kMagL = LEAN ? 80 : 160;
+    float *mag_l = taps_l + kTapsL;
     // exp(i p pi/4) with exact 0 / +-1 entries, in 8 rotated copies: entry [rot * 8 + p] = exp(i (p + rot) pi/4).
     // The coded-bits path keeps its differential phases without the common "+1 eighth per symbol" term and
     // unreduced (see advance); the rotation is the symbol's share, picked through the table's base address.
-    cf *unit8 = reinterpret_cast<cf *>(mag_l + 160);
+    cf *unit8 = reinterpret_cast<cf *>(mag_l + kMagL);
     cf *tw8_l = unit8 + 64;                             // DABGPU_TW8_LDS: 7 x 8 twiddles
     if (DABGPU_TW8_LDS) F::fill_tw8(a.t.twiddle, tw8_l, t);
     cf *tw64_l = tw8_l + 56;                            // DABGPU_TW64_LDS: 7 x 64 twiddles (FIR variants)
     // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
     float *cfr_red = reinterpret_cast<float *>(tw64_l + 448);
-    constexpr bool TW64 = (DABGPU_TW64_LDS || (GVAR && DABGPU_GVAR_TW64)) && FIR && F::NR8 >= 3;
+    constexpr bool TW64 = (DABGPU_TW64_LDS || (GVAR && DABGPU_GVAR_TW64) || LEAN) && FIR && F::NR8 >= 3;
     constexpr int kU8 = DABGPU_TW8_LDS ? 1 : 0;
     if (TW64) F::fill_tw64(a.t.twiddle, tw64_l, t, (int)blockDim.x);
     if (t < 64) {
@@ -986,7 +1042,7 @@ void tf_kernel(const TfArgs a)
         const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
         unit8[t] = mk(cx, cy);
     }
-    for (int i = t; i < kMaxTaps; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
+    for (int i = t; i < kTapsL; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
     if (FROM_BITS)
         for (int i = t; i < G::nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
     lds_barrier();
@@ -1027,6 +1083,7 @@ void tf_kernel(const TfArgs a)
         for (int m = 0; m < 8; ++m) hk8[m] = a.t.fir_h[tt + T * m];
     }
     int bitpos[6];
+    unsigned bitpack[3] = {0u, 0u, 0u};      // LEAN: the six positions, two 16-bit fields per register
     // differential state of the lane's carriers, without the
     // "+1 eighth" every data block adds to every carrier: phase of symbol s = 2 q_c + s - 1 eighths.
     // Kept as six 4-bit fields of ONE register, in quarter turns (every increment is an even number of eighths): the
@@ -1035,23 +1092,36 @@ void tf_kernel(const TfArgs a)
     // in the lane that holds them -- carriers (5, 4, 3) at bits (12, 16, 20), lane 0 (which pairs with itself and has
     // bin 3T in slot 0): carriers (3, 5, 4).
     unsigned P = 0u;
-    unsigned fpos[6] = {0u, 4u, 8u, tt == 0 ? 12u : 20u, tt == 0 ? 20u : 16u, tt == 0 ? 16u : 12u};
+    // (LEAN: the same compile-time positions in every lane -- three registers fewer; lane 0 permutes the word it reads back)
+    unsigned fpos[6] = {0u, 4u, 8u, (!LEAN && tt == 0) ? 12u : 20u, (!LEAN && tt == 0) ? 20u : 16u, (!LEAN && tt == 0) ? 16u : 12u};
     const uint8_t *fbits = nullptr;
     if (FROM_BITS) {
         fbits = a.bits + (size_t)frame * (size_t)(G::nb_symbols - 1) * (size_t)(K / 4);
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             bitpos[c] = a.t.src_carrier[kpos[c]];
+            bitpack[c >> 1] |= (unsigned)bitpos[c] << (16 * (c & 1));
             P |= ((unsigned)a.t.phase_q[kpos[c]] & 3u) << fpos[c];
         }
     }
     const cf *fcar = FROM_BITS ? nullptr
                                : a.carriers + (size_t)frame * (size_t)nsym * (size_t)K;
-    cf *fout = a.out + (size_t)frame * a.out_stride;
-    uint32_t *fout16 = reinterpret_cast<uint32_t *>(a.out) + (size_t)frame * a.out_stride;   // OFMT = 1
+    // The frame's output through a buffer resource: every store is "scalar base + scalar offset + 32-bit lane offset"
+    // (buffer_store ... offen).  Flat 64-bit addresses cost a register pair and a 64-bit add per store, and were
+    // what the register allocator spilled first.  soff: wave-uniform sample index inside the frame (>= 0), voff: the
+    // lane's; out-of-range lanes are exec-masked by the callers (the hardware would drop them as well).
+    constexpr int kOutBytes = OFMT == 1 ? 4 : 8;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(a.out) + (size_t)frame * a.out_stride * kOutBytes, 0, (int)(a.out_stride * kOutBytes), 0x00020000);
     unsigned nclip = 0;
-    auto put = [&](size_t idx, cf y) __attribute__((always_inline)) {
-        if (OFMT == 1) fout16[idx] = s16_pack(y, nclip); else fout[idx] = y;
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    auto put = [&](int soff, int voff, cf y) __attribute__((always_inline)) {
+        if (OFMT == 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(s16_pack(y, nclip), orsrc, voff * 4, soff * 4, 0);
+        } else {
+            const v2u_ d = {__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.y)};
+            __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, voff * 8, soff * 8, 0);
+        }
     };
 
     // advance the differential state over one data block (K/4 bytes: I bits, then Q bits)
@@ -1060,17 +1130,19 @@ void tf_kernel(const TfArgs a)
         unsigned ib[6], qb[6];
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
+            const int bp = LEAN ? (int)((bitpack[c >> 1] >> (16 * (c & 1))) & 0xffffu) : bitpos[c];
 #ifdef DABGPU_EXPERIMENT_NOBITS
-            ib[c] = bitpos[c] * 3; qb[c] = bitpos[c] * 5;
+            ib[c] = bp * 3; qb[c] = bp * 5;
 #else
-            ib[c] = blk[bitpos[c] >> 3];
-            qb[c] = blk[(K >> 3) + (bitpos[c] >> 3)];
+            ib[c] = blk[bp >> 3];
+            qb[c] = blk[(K >> 3) + (bp >> 3)];
 #endif
         }
         unsigned I = 0u, Q = 0u;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const unsigned sh = 7u - ((unsigned)bitpos[c] & 7u);
+            const int bp2 = LEAN ? (int)((bitpack[c >> 1] >> (16 * (c & 1))) & 0xffffu) : bitpos[c];
+            const unsigned sh = 7u - ((unsigned)bp2 & 7u);
             I |= __builtin_amdgcn_ubfe(ib[c], sh, 1u) << fpos[c];
             Q |= __builtin_amdgcn_ubfe(qb[c], sh, 1u) << fpos[c];
         }
@@ -1114,8 +1186,13 @@ void tf_kernel(const TfArgs a)
     // scatter them into the first-stage register layout
     const float m_r0 = r0 == 0 ? 1.0f : 0.0f, m_r3 = 1.0f - m_r0;       // (two multiplies are two packed instructions
     auto place = [&](const cf *val, cf *v) __attribute__((always_inline)) {   //  per pair; two selects are four)
-        v[0] = cscale(val[0], m_r0);
-        v[3] = cscale(val[0], m_r3);
+        if (LEAN) {
+            v[0] = tt == 0 ? mk(0.f, 0.f) : val[0];
+            v[3] = tt == 0 ? val[0] : mk(0.f, 0.f);
+        } else {
+            v[0] = cscale(val[0], m_r0);
+            v[3] = cscale(val[0], m_r3);
+        }
         v[4] = mk(0.f, 0.f);
         v[1] = val[1]; v[2] = val[2]; v[5] = val[3]; v[6] = val[4]; v[7] = val[5];
     };
@@ -1123,7 +1200,26 @@ void tf_kernel(const TfArgs a)
     if (FROM_BITS) {
         // the loop below applies block s-2 on entering symbol s; bring the state to
         // "blocks 0 .. s_begin-3 applied"
-        for (int d = 0; d + 3 <= s_begin; ++d) advance(fbits + (size_t)d * (size_t)(K / 4));
+        // A chunk that starts deep inside the frame replays up to 74 blocks here.  Gathering their bits straight from
+        // global memory costs 12 scattered byte loads per lane and block -- 3500 load instructions per workgroup whose
+        // 64 lanes each touch their own byte: 27 of the 35 us of a one-frame launch went into the texture addresser.
+        // So the blocks are copied to LDS first (coalesced dwords into the exchange buffer, which is idle until the
+        // first transform) and the bytes are gathered from there, in slabs of as many blocks as the buffer holds.
+        {
+            const int nblk = s_begin - 2;                        // blocks 0 .. s_begin - 3
+            uint32_t *stage = reinterpret_cast<uint32_t *>(fbuf);
+            constexpr int kBlkWords = K / 16;                    // K / 4 bytes per block
+            constexpr int kSlab = (kXElems * (int)sizeof(cf)) / (kBlkWords * 4);
+            static_assert(kSlab >= 1, "the exchange buffer holds at least one block");
+            for (int d0 = 0; d0 < nblk; d0 += kSlab) {
+                const int nb = min(kSlab, nblk - d0);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(fbits + (size_t)d0 * (size_t)(K / 4));
+                for (int i = t; i < nb * kBlkWords; i += (int)blockDim.x) stage[i] = src[i];
+                lds_barrier_vm();
+                for (int j = 0; j < nb; ++j) advance(reinterpret_cast<const uint8_t *>(stage + j * kBlkWords));
+                lds_barrier();                                   // the slab is consumed (next slab / first exchange)
+            }
+        }
         // stage the block of the first symbol (block s_begin-2) into bitbuf[0]
         bitbuf[bit_slot] = fetch_block(s_begin - 2);   // (clamped; unused when the loop starts at s <= 1)
     }
@@ -1308,7 +1404,7 @@ void tf_kernel(const TfArgs a)
     // obtain the head that the chunk's last boundary outputs look into.
     const int s_stop = (FIR && s_end < nsym) ? s_end + 1 : s_end;
     int cur = 0;               // which tail buffer holds the previous symbol's tail
-    size_t prev_pos = 0;       // stream position of the previous segment
+    int prev_pos = 0;          // stream position of the previous segment
     int prev_seg = 0;
     bool have_prev = false;
 
@@ -1352,7 +1448,7 @@ void tf_kernel(const TfArgs a)
             }
             acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);   // the 4 lanes of an output
             acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);   // are one DPP quad
-            if (i < C && q == 0) put(prev_pos + (size_t)(prev_seg - C + i), acc);
+            if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, t >> 2, acc);
         }
     };
 
@@ -1369,7 +1465,8 @@ void tf_kernel(const TfArgs a)
     int s_loop = s_begin;
     if (FROM_BITS && s_begin == 0) {
         const int nz = len0 - C;                      // the last C outputs belong to `boundary`
-        for (int i = t; i < nz; i += (int)blockDim.x) put((size_t)i, mk(0.f, 0.f));
+        for (int i0 = 0; i0 < nz; i0 += kThreads)
+            if (i0 + t < nz) put(i0, t, mk(0.f, 0.f));
         if (FIR) {
             for (int i = t; i < KB; i += (int)blockDim.x) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
             have_prev = true;
@@ -1397,9 +1494,15 @@ void tf_kernel(const TfArgs a)
                 //   S = sum over carrier pairs {k, -k} of cos(pi/4 (p_k + p_-k)),
                 // because sum_n x[n]^2 = N sum_k X[k] X[-k].  Carrier -k of the lane's three positive
                 // carriers lives in lane T - t (lane 0 pairs with itself): exchange one packed word.
-                phw[tt] = P >> 12;                           // fields (-k0, -k1, -k2) of this lane
+                if (LEAN) phw16[tt] = (uint16_t)(P >> 12); else phw[tt] = P >> 12;   // fields (-k0, -k1, -k2) of this lane
                 lds_barrier();
-                const unsigned o = phw[(T - tt) & (T - 1)];
+                unsigned o = LEAN ? (unsigned)phw16[(T - tt) & (T - 1)] : phw[(T - tt) & (T - 1)];
+                if (LEAN) {
+                    // lane 0 pairs with itself and holds bin 3T in slot 0: its (-k0, -k1, -k2) are carriers (3, 5, 4),
+                    // which the uniform layout keeps at fields (2, 0, 1) of the word
+                    const unsigned o0 = ((o >> 8) & 0xfu) | ((o & 0xfu) << 4) | (((o >> 4) & 0xfu) << 8);
+                    o = tt == 0 ? o0 : o;
+                }
                 // Every carrier of a symbol has the same phase parity (each block adds an odd number of eighths
                 // to all of them), so a pair's phase sum is an even number of eighths and its cosine is +1, 0 or -1:
                 // S = #(sum = 0 mod 4 quarter turns) - #(sum = 2 mod 4).  Both phases of a pair carry the symbol's
@@ -1446,7 +1549,7 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
             for (int r = 0; r < 8; ++r) v2[r] = c2{make_float2(v[r].x, z[r].x), make_float2(v[r].y, z[r].y)};
             if constexpr (ZONLY) {
-                F::template run_dual_zonly<+1, kU8>(v2, reinterpret_cast<c2 *>(fbuf), tw, tt, tw8_l, z, uedge);
+                F::template run_dual_zonly<+1, kU8, TW64 ? 1 : 0>(v2, reinterpret_cast<c2 *>(fbuf), tw, tt, tw8_l, z, uedge, tw64_l);
             } else {
                 F::template run<+1, DBUF, c2, kU8, TW64 ? 1 : 0>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l, tw64_l);
 #pragma unroll
@@ -1524,8 +1627,7 @@ void tf_kernel(const TfArgs a)
         const int cpl = (!FROM_BITS && s == 0) ? cp0 : cp;
         const int seg = N + cpl;
         // position of this segment in the frame's output stream
-        const size_t pos = GUARD ? (s == 0 ? 0 : (size_t)len0 + (size_t)(s - 1) * (size_t)len)
-                                 : (size_t)s * (size_t)N;
+        const int pos = GUARD ? (s == 0 ? 0 : len0 + (s - 1) * len) : s * N;
         if (FIR) {
             // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
             cf *tail_new = bnd + (cur ^ 1) * 2 * KB, *tail_prev = bnd + cur * 2 * KB, *head = tail_prev + C;
@@ -1585,8 +1687,8 @@ void tf_kernel(const TfArgs a)
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
                 const cf y = scaled(v[m]);
-                if (!FIR || n < N - C) put(pos + cpl + n, y);              // FIR: the last C belong to `boundary`
-                if (m > m_cp || (m == m_cp && n >= N - cpl)) put(pos + n - (N - cpl), y);
+                if (!FIR || n < N - C) put(pos + cpl + T * m, t, y);       // FIR: the last C belong to `boundary`
+                if (m > m_cp || (m == m_cp && n >= N - cpl)) put(pos, n - (N - cpl), y);
             }
         }
         have_prev = true;
@@ -1614,7 +1716,9 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const dim3 block(T < 64 ? 64 : T);
     const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
     const bool gvar = !(flags & TF_FROM_BITS) && (flags & TF_GAIN) && !(flags & TF_CFR) && a.gain.mode == 2;
-    const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0), (flags & TF_FIR) ? NT : 0);
+    const bool lean = DABGPU_TF_LEAN && LOGN == 11 && NT == 45 && (flags & TF_FROM_BITS) && (flags & TF_FIR) && (flags & TF_GUARD) &&
+                      DABGPU_ZONLY && !(flags & TF_CFR) && (!(flags & TF_GAIN) || a.gain.mode != 1);
+    const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0) | (lean ? TF_LEAN : 0), (flags & TF_FIR) ? NT : 0);
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
 #define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
@@ -1680,6 +1784,12 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 size_t tf_lds_bytes(int logN, unsigned flags, int nt)
 {
     const size_t N = (size_t)1 << logN;
+    if (flags & TF_LEAN) {
+        // the cfg 3 kernel trimmed for four workgroups per CU: row-layout exchange buffer, 16-bit phase words, short tables
+        return 8 * (N / 8 + 4) * 2 * sizeof(float2) + 16 * sizeof(double) + ((flags & TF_GAIN) ? (N / 8) * sizeof(uint16_t) : 0) +
+               4 * (size_t)(nt - 1) * sizeof(float2) + 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t) +
+               (size_t)(nt + 3 + 80) * sizeof(float) + (64 + 56 + 448) * sizeof(float2);
+    }
     const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
     const bool dual = (flags & TF_FIR) && DABGPU_DUAL_FFT;
     size_t b = dual ? ((!dbuf && DABGPU_C2_PAD_SHIFT == 4) ? (N + N / 16) : (dbuf ? 2 : 1) * (N + N / 8)) * 2 * sizeof(float2)
@@ -2671,14 +2781,38 @@ void resampler4w_kernel(const ResamplerArgs a, int hops_per_run)
     }
     lds_barrier();
 
+    // Global memory through buffer resources (scalar base + scalar offset + 32-bit lane offset): no 64-bit lane
+    // addresses to keep or to add, and an access outside a resource's range reads as zero / is dropped -- the halo
+    // and the stream are then two loads whose sum is the sample, with no per-lane select of a pointer.
+    // S = [halo (2 hops) | in]; hop h uses S[(h+1)*HIN .. (h+3)*HIN); the stream resource is based at hop h0 - 1
+    // (the address below the buffer it yields for h0 = 0 is never dereferenced: those offsets are out of range).
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
+    const int run_hops = (int)(h1 - h0);
+    const __amdgpu_buffer_rsrc_t r_win = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.window), 0, NIN * 4, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_halo = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.halo), 0, NIN * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_twi = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.tw_in), 0, NIN * 8, 0x00020000);
+    // stream positions [(h0 + 1) HIN - NIN, ...) as offsets 0 ... of the resource; only offsets >= the start of `in` are in range
+    const long in_first = (h0 + 1) * HIN - NIN;               // stream index of the resource's offset 0 (may be < 0)
+    const long in_skip = in_first < 0 ? -in_first : 0;        // samples at the front that belong to the halo
+    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<cf *>(a.in) + (in_first + in_skip), 0, (int)(((long)run_hops + 2) * HIN - in_skip) * 8, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)h0 * HOUT, 0, run_hops * HOUT * 8, 0x00020000);
+    const bool uses_halo = h0 <= 1;
     auto wnd = [&](int u, int m) __attribute__((always_inline)) -> float {
         const int vt = t + TP * u;
-        return m < 4 ? a.window[vt + TV * m] : a.window[TV * (7 - m) + (TV - 1 - vt)];
+        return __builtin_bit_cast(float, m < 4 ? __builtin_amdgcn_raw_buffer_load_b32(r_win, vt * 4, TV * m * 4, 0)
+                                               : __builtin_amdgcn_raw_buffer_load_b32(r_win, (TV - 1 - vt) * 4, TV * (7 - m) * 4, 0));
     };
-    // S = [halo (2 hops) | in]; hop h uses S[(h+1)*HIN .. (h+3)*HIN)
     auto sample = [&](long h, int u, int m) __attribute__((always_inline)) -> cf {
-        const long i = (h + 1) * HIN + t + TP * u + TV * m;
-        return i < NIN ? a.halo[i] : a.in[i - NIN];
+        const int vt = t + TP * u;
+        const int rel = (int)((h + 1) * HIN - in_first - in_skip) + TV * m;      // wave-uniform; negative inside the halo
+        v2u_ x = __builtin_amdgcn_raw_buffer_load_b64(r_in, (rel + vt) * 8, 0, 0);   // (negative -> huge unsigned -> zero)
+        if (uses_halo) {
+            const v2u_ y = __builtin_amdgcn_raw_buffer_load_b64(r_halo, (int)((h + 1) * HIN + TV * m + vt) * 8, 0, 0);
+            x = v2u_{x.x | y.x, x.y | y.y};
+        }
+        return mk(__builtin_bit_cast(float, x.x), __builtin_bit_cast(float, x.y));
     };
     // the packed dual transform of both virtual lanes (Fft<12>::run, two lanes per lane, one buffer)
     auto fft2v = [&](c2 (&v)[NU][8]) __attribute__((always_inline)) {
@@ -2716,7 +2850,10 @@ void resampler4w_kernel(const ResamplerArgs a, int hops_per_run)
 #pragma unroll
         for (int r = 1; r < 8; ++r) {
 #pragma unroll
-            for (int u = 0; u < NU; ++u) w512[u][r - 1] = a.tw_in[(r * (to + TP * u)) & (NIN - 1)];
+            for (int u = 0; u < NU; ++u) {
+                const v2u_ wv = __builtin_amdgcn_raw_buffer_load_b64(r_twi, ((r * (to + TP * u)) & (NIN - 1)) * 8, 0, 0);
+                w512[u][r - 1] = mk(__builtin_bit_cast(float, wv.x), __builtin_bit_cast(float, wv.y));
+            }
         }
         xbarrier();
 #pragma unroll
@@ -2803,24 +2940,12 @@ void resampler4w_kernel(const ResamplerArgs a, int hops_per_run)
                 v2[u][m] = c2{make_float2(xa.x, xn.x * w), make_float2(xa.y, -xn.y * w)};
             }
         fft2v(v2);
-        // branch 0 needs no transform: IDFT(DFT(u)) = NIN u -- the input samples under the sum of the two window
-        // halves -- plus the second copy of the Nyquist bin, G[NIN/2] e^{i pi q} (q = vt + 512 m, even offsets)
-        const cf ny = nyq[slot];
-        cf *dst = a.out + (size_t)h * HOUT;
+        // item b = conj(F_{h+1}); the overlap-add with F_h gives the next hop's spectrum
+        cf o3[NU][4];
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const cf c = sample(h, u, m);
-                const float ws = (wnd(u, m) + wnd(u, m + 4)) * sc;
-                cf a0 = mk(fmaf(sgn, ny.x, c.x * ws), fmaf(sgn, ny.y, c.y * ws));
-                cf a1 = o12[u][m][0], a2 = o12[u][m][1], a3 = mk(v2[u][m].re.x, v2[u][m].im.x);
-                if (POLY) { poly_apply2(a0, a1, pc); poly_apply2(a2, a3, pc); }
-                float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + TP * u + TV * m));
-                d4[0] = make_float4(a0.x, a0.y, a1.x, a1.y);
-                d4[1] = make_float4(a2.x, a2.y, a3.x, a3.y);
-            }
-        // item b = conj(F_{h+1}); the overlap-add with F_h gives the next hop's spectrum
+            for (int m = 0; m < 4; ++m) o3[u][m] = mk(v2[u][m].re.x, v2[u][m].im.x);
 #pragma unroll
         for (int u = 0; u < NU; ++u)
 #pragma unroll
@@ -2828,6 +2953,24 @@ void resampler4w_kernel(const ResamplerArgs a, int hops_per_run)
                 const cf fn = mk(v2[u][m].re.y * a.factor, -v2[u][m].im.y * a.factor);
                 G[u][m] = mk(fmaf(sgn, Fc[u][m].x, fn.x), fmaf(sgn, Fc[u][m].y, fn.y));
                 Fc[u][m] = fn;
+            }
+        // branch 0 needs no transform: IDFT(DFT(u)) = NIN u -- the input samples under the sum of the two window
+        // halves -- plus the second copy of the Nyquist bin, G[NIN/2] e^{i pi q} (q = vt + 512 m, even offsets)
+        const cf ny = nyq[slot];
+        const int ho = (int)(h - h0) * HOUT * 8;
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+            for (int m = 0; m < 4; ++m) {
+                const cf c = sample(h, u, m);
+                const float ws = (wnd(u, m) + wnd(u, m + 4)) * sc;
+                cf a0 = mk(fmaf(sgn, ny.x, c.x * ws), fmaf(sgn, ny.y, c.y * ws));
+                cf a1 = o12[u][m][0], a2 = o12[u][m][1], a3 = o3[u][m];
+                if (POLY) { poly_apply2(a0, a1, pc); poly_apply2(a2, a3, pc); }
+                const int vo = Q * (t + TP * u) * 8, so = ho + Q * TV * m * 8;
+                auto bits = [](float f) __attribute__((always_inline)) { return __builtin_bit_cast(unsigned, f); };
+                __builtin_amdgcn_raw_buffer_store_b128(v4u_{bits(a0.x), bits(a0.y), bits(a1.x), bits(a1.y)}, r_out, vo, so, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(v4u_{bits(a2.x), bits(a2.y), bits(a3.x), bits(a3.y)}, r_out, vo + 16, so, 0);
             }
     }
 }
