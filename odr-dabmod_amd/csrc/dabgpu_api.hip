@@ -398,17 +398,19 @@ GainParams gain_of(const dabgpu_ctx *c)
 int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
 {
     if (c->chunks_cfg > 0) return c->chunks_cfg;
-    // one workgroup per frame once the batch alone fills the chip (256 CUs x 4
-    // workgroups); below that split frames into runs of symbols.
+    // One workgroup per frame once the batch alone fills the chip; below that frames are split into runs of
+    // symbols.  Every run pays a prologue (the differential state up to its first symbol, gathered from LDS-staged
+    // blocks) and, with FIR, one look-ahead transform, so the split stops at about three workgroups per CU -- the
+    // measured optimum (tools/sweep_chunks.py, Mode I): 768 / B runs for B >= 48, 13 ... 39 runs for a handful of
+    // frames, single symbols for one or two (latency, not efficiency, counts there: 18 us per Mode-I frame).
     const int nsym = c->g.nb_symbols + 1;
-    if (n_frames >= 1024) return 1;
-    int want = (int)((1024 + n_frames - 1) / n_frames);
-    want = std::min(want, (nsym + 6) / 7);  // at least 7 symbols per workgroup (each run pays a prologue and,
-                                            // with FIR, one look-ahead transform)
-    // a handful of frames cannot fill 256 CUs even so: latency counts, not efficiency -- one workgroup per
-    // CU, down to single symbols (B = 1: 55 -> 38 us per Mode-I frame)
-    if (n_frames * (size_t)want <= 128) want = std::min<int>(nsym, (int)((256 + n_frames - 1) / n_frames));
-    return std::max(1, want);
+    const size_t n = n_frames;
+    int want;
+    if (n >= 1024) want = 1;
+    else if (n >= 48) want = (int)((768 + n - 1) / n);
+    else if (n >= 3) want = std::min(39, std::max(13, (int)((256 + n - 1) / n)));
+    else want = nsym;
+    return std::max(1, std::min(want, nsym));
 }
 
 bool is_pow2(size_t x) { return x && !(x & (x - 1)); }

@@ -33,8 +33,13 @@ def test_bench_line_single_process():
 def test_bench_with_a_real_rccl_communicator_on_one_rank():
     """torch.distributed over RCCL initialised for WORLD_SIZE = 1: barrier, all_reduce(MAX) and the optional IQ
     gather run through the same code as on N ranks."""
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
     env = {"DABGPU_FORCE_DIST": "1", "RANK": "0", "LOCAL_RANK": "0", "WORLD_SIZE": "1", "MASTER_ADDR": "127.0.0.1",
-           "MASTER_PORT": "29631", "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
+           "MASTER_PORT": str(port), "HSA_ENABLE_IPC_MODE_LEGACY": "0"}
     d = run_bench(["--gather", "8"], env)
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     g = d["iq_gather"]
