@@ -2703,7 +2703,18 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
             }
         }
         // the input after next is requested before this hop's stores (vmcnt retires in order) ...
-        if (h + 2 < h1) fetch(h + 2, xn);
+        // (only the NEW half: the window of hop h + 2 starts with the second half of hop h + 1's, and sample t + T m of
+        // the one is sample t + T (m + 4) of the other -- the same lane.  Every input sample is read once, not twice.)
+        if (h + 2 < h1) {
+            const long base = (h + 3) * HIN;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xn[m] = xn[m + 4];
+#pragma unroll
+            for (int m = 4; m < 8; ++m) {
+                const long i = base + t + T * m;
+                xn[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
+            }
+        }
         // ... and the Q branches of an output sample leave together: 8Q contiguous bytes per lane and
         // slot, so HBM sees whole 32-byte sectors (16-byte pairs stored a transform apart cost 1.5x
         // the write traffic)
