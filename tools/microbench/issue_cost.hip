@@ -21,7 +21,7 @@ enum Kind {
     K_FMA, K_PKFMA, K_PKADD, K_PKMUL, K_ADD, K_MOV_DPP, K_PERMLANE32, K_BPERMUTE,
     K_DSW128, K_DSW64, K_DSW32, K_DSWADDTID, K_DSR128, K_DSR64, K_DSR32,
     K_MIX_PK_DSW128, K_MIX_PK_DSR128, K_MIX_PK_DSW64, K_MIX_FMA_DSW128, K_MIX_PK_DSWADDTID, K_PKFMA_HALF,
-    K_MIX_PK_DSW32, K_DSW2ST64, K_DSR2ST64, K_GSTORE8, K_GSTORE16, K_COUNT
+    K_MIX_PK_DSW32, K_DSW2ST64, K_DSR2ST64, K_GSTORE8, K_GSTORE16, K_SALU, K_MIX_FMA_SALU, K_MIX_PK_SALU, K_WAITCNT, K_MIX_FMA_WAITCNT, K_COUNT
 };
 static const char *kNames[K_COUNT] = {
     "v_fma_f32 x32", "v_pk_fma_f32 x32", "v_pk_add_f32 x32", "v_pk_mul_f32 x32", "v_add_f32 x32", "v_mov_b32_dpp x32",
@@ -30,7 +30,8 @@ static const char *kNames[K_COUNT] = {
     "ds_read_b32 x32",
     "32 v_pk_fma + 8 ds_write_b128", "32 v_pk_fma + 8 ds_read_b128", "32 v_pk_fma + 16 ds_write_b64", "32 v_fma + 8 ds_write_b128",
     "32 v_pk_fma + 32 ds_write_addtid_b32", "v_pk_fma_f32 x16 (half block)", "32 v_pk_fma + 32 ds_write_b32",
-    "ds_write2st64_b32 x32", "ds_read2st64_b32 x32", "global_store_dwordx2 x8 (8 KB/wave iter)", "global_store_dwordx4 x8"};
+    "ds_write2st64_b32 x32", "ds_read2st64_b32 x32", "global_store_dwordx2 x8 (8 KB/wave iter)", "global_store_dwordx4 x8",
+    "s_add_u32 x32", "32 v_fma + 32 s_add interleaved", "32 v_pk_fma + 32 s_add interleaved", "s_waitcnt lgkmcnt(0) x32", "32 v_fma + 32 s_waitcnt interleaved"};
 
 template <int KIND> __global__ __launch_bounds__(256) void k(int iters, unsigned long long *cyc, float *sink, float4 *gout)
 {
@@ -164,6 +165,22 @@ template <int KIND> __global__ __launch_bounds__(256) void k(int iters, unsigned
                          : "v"(m), "v"(c), "v"(addr) : "memory");
             a0.x += r0.x + r1.x + r2.x + r3.x + r4.x + r5.x + r6.x + r7.x;
         }
+#define SA8 "s_add_u32 s20, s20, 1\n\ts_add_u32 s21, s21, 1\n\ts_add_u32 s22, s22, 1\n\ts_add_u32 s23, s23, 1\n\ts_add_u32 s24, s24, 1\n\ts_add_u32 s25, s25, 1\n\ts_add_u32 s26, s26, 1\n\ts_add_u32 s27, s27, 1\n\t"
+#define SCLOB : "s20", "s21", "s22", "s23", "s24", "s25", "s26", "s27", "scc"
+        if (KIND == K_SALU) asm volatile(REP4(SA8) ::SCLOB);
+#define FS(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n\ts_add_u32 s2" #i ", s2" #i ", 1\n\t"
+#define PS(i) "v_pk_fma_f32 %" #i ", %" #i ", %8, %9\n\ts_add_u32 s2" #i ", s2" #i ", 1\n\t"
+#define FW(i) "v_fma_f32 %" #i ", %" #i ", %8, %9\n\ts_waitcnt lgkmcnt(0)\n\t"
+        if (KIND == K_MIX_FMA_SALU)
+            asm volatile(REP4(FS(0) FS(1) FS(2) FS(3) FS(4) FS(5) FS(6) FS(7))
+                         : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x), "+v"(a4.x), "+v"(a5.x), "+v"(a6.x), "+v"(a7.x) : "v"(m.x), "v"(c.x) SCLOB);
+        if (KIND == K_MIX_PK_SALU)
+            asm volatile(REP4(PS(0) PS(1) PS(2) PS(3) PS(4) PS(5) PS(6) PS(7))
+                         : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) : "v"(m), "v"(c) SCLOB);
+        if (KIND == K_WAITCNT) asm volatile(REP4(REP8("s_waitcnt lgkmcnt(0)\n\t")));
+        if (KIND == K_MIX_FMA_WAITCNT)
+            asm volatile(REP4(FW(0) FW(1) FW(2) FW(3) FW(4) FW(5) FW(6) FW(7))
+                         : "+v"(a0.x), "+v"(a1.x), "+v"(a2.x), "+v"(a3.x), "+v"(a4.x), "+v"(a5.x), "+v"(a6.x), "+v"(a7.x) : "v"(m.x), "v"(c.x));
         if (KIND == K_GSTORE8) {
             float2 *g2 = reinterpret_cast<float2 *>(gp);
 #pragma unroll
@@ -183,7 +200,7 @@ template <int KIND> void run(int iters, unsigned long long *dcyc, float *dsink, 
 {
     // 256 CUs x occ workgroups of 4 waves (one per SIMD): occ = waves per SIMD.  LDS sized so that exactly occ fit.
     for (int occ = 1; occ <= 3; ++occ) {
-        const size_t lds = occ == 1 ? 96 * 1024 : (occ == 2 ? 64 * 1024 : 40 * 1024);
+        const size_t lds = occ == 1 ? 96 * 1024 : (occ == 2 ? 64 * 1024 : 36 * 1024);
         const int blocks = 256 * occ;
         CK(hipFuncSetAttribute(reinterpret_cast<const void *>(k<KIND>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024));
         hipEvent_t e0, e1;
@@ -243,6 +260,11 @@ int main(int argc, char **argv)
     run<K_MIX_PK_DSW32>(iters, dcyc, dsink, gout);
     run<K_MIX_PK_DSWADDTID>(iters, dcyc, dsink, gout);
     run<K_MIX_PK_DSR128>(iters, dcyc, dsink, gout);
+    run<K_SALU>(iters, dcyc, dsink, gout);
+    run<K_MIX_FMA_SALU>(iters, dcyc, dsink, gout);
+    run<K_MIX_PK_SALU>(iters, dcyc, dsink, gout);
+    run<K_WAITCNT>(iters, dcyc, dsink, gout);
+    run<K_MIX_FMA_WAITCNT>(iters, dcyc, dsink, gout);
     run<K_GSTORE8>(iters / 4, dcyc, dsink, gout);
     run<K_GSTORE16>(iters / 4, dcyc, dsink, gout);
     return 0;
