@@ -263,6 +263,10 @@ def main():
             elif t and t.get("frames") == B:
                 traffic = t.get("hbm_bytes_per_launch")
                 busy = {k: t[k] for k in ("valu_busy", "lds_busy") if k in t}
+                if t.get("gpu_cycles_per_launch_profiled"):
+                    # the part is power-limited under this kernel: GRBM_GUI_ACTIVE / 8 XCDs over the launch time is
+                    # the clock it actually ran at (2.4 GHz nominal)
+                    busy["effective_clock_GHz"] = round(t["gpu_cycles_per_launch_profiled"] / (kern_ms * 1e6), 2)
                 replay = "profiles/traffic.json (%s, source hash %s)" % (tj.get("profile_dir"), tj.get("source_hash"))
             else:
                 replay = "dropped: no counters for %d frames per launch" % B

@@ -26,6 +26,7 @@
 #include "dabgpu_internal.h"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 // build-time tuning knobs (tools/variants.sh sweeps them)
@@ -1718,7 +1719,10 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const bool gvar = !(flags & TF_FROM_BITS) && (flags & TF_GAIN) && !(flags & TF_CFR) && a.gain.mode == 2;
     const bool lean = DABGPU_TF_LEAN && LOGN == 11 && NT == 45 && (flags & TF_FROM_BITS) && (flags & TF_FIR) && (flags & TF_GUARD) &&
                       DABGPU_ZONLY && !(flags & TF_CFR) && (!(flags & TF_GAIN) || a.gain.mode != 1);
-    const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0) | (lean ? TF_LEAN : 0), (flags & TF_FIR) ? NT : 0);
+    size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0) | (lean ? TF_LEAN : 0), (flags & TF_FIR) ? NT : 0);
+    // (tuning aid: DABGPU_EXTRA_LDS=<bytes> pads the allocation, i.e. lowers the number of workgroups a CU holds)
+    static const size_t extra_lds = [] { const char *e = getenv("DABGPU_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
+    lds += extra_lds;
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
 #define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
