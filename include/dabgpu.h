@@ -218,7 +218,7 @@ DABGPU_API int dabgpu_format_process_dev(dabgpu_ctx *ctx, const void *d_in, size
  * half the bytes copied to the host; every other combination converts in a kernel of its own.  Output sizes of
  * dabgpu_chain_out_bytes_per_frame / _process / _submit follow the format.  dabgpu_get_num_clipped: the number of
  * clipped components of the most recent chain call (FormatConverter::get_num_clipped_samples, :56-59), after
- * waiting for that call. */
+ * waiting for that call -- or, on the asynchronous path, of the batch dabgpu_chain_collect returned last. */
 DABGPU_API int dabgpu_set_output_format(dabgpu_ctx *ctx, int format);
 DABGPU_API int dabgpu_get_num_clipped(dabgpu_ctx *ctx, size_t *num_clipped);
 

@@ -133,6 +133,7 @@ struct dabgpu_ctx {
         void *h_in = nullptr;                          // pinned (hipHostMalloc)
         size_t h_in_cap = 0, out_bytes = 0;
         int h_out_index = 0;                           // which of the three pinned output buffers this batch lands in
+        unsigned long long *h_clip = nullptr;          // pinned: this batch's clipped-component count (output formats)
         DevBuf d_in, d_out;
         hipEvent_t computed = nullptr, copied = nullptr;
         bool busy = false;
@@ -143,6 +144,8 @@ struct dabgpu_ctx {
     void *h_out[3] = {nullptr, nullptr, nullptr};
     size_t h_out_cap[3] = {0, 0, 0};
     unsigned long long submit_seq = 0;
+    bool clip_from_collect = false;        // dabgpu_get_num_clipped answers for the batch collect() returned last
+    size_t collected_clipped = 0;
     hipStream_t copy_stream = nullptr;
     int slot_head = 0, slot_count = 0;                 // oldest batch in flight, number in flight
 };
@@ -865,6 +868,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
         b->release();
     for (auto &sl : c->slot) {
         if (sl.h_in) (void)hipHostFree(sl.h_in);
+        if (sl.h_clip) (void)hipHostFree(sl.h_clip);
         sl.d_in.release();
         sl.d_out.release();
         if (sl.computed) (void)hipEventDestroy(sl.computed);
@@ -1022,6 +1026,10 @@ int dabgpu_get_num_clipped(dabgpu_ctx *c, size_t *num_clipped)
     CTXCHK(c);
     if (!num_clipped) return fail(c, DABGPU_E_INVALID, "null argument");
     *num_clipped = 0;
+    if (c->clip_from_collect) {
+        *num_clipped = c->collected_clipped;
+        return DABGPU_OK;
+    }
     if (!c->d_clip.p) return DABGPU_OK;
     HIPCHK(c, hipStreamSynchronize(c->clip_stream ? c->clip_stream : c->stream));
     unsigned long long v = 0;
@@ -1400,6 +1408,7 @@ int dabgpu_chain_process_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames,
 {
     CTXCHK(c);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    c->clip_from_collect = false;
     return run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
 }
 
@@ -1417,6 +1426,7 @@ int dabgpu_chain_process(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, un
     CTXCHK(c);
     if (n_frames > (size_t)c->max_frames)
         return fail(c, DABGPU_E_CAPACITY, "n_frames exceeds max_frames of the context");
+    c->clip_from_collect = false;
     int rc = apply_settings(c);
     if (rc) return rc;
     unsigned m2 = mask;
@@ -1475,6 +1485,11 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     size_t ob = 0;
     rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, c->stream);
     if (rc) return rc;
+    if (c->cur.out_format) {
+        // the clip counter is one per context and the next submit zeroes it: this batch's count goes to the slot now
+        if (!sl.h_clip) HIPCHK(c, hipHostMalloc((void **)&sl.h_clip, 16, hipHostMallocDefault));
+        HIPCHK(c, hipMemcpyAsync(sl.h_clip, c->d_clip.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+    }
     HIPCHK(c, hipEventRecord(sl.computed, c->stream));
     // the copy back runs on its own stream: the next batch's kernels overlap it
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.computed, 0));
@@ -1497,6 +1512,8 @@ int dabgpu_chain_collect(dabgpu_ctx *c, const void **iq, size_t *out_bytes)
     HIPCHK(c, hipEventSynchronize(sl.copied));
     *iq = c->h_out[sl.h_out_index];
     if (out_bytes) *out_bytes = sl.out_bytes;
+    c->clip_from_collect = true;
+    c->collected_clipped = (c->cur.out_format && sl.h_clip) ? (size_t)*sl.h_clip : 0;
     sl.busy = false;
     c->slot_head ^= 1;
     --c->slot_count;

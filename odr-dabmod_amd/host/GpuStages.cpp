@@ -790,7 +790,8 @@ const json::map_t MemlessPoly::get_all_values() const
 }
 
 // ---------------------------------------------------------------- DabGpuChain
-DabGpuChain::DabGpuChain(const Settings &s) : m_ctx(static_cast<int>(s.dabMode), 1)
+DabGpuChain::DabGpuChain(const Settings &s)
+    : m_ctx(static_cast<int>(s.dabMode), static_cast<int>(std::max<size_t>(1, s.maxBatchFrames)))
 {
     dabgpu_geometry g;
     m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
@@ -851,6 +852,18 @@ DabGpuChain::DabGpuChain(const Settings &s) : m_ctx(static_cast<int>(s.dabMode),
             throw std::runtime_error("MemlessPoly: coef file has unknown format");
         }
     }
+}
+
+void DabGpuChain::submit(const void *bits, size_t n_frames)
+{
+    m_ctx.check(dabgpu_chain_submit(m_ctx.get(), static_cast<const uint8_t *>(bits), n_frames, m_mask));
+}
+
+size_t DabGpuChain::collect(const void **iq)
+{
+    size_t n = 0;
+    m_ctx.check(dabgpu_chain_collect(m_ctx.get(), iq, &n));
+    return n;
 }
 
 size_t DabGpuChain::get_num_clipped_samples() const

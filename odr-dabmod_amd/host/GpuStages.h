@@ -311,8 +311,17 @@ public:
         // "complexf" (default), "s16", "u8" or "s8": FormatConverter as the chain's last step
         // (src/DabModulator.cpp:270-276, :407) -- for s16 the last kernel stores the integers itself
         std::string outputFormat = "complexf";
+        // frames per call of the streaming interface below (process() always takes one)
+        size_t maxBatchFrames = 1;
     };
     explicit DabGpuChain(const Settings &s);
+    // Streaming interface for a caller that can look ahead (a file, a buffered network input): submit() queues
+    // n_frames transmission frames (n_frames x the hot-path input), at most two batches in flight; collect() waits
+    // for the oldest and returns its IQ in a pinned buffer of the context, valid until the second next submit().
+    // Same stream state (resampler halo, TII parity) and the same samples as process() frame by frame.
+    void submit(const void *bits, size_t n_frames);
+    size_t collect(const void **iq);
+    size_t input_bytes_per_frame() const { return m_in_bytes; }
     int process(Buffer *const dataIn, Buffer *dataOut) override;
     const char *name() override { return "DabGpuChain"; }
     // FormatConverter::get_num_clipped_samples of the most recent frame (src/FormatConverter.cpp:56-59)

@@ -26,13 +26,15 @@
 #include <fstream>
 #include <memory>
 #include <string>
+#include <vector>
 
 namespace {
 [[noreturn]] void usage()
 {
     std::fprintf(stderr, "usage: dabmod_file <in.eti> <out> [--mode N] [--format complexf|s16|u8|s8] [--gainmode var|fix|max]\n"
                          "       [--digital G] [--normalise X] [--var V] [--fir none|default|file] [--rate R] [--poly file]\n"
-                         "       [--ofdmwindowing W] [--tii comb,pattern] [--cfr clip,errorclip] [--loop N] [--bits-only]\n");
+                         "       [--ofdmwindowing W] [--tii comb,pattern] [--cfr clip,errorclip] [--loop N] [--bits-only]\n"
+                         "       [--batch N]   N transmission frames per GPU call, two calls in flight (default 1: frame by frame)\n");
     std::exit(2);
 }
 }  // namespace
@@ -47,6 +49,7 @@ int main(int argc, char **argv)
     bool separate_converter = false;
     int loops = 1;
     bool bits_only = false;
+    size_t batch = 1;
     try {
         for (int i = 3; i < argc; ++i) {
             const std::string a = argv[i];
@@ -78,6 +81,7 @@ int main(int argc, char **argv)
             }
             else if (a == "--loop") loops = std::atoi(val().c_str());
             else if (a == "--bits-only") bits_only = true;
+            else if (a == "--batch") batch = std::max<size_t>(1, std::stoul(val()));
             else usage();
         }
 
@@ -99,6 +103,15 @@ int main(int argc, char **argv)
         Buffer bits, iq, converted;
         uint8_t frame[6144];
         size_t n_eti = 0, n_tf = 0, clipped = 0;
+        std::vector<uint8_t> pending;             // --batch: hot-path input of the batch being filled
+        int in_flight = 0;
+        auto drain_one = [&]() {
+            const void *p = nullptr;
+            const size_t n = chain->collect(&p);
+            if (format != "complexf") clipped += chain->get_num_clipped_samples();
+            out.write(static_cast<const char *>(p), static_cast<std::streamsize>(n));
+            --in_flight;
+        };
         for (int l = 0; l < loops; ++l) {
             if (l && reader.Open(in_path, false) != 0) return 1;
             int got;
@@ -116,6 +129,24 @@ int main(int argc, char **argv)
                 ++n_tf;
                 if (bits_only) {
                     out.write(static_cast<const char *>(bits.getData()), static_cast<std::streamsize>(bits.getLength()));
+                    continue;
+                }
+                if (batch > 1 && !separate_converter) {
+                    // streaming shape: the front-end fills a batch while the GPU works on the previous two
+                    if (!chain) {
+                        gs.outputFormat = format;
+                        gs.maxBatchFrames = batch;
+                        chain.reset(new DabGpuChain(gs));
+                        pending.reserve(batch * bits.getLength());
+                    }
+                    const uint8_t *b = static_cast<const uint8_t *>(bits.getData());
+                    pending.insert(pending.end(), b, b + bits.getLength());
+                    if (pending.size() == batch * chain->input_bytes_per_frame()) {
+                        if (in_flight == 2) { drain_one(); }
+                        chain->submit(pending.data(), batch);
+                        ++in_flight;
+                        pending.clear();
+                    }
                     continue;
                 }
                 if (!chain) {
@@ -140,6 +171,16 @@ int main(int argc, char **argv)
                 std::fprintf(stderr, "dabmod_file: error while reading %s\n", in_path.c_str());
                 return 1;
             }
+        }
+        if (chain && batch > 1 && !separate_converter) {
+            // the tail: a last, shorter batch, then whatever is still in flight, in order
+            const size_t rest = pending.size() / chain->input_bytes_per_frame();
+            if (rest) {
+                if (in_flight == 2) drain_one();
+                chain->submit(pending.data(), rest);
+                ++in_flight;
+            }
+            while (in_flight) drain_one();
         }
         std::fprintf(stderr, "dabmod_file: %zu ETI frames -> %zu transmission frames (mode %u)", n_eti, n_tf, gs.dabMode);
         if (format != "complexf") std::fprintf(stderr, ", %zu clipped components", clipped);
