@@ -262,7 +262,7 @@ int build_tables(dabgpu_ctx *c)
 // (+ their frequency response), guard window, predistorter coefficients, resampler.  Gain, CFR and TII
 // parameters are kernel arguments / cached-segment keys and need no upload at all.  A table is only
 // rewritten after the device has drained: the previous call may still be running on a caller's stream.
-int apply_settings(dabgpu_ctx *c)
+int apply_settings_groups(dabgpu_ctx *c)
 {
     Settings prev;
     {
@@ -373,6 +373,20 @@ int apply_settings(dabgpu_ctx *c)
     // everything above went through the context's own stream; the caller may launch on another one
     HIPCHK(c, hipStreamSynchronize(s));
     return DABGPU_OK;
+}
+
+// A failed upload leaves some group half-written: forget what was applied, so that the next call redoes all of them.
+int apply_settings(dabgpu_ctx *c)
+{
+    const int rc = apply_settings_groups(c);
+    if (rc != DABGPU_OK) {
+        std::lock_guard<std::mutex> lk(c->mu);
+        c->applied_epoch = 0;
+        c->tables_valid = false;
+        c->tii_seg_epoch = 0;
+        c->rs_nin = c->rs_nout = 0;           // (the resampler's tables and halo are rebuilt as well)
+    }
+    return rc;
 }
 
 Tables tables_of(dabgpu_ctx *c)

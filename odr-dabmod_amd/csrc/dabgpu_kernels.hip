@@ -1550,7 +1550,13 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
             for (int r = 0; r < 8; ++r) v2[r] = c2{make_float2(v[r].x, z[r].x), make_float2(v[r].y, z[r].y)};
             if constexpr (ZONLY) {
+#ifdef DABGPU_EXPERIMENT_SINGLE
+                // timing experiment (wrong boundary samples): the filtered transform alone
+                F::template run<+1, false, cf, kU8, TW64 ? 1 : 0>(z, fbuf, fpar, tw, tt, tw8_l, tw64_l);
+                uedge = cadd(z[6], z[7]);
+#else
                 F::template run_dual_zonly<+1, kU8, TW64 ? 1 : 0>(v2, reinterpret_cast<c2 *>(fbuf), tw, tt, tw8_l, z, uedge, tw64_l);
+#endif
             } else {
                 F::template run<+1, DBUF, c2, kU8, TW64 ? 1 : 0>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l, tw64_l);
 #pragma unroll

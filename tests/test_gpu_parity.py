@@ -761,6 +761,128 @@ def test_full_size_batch_round_trip_through_a_receiver(pkg):
         md.close()
 
 
+def _free_gib():
+    import torch
+    return torch.cuda.mem_get_info()[0] / 2 ** 30
+
+
+@pytest.mark.parametrize("fmt", ["complexf", "s16"])
+def test_bench_size_batch_equals_small_batch_frame_for_frame(pkg, fmt):
+    """The bench's own batch (cfg 3, B = 32768: 51.5 GB of IQ, one workgroup per frame, offsets beyond 2^32 bytes):
+    the batch is a shuffle of four distinct frames, and EVERY frame of it -- compared on the device, slice by slice --
+    carries the bytes of that frame in a 4-frame batch of the same launch geometry, which in turn is within the bar
+    of the oracle.  Also with FormatConverter(s16) fused into the store, clipped-component count included."""
+    import torch
+    B = 32768
+    s16 = fmt == "s16"
+    if _free_gib() < (30 if s16 else 56):
+        pytest.skip("needs the bench's device memory")
+    md = pkg.Modulator(mode=1, max_frames=B)
+    md4 = pkg.Modulator(mode=1, max_frames=4, chunks_per_frame=1)
+    try:
+        stages = pkg.STAGE_GAIN | pkg.STAGE_FIR
+        for m in (md, md4):
+            m.set_gain(2, 1.0, 1.0 if s16 else 1.0 / 50000.0, 4.0)       # (s16: sample values up to ~4e4, some clip)
+            if s16:
+                m.set_output_format("s16")
+        per = md.geometry["tf_input_bytes"]
+        uniq = np.stack([golden_bits(1)] + [synth_bits(per, seed=2100 + i) for i in range(3)])
+        ns = md.out_samples_per_frame(stages)
+        dt = torch.int16 if s16 else torch.complex64
+        shape4 = (4, 2 * ns) if s16 else (4, ns)
+        ref4 = torch.empty(shape4, dtype=dt, device="cuda")
+        md4.chain_dev(torch.from_numpy(uniq).cuda(), 4, stages, ref4)
+        clip4 = md4.num_clipped() if s16 else 0
+        # the 4-frame batch against the oracle
+        ref = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1.0 if s16 else 1.0 / 50000.0).process(uniq)
+        y4 = ref4.cpu().numpy()
+        for f in range(4):
+            if s16:
+                want, _ = O.format_convert(ref[f].view(np.float32), "s16")
+                d = np.abs(y4[f].astype(np.int32) - want.astype(np.int32))
+                assert d.max() <= 1 and (d != 0).mean() < 0.01
+            else:
+                assert rel_rms(y4[f], ref[f]) < REL_RMS
+        g = torch.Generator(device="cpu").manual_seed(7)
+        order = torch.randint(0, 4, (B,), generator=g)
+        order[0], order[B - 1] = 3, 2
+        d_bits = torch.from_numpy(uniq).cuda()[order.cuda()]
+        out = torch.empty((B, shape4[1]), dtype=dt, device="cuda")
+        md.chain_dev(d_bits, B, stages, out)
+        torch.cuda.synchronize()
+        o_dev = order.cuda()
+        view = (lambda t: t) if s16 else torch.view_as_real
+        bad = 0
+        for i in range(0, B, 1024):
+            want = ref4[o_dev[i:i + 1024]]
+            bad += int((view(out[i:i + 1024]).view(torch.int16 if s16 else torch.int32) !=
+                        view(want).view(torch.int16 if s16 else torch.int32)).any(dim=-1).reshape(1024, -1).any(dim=-1).sum())
+            del want
+        assert bad == 0, "%d of %d frames differ from the same frame in a small batch" % (bad, B)
+        if s16:
+            # every frame clips what its twin in the small batch clips
+            per_frame = []
+            for f in range(4):
+                mdf = pkg.Modulator(mode=1, max_frames=1, chunks_per_frame=1)
+                mdf.set_gain(2, 1.0, 1.0, 4.0)
+                mdf.set_output_format("s16")
+                o1 = torch.empty((1, 2 * ns), dtype=dt, device="cuda")
+                mdf.chain_dev(torch.from_numpy(uniq[f:f + 1]).cuda(), 1, stages, o1)
+                per_frame.append(mdf.num_clipped())
+                mdf.close()
+            assert sum(per_frame) == clip4
+            assert md.num_clipped() == sum(per_frame[int(o)] for o in order)
+        del out, d_bits
+    finally:
+        md.close()
+        md4.close()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
+def test_bench_size_cfg4_stream_is_periodic_like_its_input(pkg):
+    """cfg 4 at the bench's batch (B = 4096 frames, 25.8 GB of IQ at 8.192 Msps) as ONE stream: the input repeats
+    with a period of four frames, so the output does too once the resampler's zero start state (two hops) has left
+    -- frame f equals frame f + 4 for f >= 1, byte for byte, wherever the frames fall in the kernel's runs of hops --
+    and the first period is within the bar of the oracle."""
+    import torch
+    B = 4096
+    if _free_gib() < 45:
+        pytest.skip("needs the bench's device memory")
+    md = pkg.Modulator(mode=1, max_frames=B)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_resampler(2048000, 8192000)
+        md.set_poly(POLY_AM, POLY_PM)
+        stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY
+        per = md.geometry["tf_input_bytes"]
+        uniq = np.stack([golden_bits(1)] + [synth_bits(per, seed=2200 + i) for i in range(3)])
+        d_bits = torch.from_numpy(uniq).cuda().repeat(B // 4, 1)
+        ns = md.out_samples_per_frame(stages)
+        out = torch.empty((B, ns), dtype=torch.complex64, device="cuda")
+        md.chain_dev(d_bits, B, stages, out)
+        torch.cuda.synchronize()
+        v = torch.view_as_real(out).view(torch.int32).reshape(B, -1)
+        bad = 0
+        for i in range(4, B - 4, 512):
+            j = min(i + 512, B - 4)
+            bad += int((v[i:j] != v[i + 4:j + 4]).any(dim=-1).sum())
+        bad += int((v[1:4] != v[5:8]).any(dim=-1).sum())
+        first = out[:5].cpu().numpy()
+        del v, out
+        ch = O.Chain(mode=1, stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000, am=POLY_AM, pm=POLY_PM)
+        ref = ch.process(np.concatenate([uniq, uniq[:1]]))
+        for f in range(5):
+            assert rel_rms(first[f], ref[f]) < REL_RMS, f
+        assert bad == 0, "%d frames break the period" % bad
+    finally:
+        md.close()
+        import gc
+        gc.collect()
+        torch.cuda.empty_cache()
+
+
 @pytest.mark.parametrize("mode", [2, 3, 4])
 def test_other_modes_round_trip_through_a_receiver(pkg, mode):
     """Transmission modes II - IV, cfg 2 and cfg 3, three frames each, decoded by the independent receiver."""
