@@ -573,10 +573,19 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         HIPCHK(c, hipMemsetAsync(a.cfr_papr, 0, b2, s));
     }
 
+    a.overlap = (int)c->cur.overlap;
     if (!windowed) {
         if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
         if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
         if (s16_clipped) flags |= TF_OUT_S16;
+        a.chunks_per_frame = auto_chunks(c, n_frames);
+        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.out = native_out;
+        a.out_stride = native;
+        HIPCHK(c, launch_tf(a, flags, s));
+    } else if (!(mask & DABGPU_STAGE_FIR) && tf_has_window(a, flags | TF_GUARD)) {
+        // OFDM windowing without FIR on the coded-bits chain: the frame kernel windows the guard interval itself
+        flags |= TF_GUARD | TF_WINDOW;
         a.chunks_per_frame = auto_chunks(c, n_frames);
         a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
         a.out = native_out;

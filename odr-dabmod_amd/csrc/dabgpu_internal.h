@@ -61,14 +61,17 @@ struct TfArgs {
     double *cfr_papr;         // [frame][nb_symbols+1][4]: peak, mean of |x|^2 before / after CFR (pre-zeroed)
     // TF_OUT_S16: `out` holds 4-byte s16 pairs; the number of clipped components is ADDED to *clipped
     unsigned long long *clipped;
+    // TF_WINDOW: raised-cosine overlap of the guard interval (t.window holds the 2 * overlap factors)
+    int overlap;
 };
 
 enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */,
-               TF_OUT_S16 = 64, TF_LEAN = 128 /* internal */ };
+               TF_OUT_S16 = 64, TF_LEAN = 128 /* internal */, TF_WINDOW = 256 };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0);
 int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
+bool tf_has_window(const TfArgs &a, unsigned flags); // a frame-kernel variant windows the guard interval itself (TF_WINDOW)
 bool tf_has_s16(const TfArgs &a, unsigned flags);   // a frame-kernel variant stores s16 itself (TF_OUT_S16)
 
 // Stand-alone stage kernels (per-stage drop-ins and the non-fused fallbacks).

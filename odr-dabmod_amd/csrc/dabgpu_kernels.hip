@@ -83,6 +83,9 @@
 #define DABGPU_TF_LEAN 0        // cfg 3 kernel (Mode I coded-bits chain, ZONLY): LDS trimmed to 40 KB and 128 registers asked for,
                                // i.e. FOUR workgroups (16 waves) per CU instead of three
 #endif
+#ifndef DABGPU_CFR_WAVES
+#define DABGPU_CFR_WAVES 2      // waves per SIMD asked for the crest-factor-reduction variants
+#endif
 #ifndef DABGPU_FFT_DBUF
 #define DABGPU_FFT_DBUF 0      // FIR variants: 1 = two LDS exchange buffers (one barrier per exchange), 0 = one buffer,
                                // two barriers (36 KB of LDS per workgroup -> three workgroups per CU); the
@@ -940,6 +943,7 @@ constexpr unsigned kCX = 0x901Au;
 #ifndef DABGPU_KBND
 #define DABGPU_KBND 128
 #endif
+constexpr int kWinMax = 128;       // widest raised-cosine overlap the frame kernel applies itself (TF_WINDOW)
 constexpr int kBnd = DABGPU_KBND;  // LDS slots per boundary buffer; the fused FIR handles ntaps <= kBnd
 
 // FIR inside the fused kernel ("spectral FIR").
@@ -973,10 +977,16 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // the boundary FIR reads it (Fft::run_dual_zonly).
 // OFMT = 1: the output is s16 (4 bytes per sample, FormatConverter semantics) instead of cf32 -- instantiated for the
 // production variants only (Mode I coded-bits chain, default filter); everything else converts in format_kernel.
+// WIN (coded-bits chain with guard interval, no FIR): the guard interval is windowed (ofdmwindowing > 0, f-4,
+// src/GuardIntervalInserter.cpp:149-300).  Every sample outside the 2W-wide seams is the copy it is without a window;
+// seam sample j between symbols s-1 and s is  prev[j] * w[2W-1-j] + rise[j] * w[j], with prev = the last W samples of
+// symbol s-1 followed by its first W (the suffix written past its end) and rise = samples [N-cp-W, N-cp+W) of symbol
+// s.  The 2W + 2W samples go through LDS; the seam before a run's first symbol is written by the run before it,
+// which transforms that symbol too (look-ahead, as with the FIR).
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
-          bool ZONLY = false, int OFMT = 0>
+          bool ZONLY = false, int OFMT = 0, bool WIN = false>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             (!FIR || CFR) ? 2 : (GVAR ? DABGPU_GVAR_WAVES
+                             CFR ? DABGPU_CFR_WAVES : !FIR ? 2 : (GVAR ? DABGPU_GVAR_WAVES
                                                   : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2
                                                      : ((DABGPU_TF_LEAN && ZONLY && FROM_BITS) ? 4 : DABGPU_TF_WAVES))))
 void tf_kernel(const TfArgs a)
@@ -987,6 +997,7 @@ void tf_kernel(const TfArgs a)
     static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR && DABGPU_DUAL_FFT && !DABGPU_FFT_DBUF),
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
+    static_assert(!WIN || (FROM_BITS && GUARD && !FIR && !CFR && OFMT == 0), "WIN: coded-bits chain, guard interval, no FIR");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
@@ -1016,7 +1027,10 @@ void tf_kernel(const TfArgs a)
     cf *bnd = reinterpret_cast<cf *>(phw + (GAIN ? (FROM_BITS ? (LEAN ? T / 2 : T) : 6 * T) : 0));
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     constexpr int KB = NT ? NT - 1 : kBnd;      // slots per half buffer: the look-ahead C when it is a compile-time constant
-    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * KB : 0));
+    // WIN: two seam buffers [last W | first W samples of a symbol], the rising 2W samples of the next one, the window
+    cf *wbuf = bnd;
+    float *win_l = reinterpret_cast<float *>(wbuf + 6 * kWinMax);
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * KB : (WIN ? 7 * kWinMax : 0)));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
     // small read-only tables copied to LDS once: read through global memory they compile to
@@ -1044,6 +1058,9 @@ void tf_kernel(const TfArgs a)
         unit8[t] = mk(cx, cy);
     }
     for (int i = t; i < kTapsL; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
+    const int W = WIN ? a.overlap : 0;
+    if (WIN)
+        for (int i = t; i < 2 * W; i += blockDim.x) win_l[i] = a.t.window[i];
     if (FROM_BITS)
         for (int i = t; i < G::nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
     lds_barrier();
@@ -1403,7 +1420,7 @@ void tf_kernel(const TfArgs a)
 
     // With FIR the symbol after the chunk is transformed too (first IFFT only) to
     // obtain the head that the chunk's last boundary outputs look into.
-    const int s_stop = (FIR && s_end < nsym) ? s_end + 1 : s_end;
+    const int s_stop = ((FIR || WIN) && s_end < nsym) ? s_end + 1 : s_end;
     int cur = 0;               // which tail buffer holds the previous symbol's tail
     int prev_pos = 0;          // stream position of the previous segment
     int prev_seg = 0;
@@ -1465,7 +1482,7 @@ void tf_kernel(const TfArgs a)
     // lane predicates of the prefix copy and of the boundary samples hoist out of the loop.
     int s_loop = s_begin;
     if (FROM_BITS && s_begin == 0) {
-        const int nz = len0 - C;                      // the last C outputs belong to `boundary`
+        const int nz = len0 - C - W;                  // the last C outputs belong to `boundary` (W: to the seam)
         for (int i0 = 0; i0 < nz; i0 += kThreads)
             if (i0 + t < nz) put(i0, t, mk(0.f, 0.f));
         if (FIR) {
@@ -1474,13 +1491,17 @@ void tf_kernel(const TfArgs a)
             prev_pos = 0;
             prev_seg = len0;
         }
+        if (WIN) {
+            for (int i = t; i < 2 * W; i += (int)blockDim.x) wbuf[cur * 2 * kWinMax + i] = mk(0.f, 0.f);
+            have_prev = true;
+        }
         // bring the staged block to the state the loop expects at s = 1 (block index -1: none)
         s_loop = 1;
     }
 
     for (int s = s_loop; s < s_stop; ++s) {
         if (FROM_BITS) __builtin_assume(s >= 1);    // (the blank null symbol was peeled off above)
-        const bool lookahead = s >= s_end;      // FIR only: no output for this symbol
+        const bool lookahead = s >= s_end;      // FIR / WIN only: no output for this symbol
         cf val[6], v[8];
         uint32_t pf = 0u;
         if (FROM_BITS) {
@@ -1614,8 +1635,11 @@ void tf_kernel(const TfArgs a)
 
         // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the
         // (unfiltered, filtered) pairs the dual transform left side by side; everything below uses v and z as is
-        constexpr bool PRESCALED = DUAL && GAIN;
-        if (PRESCALED && ZONLY) {
+        constexpr bool PRESCALED = (DUAL || WIN) && GAIN;
+        if (WIN && GAIN) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = cscale(v[m], g);
+        } else if (PRESCALED && ZONLY) {
             uedge = cscale(uedge, g);
 #pragma unroll
             for (int m = 0; m < 8; ++m) z[m] = cscale(z[m], g);
@@ -1686,16 +1710,42 @@ void tf_kernel(const TfArgs a)
                 F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
             }
         }
+        if (WIN) {
+            // ---- seam between the previous symbol and this one -------------------------
+            cf *pprev = wbuf + cur * 2 * kWinMax, *pnew = wbuf + (cur ^ 1) * 2 * kWinMax, *rise = wbuf + 4 * kWinMax;
+            if (lane_on) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int n = t + T * m, r = n - (N - cpl - W);
+                    if (n >= N - W) pnew[n - (N - W)] = v[m];
+                    if (n < W) pnew[W + n] = v[m];
+                    if (r >= 0 && r < 2 * W) rise[r] = v[m];
+                }
+            }
+            lds_barrier();
+            if (have_prev) {
+                for (int j = t; j < 2 * W; j += kThreads) {
+#pragma clang fp contract(off)  // products and sum rounded separately, like the reference (see guard_window_at)
+                    const cf xp = pprev[j], xr = rise[j];
+                    const float fp = win_l[2 * W - 1 - j], fr = win_l[j];
+                    const float ar = xp.x * fp, ai = xp.y * fp, br = xr.x * fr, bi = xr.y * fr;
+                    put(pos - W, j, mk(ar + br, ai + bi));
+                }
+            }
+            cur ^= 1;
+        }
         if (FROM_BITS) bb ^= 1;
         if (lookahead) break;
         if (lane_on) {
             const int m_cp = (N - cpl) / T;   // first register slot that is also copied into the prefix
+            const bool keep_tail = !WIN || s == nsym - 1;    // WIN: the last W samples belong to the next seam
 #pragma unroll
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
                 const cf y = scaled(v[m]);
-                if (!FIR || n < N - C) put(pos + cpl + T * m, t, y);       // FIR: the last C belong to `boundary`
-                if (m > m_cp || (m == m_cp && n >= N - cpl)) put(pos, n - (N - cpl), y);
+                // FIR: the last C belong to `boundary`
+                if ((!FIR || n < N - C) && (keep_tail || n < N - W)) put(pos + cpl + T * m, t, y);
+                if ((m > m_cp || (m == m_cp && n >= N - cpl)) && (!WIN || n - (N - cpl) >= W)) put(pos, n - (N - cpl), y);
             }
         }
         have_prev = true;
@@ -1737,6 +1787,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
     if ((flags & TF_OUT_S16) && !tf_has_s16(a, flags)) return hipErrorInvalidValue;
+    if ((flags & TF_WINDOW) && !tf_has_window(a, flags)) return hipErrorInvalidValue;
     if (flags & TF_CFR) {
         // with the whole fused epilogue (guard + FIR) or with none of it
         if (gd != fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
@@ -1760,6 +1811,12 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         return hipGetLastError();
     }
 #undef TF_LAUNCH_GVAR
+    if (flags & TF_WINDOW) {
+        if (!tf_has_window(a, flags) || NT != 0) return hipErrorInvalidValue;
+        if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+        return hipGetLastError();
+    }
     if (LOGN == 11 && NT == 45 && !fb && !gn && fr && gd && DABGPU_ZONLY) {
         hipLaunchKernelGGL((tf_kernel<11, false, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
         return hipGetLastError();
@@ -1814,7 +1871,17 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
 #endif
     if ((flags & TF_FIR) && (DABGPU_TW64_LDS || ((flags & TF_GVAR) && DABGPU_GVAR_TW64))) b += 448 * sizeof(float2);
     if (flags & TF_CFR) b += (448 * sizeof(float2)) + 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red sits behind the tw64 slot
+    if (flags & TF_WINDOW) b += 7 * kWinMax * sizeof(float2);                                     // seam buffers + window
     return b;
+}
+
+// the frame-kernel variants that window the guard interval themselves: coded-bits chain with guard interval and
+// without FIR / CFR / s16 store, overlap up to kWinMax (and inside the cyclic prefix)
+bool tf_has_window(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_FIR | TF_CFR | TF_OUT_S16;
+    return (flags & want) == want && !(flags & never) && a.overlap >= 1 && a.overlap <= kWinMax &&
+           a.overlap <= a.g.sym_size - a.g.N;
 }
 
 int tf_max_fused_taps() { return DABGPU_KBND < kMaxTaps ? DABGPU_KBND : kMaxTaps; }

@@ -437,6 +437,54 @@ def test_chain_windowed_guard(pkg):
                 dict(gain_mode=2, normalise=1.0 / 50000.0, window_overlap=10), setup)
 
 
+@pytest.mark.parametrize("mode,overlap", [(1, 10), (1, 1), (1, 128), (2, 10), (2, 126), (3, 7), (3, 63), (4, 10)])
+@pytest.mark.parametrize("chunks", [1, 3, 77])
+@pytest.mark.parametrize("gain_mode", [None, 2, 1])
+def test_chain_windowed_guard_without_fir_is_windowed_by_the_frame_kernel(pkg, mode, overlap, chunks, gain_mode):
+    """ofdmwindowing > 0 without FIRFilter (f-4): tf_kernel<..., WIN> writes the raised-cosine seams itself -- every
+    chunking (the seam before a run's first symbol comes from the run before it), every mode, overlaps from one
+    sample to the widest the kernel takes / the whole cyclic prefix, with and without GainControl."""
+    if chunks == 77 and (mode != 1 or gain_mode == 1):
+        pytest.skip("one symbol per workgroup is exercised on Mode I")
+    def setup(md):
+        if gain_mode is not None:
+            md.set_gain(gain_mode, 1.0, 1.0 / 50000.0 if gain_mode == 2 else 1.0, 4.0)
+        md.set_window_overlap(overlap)
+    kw = dict(window_overlap=overlap)
+    if gain_mode is not None:
+        kw.update(gain_mode=gain_mode, normalise=1.0 / 50000.0 if gain_mode == 2 else 1.0)
+    y, ref = _chain_case(pkg, mode, pkg.STAGE_GAIN if gain_mode is not None else 0, chunks, 2, kw, setup)
+    # a6 + a7 along the chain: the transform's rounding plus the gain scalar's 2e-7 (SURVEY 8a); the seams add two
+    # products and one sum, rounded exactly as the reference rounds them
+    assert record_bound("a6+a7+a8 windowed chain max-abs / |out|_inf, mode %d overlap %d chunks %d gain %s"
+                        % (mode, overlap, chunks, gain_mode), np.abs(y - ref).max() / np.abs(ref).max(), 5e-7)
+
+
+def test_chain_windowed_guard_fused_equals_the_guard_kernel(pkg):
+    """The fused seams against GuardIntervalInserter's own kernel (bit-exact against the reference golden) fed with
+    the chain's symbols: the same two products and one sum per seam sample."""
+    md = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([golden_bits(1), synth_bits(per, seed=77)])
+        sym = md.chain(bits, pkg.STAGE_GAIN | pkg.STAGE_NOGUARD)          # gain-scaled symbols, no guard interval
+        md.set_window_overlap(10)
+        want = np.stack([md.guard(sym[f]) for f in range(2)])
+        got = md.chain(bits, pkg.STAGE_GAIN)
+        # (two instantiations of the frame kernel produced the symbols: same arithmetic, not necessarily the same rounding)
+        assert rel_rms(got.reshape(-1), want.reshape(-1).astype(np.complex128)) < 2e-7
+        # outside the seams the guard interval stays a copy, bit for bit
+        g = md.geometry
+        N, ns, ss, W = g["spacing"], g["null_size"], g["sym_size"], 10
+        cp = ss - N
+        for s_ in (0, 1, 40, 75):
+            o = ns + s_ * ss
+            assert bits_eq(got[0][o + W:o + cp - W], got[0][o + N + W:o + N + cp - W])
+    finally:
+        md.close()
+
+
 def test_chain_cfg4_resample_x4_and_poly(pkg):
     """BASELINE config 4: cfg 3 + Resampler 2.048 -> 8.192 Msps + MemlessPoly."""
     def setup(md):
