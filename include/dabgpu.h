@@ -209,6 +209,15 @@ DABGPU_API int dabgpu_format_process_dev(dabgpu_ctx *ctx, const void *d_in, size
                                          size_t *out_bytes, unsigned long long *d_num_clipped,
                                          void *stream);
 
+/* Host-side helper of the fused chain, no device involved: the inverse filter the Mode I frame kernel uses to
+ * correct the FIR outputs at symbol boundaries from the FILTERED symbols alone ("equalised
+ * boundary").  For `taps` (the reference's FIRFilter taps, src/FIRFilter.cpp:59-133) it returns in g[0 .. 160) the
+ * real filter with  x[n] = sum_j g[j] z[n - (j - 56)]  wherever z[n] = sum_j taps[j] x[n + j] (cyclically) and x
+ * has energy on the 1536 occupied carriers of a 2048-point symbol only; *fit = max |G H - 1| over those carriers.
+ * Returns DABGPU_OK when such a filter exists to 1e-7 (the chain then uses it), DABGPU_E_INVALID when the taps
+ * have no well-conditioned inverse there or ntaps != 45 (the chain keeps the packed dual transform). */
+DABGPU_API int dabgpu_fir_inverse_design(const float *taps, size_t ntaps, float *g, double *fit);
+
 /* ---- the fused chain ----------------------------------------------------- */
 
 /* FormatConverter as the last step of the chain (the reference wires it after cifPoly when the output is not

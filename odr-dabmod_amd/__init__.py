@@ -32,7 +32,7 @@ EXPORTS = [
     "dabgpu_chain_submit", "dabgpu_chain_collect", "dabgpu_set_cfr", "dabgpu_get_cfr_stats",
     "dabgpu_cic_equalizer_process", "dabgpu_set_tii", "dabgpu_tii_process",
     "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
-    "dabgpu_set_output_format", "dabgpu_get_num_clipped",
+    "dabgpu_set_output_format", "dabgpu_get_num_clipped", "dabgpu_fir_inverse_design",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -137,8 +137,20 @@ def load_library():
     lib.dabgpu_time_chain_dev.argtypes = [vp, vp, sz, u, vp, sz, C.c_int, C.POINTER(C.c_float)]
     lib.dabgpu_set_output_format.argtypes = [vp, C.c_int]
     lib.dabgpu_get_num_clipped.argtypes = [vp, szp]
+    lib.dabgpu_fir_inverse_design.argtypes = [C.POINTER(C.c_float), sz, C.POINTER(C.c_float), C.POINTER(C.c_double)]
     _lib = lib
     return lib
+
+
+def fir_inverse_design(taps):
+    """Host-side helper (no device): the 160-tap inverse of a 45-tap FIR on the occupied carriers of a Mode I symbol,
+    as the frame kernel's equalised-boundary variant uses it.  Returns (ok, g, fit)."""
+    lib = load_library()
+    taps = np.ascontiguousarray(taps, np.float32)
+    g = np.zeros(160, np.float32)
+    fit = C.c_double()
+    rc = lib.dabgpu_fir_inverse_design(_f32p(taps), taps.size, _f32p(g), C.byref(fit))
+    return rc == 0, g, fit.value
 
 
 def _f32p(a):

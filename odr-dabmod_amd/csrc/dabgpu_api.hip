@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <mutex>
 #include <string>
@@ -95,7 +96,10 @@ struct dabgpu_ctx {
     std::string err;
 
     // constant tables
-    DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_firh, d_window, d_coef;
+    DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_firh, d_window, d_coef, d_eqg;
+    bool use_eq = true;                   // tuning aid: environment DABGPU_EQ=0 when the context is created turns TF_EQ off
+    bool eq_ok = false;                   // d_eqg holds a well-conditioned inverse of the current taps (TF_EQ may be used)
+    double eq_fit = 0.0;                  // max |G H - 1| over the occupied bins
     // resampler
     DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo, d_rs_tw_s, d_rs_tw_l;
     int rs_nin = 0, rs_nout = 0;
@@ -198,6 +202,117 @@ template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v, hipS
     e = hipMemcpyAsync(b.p, v.data(), v.size() * sizeof(T), hipMemcpyHostToDevice, s);
     if (e != hipSuccess) return e;
     return hipStreamSynchronize(s);  // v may be a temporary
+}
+
+// Inverse of the FIR filter on the occupied carriers, for the equalised-boundary variant of the frame kernel
+// (tf_kernel<..., EQ>, dabgpu_kernels.hip): real g[0 .. L) with
+//     x[n] = sum_j g[j] z[n - (j - c)]      (z = x filtered cyclically, z[n] = sum_j taps[j] x[n + j]),
+// i.e. G[k] H[k] = 1 on the K occupied bins, G[k] = sum_j g[j] exp(-2 pi i k (j - c) / N), and little gain in the empty
+// band (stop-band rows weighted sqrt(lambda); the transition bins are free, which is what lets a short g fit to 1e-8).
+// Least squares over the bins k = 1 .. K/2 (g and the taps are real: the negative half follows by symmetry), solved by
+// Householder QR in float64 -- the normal equations of this problem are numerically singular.  Returns false when the
+// taps have no well-conditioned inverse (e.g. a zero of H inside the occupied band): the chain then keeps the packed
+// dual transform.  tools/design/inverse_filter_study.py is the numpy study behind the constants.
+bool design_inverse_filter(const std::vector<float> &taps, int N, int K, std::vector<float> &g_out, double *fit_out)
+{
+    const int L = kEqTaps, cen = kEqCentre;
+    const int edge = K / 2 + (N - K) / 4;
+    const double lambda = 1e-6;
+    const int nocc = K / 2, nstop = N / 2 - edge + 1, m = 2 * (nocc + nstop), n = L;
+    std::vector<double> A((size_t)m * n), b((size_t)m, 0.0);           // column-major
+    std::vector<double> hre(nocc + 1), him(nocc + 1);
+    for (int k = 1; k <= nocc; ++k) {
+        double re = 0.0, im = 0.0;
+        for (size_t j = 0; j < taps.size(); ++j) {
+            const double a = 2.0 * M_PI * (double)((j * (size_t)k) % (size_t)N) / (double)N;
+            re += (double)taps[j] * std::cos(a);
+            im += (double)taps[j] * std::sin(a);
+        }
+        hre[k] = re; him[k] = im;
+        const double d = re * re + im * im;
+        if (!(d > 1e-12)) return false;
+        b[2 * (k - 1)] = re / d;                                         // 1 / H
+        b[2 * (k - 1) + 1] = -im / d;
+    }
+    const double ws = std::sqrt(lambda);
+    for (int j = 0; j < n; ++j) {
+        double *col = &A[(size_t)j * m];
+        for (int r = 0; r < nocc + nstop; ++r) {
+            const int k = r < nocc ? r + 1 : edge + (r - nocc);
+            const double w = r < nocc ? 1.0 : ws;
+            const long q = ((long)k * (long)(j - cen)) % N;
+            const double a = -2.0 * M_PI * (double)q / (double)N;
+            col[2 * r] = w * std::cos(a);
+            col[2 * r + 1] = w * std::sin(a);
+        }
+    }
+    std::vector<double> v(m);
+    for (int k = 0; k < n; ++k) {
+        double *ck = &A[(size_t)k * m];
+        double nrm = 0.0;
+        for (int i = k; i < m; ++i) nrm += ck[i] * ck[i];
+        nrm = std::sqrt(nrm);
+        if (nrm == 0.0) return false;
+        const double alpha = ck[k] > 0.0 ? -nrm : nrm;
+        for (int i = k; i < m; ++i) v[i] = ck[i];
+        v[k] -= alpha;
+        double vv = 0.0;
+        for (int i = k; i < m; ++i) vv += v[i] * v[i];
+        if (vv == 0.0) return false;
+        auto reflect = [&](double *x) {
+            double dot = 0.0;
+            for (int i = k; i < m; ++i) dot += v[i] * x[i];
+            const double f = 2.0 * dot / vv;
+            for (int i = k; i < m; ++i) x[i] -= f * v[i];
+        };
+        for (int j = k + 1; j < n; ++j) reflect(&A[(size_t)j * m]);
+        reflect(b.data());
+        ck[k] = alpha;
+    }
+    std::vector<double> g(n);
+    for (int k = n - 1; k >= 0; --k) {
+        double acc = b[k];
+        for (int j = k + 1; j < n; ++j) acc -= A[(size_t)j * m + k] * g[j];
+        const double d = A[(size_t)k * m + k];
+        if (std::fabs(d) < 1e-300) return false;
+        g[k] = acc / d;
+    }
+    // what the kernel will use: the fp32 taps; fit over the occupied bins and the noise gain
+    g_out.assign((size_t)L + 1, 0.0f);
+    double norm2 = 0.0;
+    for (int j = 0; j < L; ++j) { g_out[j] = (float)g[j]; norm2 += (double)g_out[j] * (double)g_out[j]; }
+    double fit = 0.0;
+    for (int k = 1; k <= nocc; ++k) {
+        double re = 0.0, im = 0.0;
+        for (int j = 0; j < L; ++j) {
+            const long q = ((long)k * (long)(j - cen)) % N;
+            const double a = -2.0 * M_PI * (double)q / (double)N;
+            re += (double)g_out[j] * std::cos(a);
+            im += (double)g_out[j] * std::sin(a);
+        }
+        const double pr = re * hre[k] - im * him[k] - 1.0, pi = re * him[k] + im * hre[k];
+        fit = std::max(fit, std::sqrt(pr * pr + pi * pi));
+    }
+    if (fit_out) *fit_out = fit;
+    return fit < 1e-7 && norm2 < 4.0;
+}
+
+// (the design takes ~0.1 s: one per distinct set of taps and process)
+bool cached_inverse_filter(const std::vector<float> &taps, int N, int K, std::vector<float> &g, double *fit)
+{
+    struct Entry { std::vector<float> taps, g; int N, K; bool ok; double fit; };
+    static std::mutex mu;
+    static std::vector<Entry> cache;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const Entry &e : cache)
+        if (e.N == N && e.K == K && e.taps == taps) { g = e.g; if (fit) *fit = e.fit; return e.ok; }
+    Entry e{taps, {}, N, K, false, 0.0};
+    e.ok = design_inverse_filter(taps, N, K, e.g, &e.fit);
+    if (cache.size() >= 16) cache.erase(cache.begin());
+    cache.push_back(e);
+    g = e.g;
+    if (fit) *fit = e.fit;
+    return e.ok;
 }
 
 int build_tables(dabgpu_ctx *c)
@@ -306,6 +421,13 @@ int apply_settings_groups(dabgpu_ctx *c)
             h[k] = make_float2((float)re, (float)im);
         }
         HIPCHK(c, upload(c->d_firh, h, s));
+        // the equalised-boundary variant of the frame kernel (Mode I, 45 taps): the taps' inverse on the occupied bins
+        c->eq_ok = false;
+        if (c->g.logN == 11 && c->cur.taps.size() == 45) {
+            std::vector<float> g;
+            c->eq_ok = cached_inverse_filter(c->cur.taps, N, c->g.K, g, &c->eq_fit);
+            if (c->eq_ok) HIPCHK(c, upload(c->d_eqg, g, s));
+        }
     }
     if (window_changed) {
         // src/GuardIntervalInserter.cpp:106-111
@@ -400,6 +522,7 @@ Tables tables_of(dabgpu_ctx *c)
     t.taps = (const float *)c->d_taps.p;
     t.window = (const float *)c->d_window.p;
     t.fir_h = (const float2 *)c->d_firh.p;
+    t.eq_g = c->eq_ok ? (const float *)c->d_eqg.p : nullptr;
     return t;
 }
 
@@ -578,6 +701,9 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
         if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
         if (s16_clipped) flags |= TF_OUT_S16;
+        // cfg 3 chain: the filtered transform alone with equalised boundaries (DABGPU_EQ=0 at dabgpu_create: the packed
+        // dual transform)
+        if (c->use_eq && tf_has_eq(a, flags)) flags |= TF_EQ;
         a.chunks_per_frame = auto_chunks(c, n_frames);
         a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
         a.out = native_out;
@@ -859,6 +985,7 @@ int dabgpu_create(const dabgpu_config *cfg, dabgpu_ctx **out)
     c->device = cfg->device;
     c->max_frames = std::max(1, cfg->max_frames);
     c->chunks_cfg = cfg->chunks_per_frame;
+    { const char *e = getenv("DABGPU_EQ"); c->use_eq = !e || atoi(e) != 0; }
     auto bail = [&](int rc) {
         g_create_error = c->err;
         dabgpu_destroy(c);
@@ -883,7 +1010,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
-    for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh,
+    for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh, &c->d_eqg,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
                       &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count, &c->d_fmt, &c->d_clip,
                       &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1, &c->d_cic,
@@ -1359,6 +1486,17 @@ int dabgpu_poly_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *ou
 }
 
 // ---- f-2 FormatConverter -------------------------------------------------------
+
+int dabgpu_fir_inverse_design(const float *taps, size_t ntaps, float *g, double *fit)
+{
+    if (!taps || !g || ntaps != 45) return DABGPU_E_INVALID;
+    std::vector<float> t(taps, taps + ntaps), out;
+    double f = 0.0;
+    const bool ok = cached_inverse_filter(t, 2048, 1536, out, &f);
+    if (fit) *fit = f;
+    if (out.size() >= (size_t)kEqTaps) std::copy(out.begin(), out.begin() + kEqTaps, g);
+    return ok ? DABGPU_OK : DABGPU_E_INVALID;
+}
 
 size_t dabgpu_format_size(int format)
 {

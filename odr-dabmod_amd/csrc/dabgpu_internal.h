@@ -8,6 +8,8 @@
 namespace dabgpu {
 
 constexpr int kMaxTaps = 128;        // fused (spectral) FIR of the frame kernel
+constexpr int kEqTaps = 160;         // length of the inverse filter of the equalised-boundary variant (TF_EQ), centre at kEqCentre:
+constexpr int kEqCentre = 56;        //   x[n] = sum_j eq_g[j] z[n - (j - kEqCentre)]
 constexpr int kMaxTapsUnfused = 512; // direct FIR kernels (the chain falls back to them for longer filters)
 
 // Transmission-mode geometry (reference src/DabModulator.cpp:84-122).
@@ -31,6 +33,7 @@ struct Tables {
     const float *taps;            // kMaxTaps floats, zero padded
     const float *window;          // 2*overlap floats (guard-interval raised cosine)
     const float2 *fir_h;          // N: frequency response of the taps, sum_j taps[j] e^{+2 pi i jk/N}
+    const float *eq_g;            // TF_EQ: kEqTaps + 1 floats, the inverse of the taps on the occupied bins (see tf_kernel<..., EQ>)
 };
 
 struct GainParams {
@@ -66,11 +69,12 @@ struct TfArgs {
 };
 
 enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */,
-               TF_OUT_S16 = 64, TF_LEAN = 128 /* internal */, TF_WINDOW = 256 };
+               TF_OUT_S16 = 64, TF_LEAN = 128 /* internal */, TF_WINDOW = 256, TF_EQ = 512 };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0);
 int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
+bool tf_has_eq(const TfArgs &a, unsigned flags);     // the equalised-boundary variant exists for this chain (TF_EQ; needs t.eq_g)
 bool tf_has_window(const TfArgs &a, unsigned flags); // a frame-kernel variant windows the guard interval itself (TF_WINDOW)
 bool tf_has_s16(const TfArgs &a, unsigned flags);   // a frame-kernel variant stores s16 itself (TF_OUT_S16)
 

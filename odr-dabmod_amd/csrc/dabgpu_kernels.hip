@@ -83,6 +83,9 @@
 #define DABGPU_TF_LEAN 0        // cfg 3 kernel (Mode I coded-bits chain, ZONLY): LDS trimmed to 40 KB and 128 registers asked for,
                                // i.e. FOUR workgroups (16 waves) per CU instead of three
 #endif
+#ifndef DABGPU_EQ_WAVES
+#define DABGPU_EQ_WAVES 3       // waves per SIMD asked for the equalised-boundary variant (tf_kernel<..., EQ>)
+#endif
 #ifndef DABGPU_CFR_WAVES
 #define DABGPU_CFR_WAVES 2      // waves per SIMD asked for the crest-factor-reduction variants
 #endif
@@ -943,6 +946,14 @@ constexpr unsigned kCX = 0x901Au;
 #ifndef DABGPU_KBND
 #define DABGPU_KBND 128
 #endif
+#ifndef DABGPU_EQ_MFMA
+#define DABGPU_EQ_MFMA 0        // EQ variant: the inverse filter as a 16 x 176 by 176 x 6 product on the matrix cores instead of
+                                // packed FMAs.  Measured, same box: 2.25 M TF/s against 2.32 M with the VALU form (cfg 3, 32768
+                                // frames) -- eleven 32-cycle v_mfma_f32_16x16x4_f32 per wave and symbol with six of sixteen columns
+                                // in use, two LDS dwords per instruction and a second barrier for the four waves' partial sums cost
+                                // more than 80 FMAs and four DPP steps per lane.  Kept as a knob.
+#endif
+constexpr int kEqElems = 3 * 208 + 48 + (kEqTaps + 8) / 2 + (DABGPU_EQ_MFMA ? 96 + 192 : 0);   // cf slots of LDS the EQ variant keeps (see tf_kernel)
 constexpr int kWinMax = 128;       // widest raised-cosine overlap the frame kernel applies itself (TF_WINDOW)
 constexpr int kBnd = DABGPU_KBND;  // LDS slots per boundary buffer; the fused FIR handles ntaps <= kBnd
 
@@ -983,10 +994,20 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // symbol s-1 followed by its first W (the suffix written past its end) and rise = samples [N-cp-W, N-cp+W) of symbol
 // s.  The 2W + 2W samples go through LDS; the seam before a run's first symbol is written by the run before it,
 // which transforms that symbol too (look-ahead, as with the FIR).
+// EQ (Mode I coded-bits chain with the 45-tap FIR, gain none / fix / var -- the cfg 3 chain): ONE transform per symbol,
+// of the FILTERED spectrum X H, instead of the packed (unfiltered, filtered) pair.  The 44 outputs between two symbols
+// that the cyclic filtering gets wrong are corrected from the filtered symbols alone:
+//     y[N-44+i] = z_prev[N-44+i] + sum_{j >= 44-i} taps[j] d[i+j-44],   d[m] = x_cur[N-cp+m] - x_prev[m]
+// (the cyclic result looked into x_prev's own start where the stream continues with x_cur's prefix), and the
+// unfiltered difference d comes out of a short inverse filter g of the taps (G H = 1 on the occupied bins -- the only
+// ones a symbol has energy in; designed on the host, dabgpu_api.hip design_inverse_filter):
+//     d[m] = sum_j g[j] w[m - (j - c)],   w[q] = z_cur[N-cp+q] - z_prev[q mod N],   q in [-103, 99].
+// 44 x 160 + 990 real-by-complex multiply-adds per symbol replace half of a packed 2048-point transform, its 16-byte
+// exchanges and the pack / unpack around it.
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
-          bool ZONLY = false, int OFMT = 0, bool WIN = false>
+          bool ZONLY = false, int OFMT = 0, bool WIN = false, bool EQ = false>
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             CFR ? DABGPU_CFR_WAVES : !FIR ? 2 : (GVAR ? DABGPU_GVAR_WAVES
+                             EQ ? DABGPU_EQ_WAVES : CFR ? DABGPU_CFR_WAVES : !FIR ? 2 : (GVAR ? DABGPU_GVAR_WAVES
                                                   : ((GAIN && !FROM_BITS && DABGPU_TF_WAVES_CARRIERS_GAIN) ? 2
                                                      : ((DABGPU_TF_LEAN && ZONLY && FROM_BITS) ? 4 : DABGPU_TF_WAVES))))
 void tf_kernel(const TfArgs a)
@@ -998,10 +1019,12 @@ void tf_kernel(const TfArgs a)
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
     static_assert(!WIN || (FROM_BITS && GUARD && !FIR && !CFR && OFMT == 0), "WIN: coded-bits chain, guard interval, no FIR");
+    static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY && !WIN),
+                  "EQ: the Mode I coded-bits chain with the 45-tap filter");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
-    constexpr bool DBUF = !FIR || DABGPU_FFT_DBUF;   // exchange buffers: see DABGPU_FFT_DBUF
+    constexpr bool DBUF = !FIR || EQ || DABGPU_FFT_DBUF;   // exchange buffers: see DABGPU_FFT_DBUF
     const int t = threadIdx.x;
     const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
     const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
@@ -1014,7 +1037,7 @@ void tf_kernel(const TfArgs a)
     // (LEAN: the row layout of the first exchange, 8 x (T + 4) elements, is the largest image the pruned dual
     // transform keeps in the buffer -- the padded size below is never used)
     constexpr int kXElems = LEAN ? 2 * 8 * F::X1_PITCH
-                          : (FIR && DABGPU_DUAL_FFT) ? ((!DBUF && DABGPU_C2_PAD_SHIFT == 4) ? 2 * F::LDS_ELEMS2 : 2 * (DBUF ? 2 : 1) * F::LDS_ELEMS)
+                          : (FIR && DABGPU_DUAL_FFT && !EQ) ? ((!DBUF && DABGPU_C2_PAD_SHIFT == 4) ? 2 * F::LDS_ELEMS2 : 2 * (DBUF ? 2 : 1) * F::LDS_ELEMS)
                                                       : (DBUF ? 2 : 1) * F::LDS_ELEMS;
     static_assert(!LEAN || (F::X1_ROWS && 8 * F::X1_PITCH >= N && 2 * 8 * F::X1_PITCH * 8 >= (2 * N + 4 * T) * 4), "LEAN buffer");
     double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
@@ -1030,7 +1053,19 @@ void tf_kernel(const TfArgs a)
     // WIN: two seam buffers [last W | first W samples of a symbol], the rising 2W samples of the next one, the window
     cf *wbuf = bnd;
     float *win_l = reinterpret_cast<float *>(wbuf + 6 * kWinMax);
-    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (FIR ? 4 * KB : (WIN ? 7 * kWinMax : 0)));
+    // EQ: two windows of the previous filtered symbol (index q + kEqQL, q in [-kEqQL, kEqQH]), the difference w, the
+    // 44 unfiltered differences d, the inverse filter
+    // (kEqW: the matrix-core form reads w up to index 175 + 32; the tail past kEqQL + kEqQH stays zero)
+    constexpr int kEqQL = kEqTaps - 1 - kEqCentre, kEqQH = 43 + kEqCentre, kEqW = 208;
+    static_assert(kEqQL + kEqQH + 1 <= kEqW && kEqTaps == 160, "EQ window");
+    static_assert(kEqElems == 3 * kEqW + 48 + (kEqTaps + 8) / 2 + (DABGPU_EQ_MFMA ? 96 + 192 : 0), "LDS share of the EQ variant (tf_lds_bytes)");
+    cf *eq_zp = bnd, *eq_w = bnd + 2 * kEqW, *eq_d = eq_w + kEqW;
+    float *g_l = reinterpret_cast<float *>(eq_d + 48);
+    // matrix-core form: gp[idx + 16] = g[idx] for idx in [0, 160), zero around it (192 floats); partial sums of the
+    // four waves, [wave][output m < 48][re | im]
+    float *gp_l = g_l + (kEqTaps + 8);
+    float *eq_part = gp_l + 192;
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : FIR ? 4 * KB : (WIN ? 7 * kWinMax : 0)));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
     // small read-only tables copied to LDS once: read through global memory they compile to
@@ -1058,6 +1093,13 @@ void tf_kernel(const TfArgs a)
         unit8[t] = mk(cx, cy);
     }
     for (int i = t; i < kTapsL; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
+    if (EQ)
+        for (int i = t; i < kEqTaps + 8; i += blockDim.x) g_l[i] = i < kEqTaps ? a.t.eq_g[i] : 0.f;
+    if (EQ) {
+        if (DABGPU_EQ_MFMA)
+            for (int i = t; i < 192; i += blockDim.x) gp_l[i] = (i >= 16 && i < 16 + kEqTaps) ? a.t.eq_g[i - 16] : 0.f;
+        for (int i = t; i < 3 * kEqW; i += blockDim.x) eq_zp[i] = mk(0.f, 0.f);     // (both windows, w: the tails stay zero)
+    }
     const int W = WIN ? a.overlap : 0;
     if (WIN)
         for (int i = t; i < 2 * W; i += blockDim.x) win_l[i] = a.t.window[i];
@@ -1470,6 +1512,93 @@ void tf_kernel(const TfArgs a)
         }
     };
 
+    // EQ: the 44 boundary outputs of the previous segment from the filtered symbols (see the template's comment).
+    // zp = the previous symbol's windows; eq_w holds w (written by the lanes that own those samples, a barrier ago).
+    auto eq_boundary = [&](const cf *zp) __attribute__((always_inline)) {
+        // d = g (*) w: 11 blocks of four outputs x 16 groups of ten taps = 176 lanes, the 16 groups of a block being one
+        // DPP row.  Output m = m0 + r, tap jj = j0 + u reads w[q] at index q + kEqQL = m + (kEqTaps - 1 - jj).
+#if DABGPU_EQ_MFMA
+        // d[m] = sum_u g'[u] w[m + u], g'[u] = g[159 - u], as ONE 16 x 176 by 176 x 6 product:
+        //     D[i][(j, c)] = sum_k A[i][k] B[k][(j, c)],  A[i][k] = g'[k - i] (Toeplitz),  B[k][(j, c)] = w[k + 16 j].c
+        // gives d[i + 16 j].c -- three blocks of sixteen outputs, re and im, in six of the sixteen columns of
+        // v_mfma_f32_16x16x4_f32 (exact f32 products and sums).  The 44 steps of k are split over the four waves; lane l
+        // feeds A[l & 15][k = 4 p + (l >> 4)] and B[k][l & 15]: one LDS dword each per step, at base + immediate.
+        {
+            typedef float f32x4 __attribute__((ext_vector_type(4)));
+            const int wv = __builtin_amdgcn_readfirstlane(t >> 6), l = t & 63;
+            const int i = l & 15, kk = l >> 4, jc = min(l & 15, 5);
+            const float *ap = gp_l + (175 - kk + i) - 44 * wv;
+            const float *bp = reinterpret_cast<const float *>(eq_w) + 2 * (kk + 16 * (jc >> 1) + 44 * wv) + (jc & 1);
+            float av[11], bv[11];
+#pragma unroll
+            for (int p = 0; p < 11; ++p) { av[p] = ap[-4 * p]; bv[p] = bp[8 * p]; }
+            f32x4 acc0 = {0.f, 0.f, 0.f, 0.f}, acc1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int p = 0; p < 11; ++p) {
+                if (p & 1) acc1 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p], acc1, 0, 0, 0);
+                else acc0 = __builtin_amdgcn_mfma_f32_16x16x4f32(av[p], bv[p], acc0, 0, 0, 0);
+            }
+            acc0 += acc1;
+            // D[row = 4 (l >> 4) + r][col = l & 15]  ->  eq_part[wave][m = row + 16 j][c]
+            if ((l & 15) < 6) {
+                float *pp = eq_part + 96 * wv + 2 * (4 * kk + 16 * (jc >> 1)) + (jc & 1);
+                pp[0] = acc0[0]; pp[2] = acc0[1]; pp[4] = acc0[2]; pp[6] = acc0[3];
+            }
+        }
+        lds_barrier();
+        if (t < 96) {
+            float *df = reinterpret_cast<float *>(eq_d);
+            df[t] = (eq_part[t] + eq_part[96 + t]) + (eq_part[192 + t] + eq_part[288 + t]);
+        }
+#else
+        cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+#ifdef DABGPU_EXPERIMENT_EQ_NODECONV
+        if (t < 0) {                     // timing experiment (wrong boundary outputs): no deconvolution
+#else
+        if (t < 176) {
+#endif
+            const int m0 = 4 * (t >> 4), j0 = 10 * (t & 15);
+            const cf *wp = eq_w + (m0 + (kEqTaps - 1 - 9) - j0);
+            const float2 *g2 = reinterpret_cast<const float2 *>(g_l + j0);
+            cf wv[13];
+            float gg[10];
+#pragma unroll
+            for (int i = 0; i < 13; ++i) wv[i] = wp[i];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { const float2 g = g2[u]; gg[2 * u] = g.x; gg[2 * u + 1] = g.y; }
+#pragma unroll
+            for (int u = 0; u < 10; ++u)
+#pragma unroll
+                for (int r = 0; r < 4; ++r) acc[r] = axpy(acc[r], gg[u], wv[r + 9 - u]);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            acc[r].x += dpp_mov<0xB1>(acc[r].x);  acc[r].y += dpp_mov<0xB1>(acc[r].y);
+            acc[r].x += dpp_mov<0x4E>(acc[r].x);  acc[r].y += dpp_mov<0x4E>(acc[r].y);
+            acc[r].x += dpp_mov<0x124>(acc[r].x); acc[r].y += dpp_mov<0x124>(acc[r].y);
+            acc[r].x += dpp_mov<0x128>(acc[r].x); acc[r].y += dpp_mov<0x128>(acc[r].y);
+        }
+        if (t < 176 && (t & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) eq_d[4 * (t >> 4) + r] = acc[r];
+        }
+#endif
+        lds_barrier();
+        // y[N-44+i] = z_prev[N-44+i] + sum_{jd <= i} taps[44-i+jd] d[jd]: four lanes (one DPP quad) per output, lane q
+        // taking jd = q, q+4, ...; past jd = i the tap index runs into the table's zero padding
+        {
+            const int i = min(t >> 2, C - 1), q = t & 3;
+            const float *tq = taps_l + (C - i) + q;
+            const cf *dq = eq_d + q;
+            cf y = mk(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
+            y.x += dpp_mov<0xB1>(y.x); y.y += dpp_mov<0xB1>(y.y);
+            y.x += dpp_mov<0x4E>(y.x); y.y += dpp_mov<0x4E>(y.y);
+            if (t < 4 * C && q == 0) put(prev_pos + prev_seg - C, t >> 2, cadd(y, zp[kEqQL - C + i]));
+        }
+    };
+
     // Input of symbol s+1 is requested while symbol s is being transformed and BEFORE
     // symbol s is stored: vmcnt retires in order, so a load issued after the stores would
     // make every symbol wait for the previous symbol's HBM writes.
@@ -1485,8 +1614,12 @@ void tf_kernel(const TfArgs a)
         const int nz = len0 - C - W;                  // the last C outputs belong to `boundary` (W: to the seam)
         for (int i0 = 0; i0 < nz; i0 += kThreads)
             if (i0 + t < nz) put(i0, t, mk(0.f, 0.f));
-        if (FIR) {
+        if (EQ) {
+            for (int i = t; i < kEqW; i += (int)blockDim.x) eq_zp[cur * kEqW + i] = mk(0.f, 0.f);
+        } else if (FIR) {
             for (int i = t; i < KB; i += (int)blockDim.x) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
+        }
+        if (FIR) {
             have_prev = true;
             prev_pos = 0;
             prev_seg = len0;
@@ -1550,7 +1683,7 @@ void tf_kernel(const TfArgs a)
             if (GAIN && !CFR && (GVAR || a.gain.mode == 2) && s > 0)
                 spectral_partial(val, reinterpret_cast<float *>(red + 8 * (s & 1)));   // combined after the transform
         }
-        constexpr bool DUAL = FIR && DABGPU_DUAL_FFT;
+        constexpr bool DUAL = FIR && DABGPU_DUAL_FFT && !EQ;
         cf z[8];                                  // DUAL: the filtered symbol
         cf uedge = mk(0.f, 0.f);                  // ZONLY: the lane's boundary sample of the unfiltered symbol
         if (DUAL && CFR) {
@@ -1587,6 +1720,11 @@ void tf_kernel(const TfArgs a)
                 }
             }
         } else {
+            if (EQ) {
+                // the filtered spectrum alone
+#pragma unroll
+                for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
+            }
             place(val, v);
             F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
             if (CFR) {
@@ -1622,7 +1760,7 @@ void tf_kernel(const TfArgs a)
                 g = spectral_gain(reinterpret_cast<const float *>(red + 8 * (s & 1)));
             } else if (GVAR) {
                 g = g_null;                                   // s == 0
-            } else if (ZONLY) {
+            } else if (ZONLY || EQ) {
                 g = 512.0f;                                   // mode fix (the launcher keeps mode max off this variant)
             } else {
                 g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
@@ -1635,8 +1773,8 @@ void tf_kernel(const TfArgs a)
 
         // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the
         // (unfiltered, filtered) pairs the dual transform left side by side; everything below uses v and z as is
-        constexpr bool PRESCALED = (DUAL || WIN) && GAIN;
-        if (WIN && GAIN) {
+        constexpr bool PRESCALED = (DUAL || WIN || EQ) && GAIN;
+        if ((WIN || EQ) && GAIN) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cscale(v[m], g);
         } else if (PRESCALED && ZONLY) {
@@ -1659,7 +1797,21 @@ void tf_kernel(const TfArgs a)
         const int seg = N + cpl;
         // position of this segment in the frame's output stream
         const int pos = GUARD ? (s == 0 ? 0 : len0 + (s - 1) * len) : s * N;
-        if (FIR) {
+        if constexpr (EQ) {
+            // ---- the windows of the filtered, gain-scaled symbol that the boundary outputs need ----
+            // w[q] = z_cur[N - cp + q] - z_prev[q mod N] for q in [-kEqQL, kEqQH], written by the lanes that hold
+            // z_cur[N - cp + q] (slots 5 and 6); the symbol's own windows around its start (slots 7 and 0) are parked
+            // for the next symbol.  Index of q everywhere: q + kEqQL.
+            cf *zp_prev = eq_zp + cur * kEqW, *zp_new = eq_zp + (cur ^ 1) * kEqW;
+            constexpr int n0 = (N - cp) - kEqQL;              // first sample of the window in z_cur (1441)
+            static_assert(!EQ || (n0 >= 5 * T && n0 + kEqQL + kEqQH < 7 * T && kEqQL < T && kEqQH < T), "EQ windows: slots 5, 6, 7, 0");
+            if (t >= n0 - 5 * T) { const int iw = t - (n0 - 5 * T); eq_w[iw] = csub(v[5], zp_prev[iw]); }
+            if (t <= n0 + kEqQL + kEqQH - 6 * T) { const int iw = t + (6 * T - n0); eq_w[iw] = csub(v[6], zp_prev[iw]); }
+            if (t >= T - kEqQL) zp_new[t - (T - kEqQL)] = v[7];
+            if (t <= kEqQH) zp_new[kEqQL + t] = v[0];
+            lds_barrier();
+            // (the boundary outputs follow the symbol's own stores, below: its samples are dead registers by then)
+        } else if (FIR) {
             // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
             cf *tail_new = bnd + (cur ^ 1) * 2 * KB, *tail_prev = bnd + cur * 2 * KB, *head = tail_prev + C;
             if (lane_on) {
@@ -1735,8 +1887,8 @@ void tf_kernel(const TfArgs a)
             cur ^= 1;
         }
         if (FROM_BITS) bb ^= 1;
-        if (lookahead) break;
-        if (lane_on) {
+        if (lookahead && !EQ) break;
+        if (lane_on && !(EQ && lookahead)) {
             const int m_cp = (N - cpl) / T;   // first register slot that is also copied into the prefix
             const bool keep_tail = !WIN || s == nsym - 1;    // WIN: the last W samples belong to the next seam
 #pragma unroll
@@ -1748,11 +1900,25 @@ void tf_kernel(const TfArgs a)
                 if ((m > m_cp || (m == m_cp && n >= N - cpl)) && (!WIN || n - (N - cpl) >= W)) put(pos, n - (N - cpl), y);
             }
         }
+        if constexpr (EQ) {
+#ifndef DABGPU_EXPERIMENT_NOBND
+            if (have_prev) eq_boundary(eq_zp + cur * kEqW);
+#endif
+            cur ^= 1;
+            if (lookahead) break;
+        }
         have_prev = true;
         prev_pos = pos;
         prev_seg = seg;
     }
-    if (FIR && s_end == nsym && have_prev) {
+    if (EQ && s_end == nsym && have_prev) {
+        // end of the frame: nothing follows (a zero symbol: w = -z_prev), missing terms are dropped
+        const cf *zp = eq_zp + cur * kEqW;
+        lds_barrier();
+        for (int i = t; i < kEqW; i += (int)blockDim.x) eq_w[i] = mk(-zp[i].x, -zp[i].y);
+        lds_barrier();
+        eq_boundary(zp);
+    } else if (FIR && s_end == nsym && have_prev) {
         // end of the frame: the look-ahead runs off the buffer, missing terms are
         // dropped (reference src/FIRFilter.cpp:186-191)
         lds_barrier();
@@ -1788,6 +1954,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     if (fr && !gd) return hipErrorInvalidValue;
     if ((flags & TF_OUT_S16) && !tf_has_s16(a, flags)) return hipErrorInvalidValue;
     if ((flags & TF_WINDOW) && !tf_has_window(a, flags)) return hipErrorInvalidValue;
+    if ((flags & TF_EQ) && !tf_has_eq(a, flags)) return hipErrorInvalidValue;
     if (flags & TF_CFR) {
         // with the whole fused epilogue (guard + FIR) or with none of it
         if (gd != fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
@@ -1822,6 +1989,16 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         return hipGetLastError();
     }
     if (LOGN == 11 && NT == 45 && fb && fr && gd && DABGPU_ZONLY && (!gn || a.gain.mode != 1)) {
+        if (flags & TF_EQ) {
+            // ... or the one that runs the filtered transform alone and equalises the boundary (needs the taps' inverse)
+            if (!a.t.eq_g || ((flags & TF_OUT_S16) && !a.clipped)) return hipErrorInvalidValue;
+#define TF_LAUNCH_EQ(GN, OF) \
+            hipLaunchKernelGGL((tf_kernel<11, true, GN, true, true, 45, false, false, false, OF, false, true>), grid, block, lds, s, a)
+            if (flags & TF_OUT_S16) { if (gn) TF_LAUNCH_EQ(true, 1); else TF_LAUNCH_EQ(false, 1); }
+            else                    { if (gn) TF_LAUNCH_EQ(true, 0); else TF_LAUNCH_EQ(false, 0); }
+#undef TF_LAUNCH_EQ
+            return hipGetLastError();
+        }
         // Mode I, default filter length, gain fix / var (or none): the variant that prunes the unfiltered transform
         if (flags & TF_OUT_S16) {
             if (!a.clipped) return hipErrorInvalidValue;
@@ -1857,13 +2034,15 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
                4 * (size_t)(nt - 1) * sizeof(float2) + 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t) +
                (size_t)(nt + 3 + 80) * sizeof(float) + (64 + 56 + 448) * sizeof(float2);
     }
-    const bool dbuf = !(flags & TF_FIR) || DABGPU_FFT_DBUF;
-    const bool dual = (flags & TF_FIR) && DABGPU_DUAL_FFT;
+    const bool eq = flags & TF_EQ;
+    const bool dbuf = !(flags & TF_FIR) || eq || DABGPU_FFT_DBUF;
+    const bool dual = (flags & TF_FIR) && DABGPU_DUAL_FFT && !eq;
     size_t b = dual ? ((!dbuf && DABGPU_C2_PAD_SHIFT == 4) ? (N + N / 16) : (dbuf ? 2 : 1) * (N + N / 8)) * 2 * sizeof(float2)
                     : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
     b += 16 * sizeof(double);
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
-    if (flags & TF_FIR) b += 4 * (nt ? nt - 1 : DABGPU_KBND) * sizeof(float2);  // 2 x [tail | next head]
+    if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter
+    else if (flags & TF_FIR) b += 4 * (nt ? nt - 1 : DABGPU_KBND) * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
 #if DABGPU_TW8_LDS
@@ -1885,6 +2064,14 @@ bool tf_has_window(const TfArgs &a, unsigned flags)
 }
 
 int tf_max_fused_taps() { return DABGPU_KBND < kMaxTaps ? DABGPU_KBND : kMaxTaps; }
+
+// the equalised-boundary variant: the chains of the pruned-dual-transform variant, given the inverse of the taps
+bool tf_has_eq(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
+    return a.t.eq_g != nullptr && a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & (TF_CFR | TF_WINDOW)) &&
+           (!(flags & TF_GAIN) || a.gain.mode != 1);
+}
 
 // the frame-kernel variants that store s16 themselves: Mode I coded-bits chain, guard + default-length filter,
 // gain none / fix / var, no CFR

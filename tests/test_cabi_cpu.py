@@ -63,3 +63,30 @@ def test_product_does_not_reference_the_oracle():
                 if re.search(r"\boracle\b|dab_oracle|liboracle|dabo_", txt):
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_fir_inverse_design_is_host_logic_and_inverts_the_filter_on_the_occupied_carriers():
+    """The inverse filter behind the frame kernel's equalised boundary (host code, no device): for the reference's
+    default taps G H = 1 on the 1536 occupied bins to < 1e-7, the noise gain |g|_2 is about one, and a symbol that
+    lives on those bins comes back from its cyclically filtered self; taps with a notch inside the band, or another
+    tap count, are refused (the chain then keeps the packed dual transform)."""
+    import numpy as np
+    import oracle as O
+    pkg = load_pkg()
+    taps = O.fir_default_taps()
+    ok, g, fit = pkg.fir_inverse_design(taps)
+    assert ok and fit < 1e-7 and 0.9 < float(np.sqrt((g.astype(np.float64) ** 2).sum())) < 1.1
+    N, K = 2048, 1536
+    occ = np.r_[1:K // 2 + 1, N - K // 2:N]
+    H = (taps.astype(np.float64)[None, :] * np.exp(2j * np.pi * np.outer(np.arange(N), np.arange(45)) / N)).sum(1)
+    G = (g.astype(np.float64)[None, :] * np.exp(-2j * np.pi * np.outer(np.arange(N), np.arange(160) - 56) / N)).sum(1)
+    assert np.abs(G[occ] * H[occ] - 1).max() < 1e-7
+    rs = np.random.RandomState(5)
+    X = np.zeros(N, complex)
+    X[occ] = np.exp(1j * np.pi / 4 * rs.randint(0, 8, K))
+    x, z = np.fft.ifft(X) * N, np.fft.ifft(X * H) * N            # z[n] = sum_j taps[j] x[n + j], cyclically
+    back = sum(float(g[j]) * np.roll(z, j - 56) for j in range(160))
+    assert np.abs(back - x).max() < 1e-7 * np.abs(x).max()
+    notch = np.convolve(taps[:43].astype(np.float64), [1, -2 * np.cos(2 * np.pi * 300 / N), 1]).astype(np.float32)
+    assert notch.size == 45 and not pkg.fir_inverse_design(notch)[0]
+    assert not pkg.fir_inverse_design(taps[:44])[0]

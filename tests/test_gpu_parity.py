@@ -395,6 +395,86 @@ def test_chain_cfg3_gain_var_fir(pkg, mode, chunks):
                         np.abs(y - ref).max() / np.abs(ref).max(), 7e-7)
 
 
+def _with_env(name, value, fn):
+    old = os.environ.get(name)
+    os.environ[name] = value
+    try:
+        return fn()
+    finally:
+        if old is None:
+            del os.environ[name]
+        else:
+            os.environ[name] = old
+
+
+@pytest.mark.parametrize("gain", [(2, 1.0 / 50000.0), (0, 1.0), (None, 0)])
+@pytest.mark.parametrize("chunks", [1, 7, 77])
+def test_cfg3_equalised_boundary_variant_against_the_packed_dual_transform(pkg, gain, chunks):
+    """The two Mode I frame kernels of the cfg 3 chain -- filtered transform alone with the boundary outputs
+    reconstructed through the taps' inverse (default), and the packed unfiltered + filtered pair (DABGPU_EQ=0 when
+    the context is created) -- against the oracle and against each other, every chunking (one symbol per workgroup:
+    every boundary crosses a run), frame start and frame end included."""
+    def make(eq):
+        return _with_env("DABGPU_EQ", eq, lambda: pkg.Modulator(mode=1, max_frames=3, chunks_per_frame=chunks))
+    a, b = make("1"), make("0")
+    try:
+        stages = pkg.STAGE_FIR | (pkg.STAGE_GAIN if gain[0] is not None else 0)
+        kw = {}
+        if gain[0] is not None:
+            for m in (a, b):
+                m.set_gain(gain[0], 1.0, gain[1], 4.0)
+            kw = dict(gain_mode=gain[0], normalise=gain[1])
+        per = a.geometry["tf_input_bytes"]
+        bits = np.stack([golden_bits(1)] + [synth_bits(per, seed=3100 + i) for i in range(2)])
+        ya, yb = a.chain(bits, stages), b.chain(bits, stages)
+        ref = O.Chain(mode=1, stages=stages & 0xF, **kw).process(bits)
+        g = a.geometry
+        ns, ss = g["null_size"], g["sym_size"]
+        for f in range(3):
+            assert rel_rms(ya[f], ref[f]) < REL_RMS and rel_rms(yb[f], ref[f]) < REL_RMS
+            assert rel_rms(ya[f], yb[f].astype(np.complex128)) < 3e-7
+        assert not bits_eq(ya, yb)                                   # (two different kernels did run)
+        # the 44 outputs before every symbol boundary and at the end of the frame are where the variants differ in kind
+        ends = [ns + s_ * ss for s_ in range(0, 77)]
+        idx = np.concatenate([np.arange(e - 44, e) for e in ends])
+        scale = np.abs(ref).max()
+        assert record_bound("cfg3 equalised boundary outputs max-abs / |out|_inf, chunks %d gain %s" % (chunks, gain[0]),
+                            np.abs(ya[:, idx] - ref[:, idx]).max() / scale, 7e-7)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_cfg3_other_45_tap_filters_with_and_without_an_inverse(pkg):
+    """45 taps that are not the default ones: a wider low-pass (invertible on the occupied carriers: the equalised
+    variant runs with its own inverse filter) and one with a notch inside the band (no inverse: the chain silently keeps
+    the packed dual transform).  Both match the oracle."""
+    from scipy.signal import firwin
+    wide = firwin(45, 900e3, window="hamming", fs=2.048e6).astype(np.float32)
+    notch = np.convolve(O.fir_default_taps()[:43].astype(np.float64), [1, -2 * np.cos(2 * np.pi * 300 / 2048), 1]).astype(np.float32)
+    assert pkg.fir_inverse_design(wide)[0] and not pkg.fir_inverse_design(notch)[0]
+    for taps in (wide, notch):
+        def setup(md):
+            md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_fir_taps(taps)
+        _chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, 3, 2, dict(gain_mode=2, normalise=1.0 / 50000.0, taps=taps), setup)
+    # and back to the default taps on the same context: the inverse filter follows the setter
+    md = pkg.Modulator(mode=1, max_frames=1)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        bits = golden_bits(1)
+        ref = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1.0 / 50000.0).process(bits)
+        y0 = md.chain(bits, 3)
+        md.set_fir_taps(wide)
+        y1 = md.chain(bits, 3)
+        md.set_fir_taps()
+        y2 = md.chain(bits, 3)
+        assert rel_rms(y0[0], ref[0]) < REL_RMS and bits_eq(y0, y2) and not bits_eq(y0, y1)
+        assert rel_rms(y1[0], O.Chain(mode=1, stages=3, gain_mode=2, normalise=1.0 / 50000.0, taps=wide).process(bits)[0]) < REL_RMS
+    finally:
+        md.close()
+
+
 @pytest.mark.parametrize("gain_mode", [0, 1])
 def test_chain_other_gain_modes_file_normalisation(pkg, gain_mode):
     def setup(md):
