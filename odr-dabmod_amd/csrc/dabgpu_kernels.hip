@@ -84,8 +84,19 @@
                                // i.e. FOUR workgroups (16 waves) per CU instead of three
 #endif
 #ifndef DABGPU_EQ_WAVES
-#define DABGPU_EQ_WAVES 3       // waves per SIMD asked for the equalised-boundary variant (tf_kernel<..., EQ>)
+#define DABGPU_EQ_WAVES 4       // waves per SIMD asked for the equalised-boundary variant (tf_kernel<..., EQ>)
 #endif
+#ifndef DABGPU_NOFIR_DBUF
+#define DABGPU_NOFIR_DBUF 1     // variants without FIR: two exchange buffers (see DABGPU_FFT_DBUF)
+#endif
+#ifndef DABGPU_EQ_R
+#define DABGPU_EQ_R 4           // EQ variant: outputs of the inverse filter per lane (4: 176 lanes at work, 2.63 M TF/s; 3: 240 lanes, 2.58 M)
+#endif
+#ifndef DABGPU_EQ_DBUF
+#define DABGPU_EQ_DBUF 0        // EQ variant: 0 = one exchange buffer, two barriers per exchange (28 KB of LDS: FOUR workgroups per CU,
+#endif                          // the register file's limit at 128 VGPRs): 2.57 M TF/s; 1 = two buffers, one barrier (47 KB: three
+                                // workgroups): 2.40 M.  (The packed dual transform lost at four workgroups per CU -- clock, DESIGN
+                                // section 6; this kernel issues about half the packed arithmetic per symbol.)
 #ifndef DABGPU_CFR_WAVES
 #define DABGPU_CFR_WAVES 2      // waves per SIMD asked for the crest-factor-reduction variants
 #endif
@@ -1024,7 +1035,7 @@ void tf_kernel(const TfArgs a)
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
-    constexpr bool DBUF = !FIR || EQ || DABGPU_FFT_DBUF;   // exchange buffers: see DABGPU_FFT_DBUF
+    constexpr bool DBUF = (!FIR && DABGPU_NOFIR_DBUF) || (EQ && DABGPU_EQ_DBUF) || DABGPU_FFT_DBUF;   // exchange buffers: see DABGPU_FFT_DBUF
     const int t = threadIdx.x;
     const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
     const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
@@ -1064,7 +1075,7 @@ void tf_kernel(const TfArgs a)
     // matrix-core form: gp[idx + 16] = g[idx] for idx in [0, 160), zero around it (192 floats); partial sums of the
     // four waves, [wave][output m < 48][re | im]
     float *gp_l = g_l + (kEqTaps + 8);
-    float *eq_part = gp_l + 192;
+    [[maybe_unused]] float *eq_part = gp_l + 192;
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : FIR ? 4 * KB : (WIN ? 7 * kWinMax : 0)));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
@@ -1551,36 +1562,64 @@ void tf_kernel(const TfArgs a)
             df[t] = (eq_part[t] + eq_part[96 + t]) + (eq_part[192 + t] + eq_part[288 + t]);
         }
 #else
+        // kEqR = 3: 15 blocks of three outputs x 16 groups of ten taps = 240 lanes (4: 11 blocks of four = 176 lanes), the 16
+        // groups of a block being one DPP row.  Output m = m0 + r, tap jj = j0 + u reads w[q] at index q + kEqQL =
+        // m + (kEqTaps - 1 - jj).
+        constexpr int kEqR = DABGPU_EQ_R, kEqLanes = 16 * ((44 + kEqR - 1) / kEqR);
+        static_assert(!EQ || ((kEqR == 3 || kEqR == 4) && kEqLanes <= T), "EQ: outputs per lane");
         cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
 #ifdef DABGPU_EXPERIMENT_EQ_NODECONV
         if (t < 0) {                     // timing experiment (wrong boundary outputs): no deconvolution
 #else
-        if (t < 176) {
+        if (t < kEqLanes) {
 #endif
-            const int m0 = 4 * (t >> 4), j0 = 10 * (t & 15);
+            const int m0 = kEqR * (t >> 4), j0 = 10 * (t & 15);
             const cf *wp = eq_w + (m0 + (kEqTaps - 1 - 9) - j0);
             const float2 *g2 = reinterpret_cast<const float2 *>(g_l + j0);
-            cf wv[13];
+            cf wv[kEqR + 9];
             float gg[10];
 #pragma unroll
-            for (int i = 0; i < 13; ++i) wv[i] = wp[i];
+            for (int i = 0; i < kEqR + 9; ++i) wv[i] = wp[i];
 #pragma unroll
             for (int u = 0; u < 5; ++u) { const float2 g = g2[u]; gg[2 * u] = g.x; gg[2 * u + 1] = g.y; }
 #pragma unroll
             for (int u = 0; u < 10; ++u)
 #pragma unroll
-                for (int r = 0; r < 4; ++r) acc[r] = axpy(acc[r], gg[u], wv[r + 9 - u]);
+                for (int r = 0; r < kEqR; ++r) acc[r] = axpy(acc[r], gg[u], wv[r + 9 - u]);
         }
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-            acc[r].x += dpp_mov<0xB1>(acc[r].x);  acc[r].y += dpp_mov<0xB1>(acc[r].y);
-            acc[r].x += dpp_mov<0x4E>(acc[r].x);  acc[r].y += dpp_mov<0x4E>(acc[r].y);
-            acc[r].x += dpp_mov<0x124>(acc[r].x); acc[r].y += dpp_mov<0x124>(acc[r].y);
-            acc[r].x += dpp_mov<0x128>(acc[r].x); acc[r].y += dpp_mov<0x128>(acc[r].y);
+        // sum over the 16 lanes of a row: x += x(lane ^ 1), x += x(lane ^ 2), x += x(ror 4), x += x(ror 8) as v_add_f32 with
+        // the DPP operand in place -- four instructions per float.  (Through update_dpp the compiler spends a
+        // v_mov_b32_dpp plus a zeroing v_mov_b32 per term, and an addition.)  Hazard: a DPP read needs two wait states
+        // after the VALU write of its source -- the s_nop covers the first step, the independent additions of a step
+        // the following ones.
+#define DABGPU_DPP6(CTRL)                                                                       \
+        "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define DABGPU_DPP2(CTRL)                                                                       \
+        "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+        if constexpr (kEqR == 4) {
+            asm volatile("s_nop 1\n\t"
+                         DABGPU_DPP6("quad_perm:[1,0,3,2]") DABGPU_DPP2("quad_perm:[1,0,3,2]")
+                         DABGPU_DPP6("quad_perm:[2,3,0,1]") DABGPU_DPP2("quad_perm:[2,3,0,1]")
+                         DABGPU_DPP6("row_ror:4") DABGPU_DPP2("row_ror:4") DABGPU_DPP6("row_ror:8") DABGPU_DPP2("row_ror:8")
+                         : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
+                           "+v"(acc[3].x), "+v"(acc[3].y));
+        } else {
+            asm volatile("s_nop 1\n\t"
+                         DABGPU_DPP6("quad_perm:[1,0,3,2]") DABGPU_DPP6("quad_perm:[2,3,0,1]")
+                         DABGPU_DPP6("row_ror:4") DABGPU_DPP6("row_ror:8")
+                         : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y));
         }
-        if (t < 176 && (t & 15) == 0) {
+#undef DABGPU_DPP6
+#undef DABGPU_DPP2
+        if (t < kEqLanes && (t & 15) == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; ++r) eq_d[4 * (t >> 4) + r] = acc[r];
+            for (int r = 0; r < kEqR; ++r) eq_d[kEqR * (t >> 4) + r] = acc[r];
         }
 #endif
         lds_barrier();
@@ -1593,8 +1632,13 @@ void tf_kernel(const TfArgs a)
             cf y = mk(0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < 11; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
-            y.x += dpp_mov<0xB1>(y.x); y.y += dpp_mov<0xB1>(y.y);
-            y.x += dpp_mov<0x4E>(y.x); y.y += dpp_mov<0x4E>(y.y);
+            asm volatile("s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                         : "+v"(y.x), "+v"(y.y));
             if (t < 4 * C && q == 0) put(prev_pos + prev_seg - C, t >> 2, cadd(y, zp[kEqQL - C + i]));
         }
     };
@@ -2035,7 +2079,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
                (size_t)(nt + 3 + 80) * sizeof(float) + (64 + 56 + 448) * sizeof(float2);
     }
     const bool eq = flags & TF_EQ;
-    const bool dbuf = !(flags & TF_FIR) || eq || DABGPU_FFT_DBUF;
+    const bool dbuf = (!(flags & TF_FIR) && DABGPU_NOFIR_DBUF) || (eq && DABGPU_EQ_DBUF) || DABGPU_FFT_DBUF;
     const bool dual = (flags & TF_FIR) && DABGPU_DUAL_FFT && !eq;
     size_t b = dual ? ((!dbuf && DABGPU_C2_PAD_SHIFT == 4) ? (N + N / 16) : (dbuf ? 2 : 1) * (N + N / 8)) * 2 * sizeof(float2)
                     : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);

@@ -2,7 +2,7 @@
 # Device ISA + resource usage of one tf_kernel instantiation (tuning aid).
 # usage: tools/isa.sh [extra hipcc flags]   -> /tmp/isa/kernels.s, /tmp/isa/cfg3.s
 mkdir -p /tmp/isa && cd /tmp/isa
-/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fvisibility=hidden ${NOLSO--Xclang -target-feature -Xclang -load-store-opt} "$@" -S --cuda-device-only \
+/opt/rocm/bin/hipcc -O3 -std=c++17 --offload-arch=gfx950 -fvisibility=hidden ${NOLSO--Xclang -target-feature -Xclang -load-store-opt} ${NOSLP--fno-slp-vectorize} "$@" -S --cuda-device-only \
     -Rpass-analysis=kernel-resource-usage -o kernels.s /root/repo/odr-dabmod_amd/csrc/dabgpu_kernels.hip 2> remarks.log
 # default: the cfg 3 kernel, tf_kernel<11, FROM_BITS, GAIN, GUARD, FIR, 45 taps, no CFR, no GVAR, ZONLY>
 S=${KERNEL:-_ZN6dabgpu12_GLOBAL__N_19tf_kernelILi11ELb1ELb1ELb1ELb1ELi45ELb0ELb0ELb1EEEvNS_6TfArgsE}
