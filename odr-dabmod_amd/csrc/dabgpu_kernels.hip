@@ -89,6 +89,13 @@
 #ifndef DABGPU_NOFIR_DBUF
 #define DABGPU_NOFIR_DBUF 1     // variants without FIR: two exchange buffers (see DABGPU_FFT_DBUF)
 #endif
+#ifndef DABGPU_PC_FFT
+#define DABGPU_PC_FFT 0         // single-symbol transforms of the frame kernel on packed (re, im) pairs (struct pc: half the VALU
+                                // instructions, every swap / sign through op_sel).  Measured 1 ... 2 % SLOWER than the scalar form on
+                                // every chain (2.48 against 2.49 M cfg 3, 2.87 against 2.94 M coded bits + guard, same box): a packed
+                                // instruction occupies the SIMD for two scalar ones, and the compiler fences every asm statement whose
+                                // result is used next with an s_nop.  Kept as a knob.
+#endif
 #ifndef DABGPU_EQ_R
 #define DABGPU_EQ_R 4           // EQ variant: outputs of the inverse filter per lane (4: 176 lanes at work, 2.63 M TF/s; 3: 240 lanes, 2.58 M)
 #endif
@@ -156,12 +163,12 @@ struct c2 {
 };
 DEV c2 cadd(c2 a, c2 b) { return c2{a.re + b.re, a.im + b.im}; }
 DEV c2 csub(c2 a, c2 b) { return c2{a.re - b.re, a.im - b.im}; }
+typedef float v2f __attribute__((ext_vector_type(2)));
 #if DABGPU_PK_OPSEL
 // Twiddle product of the packed pair: four VOP3P instructions that read the twiddle's two halves through
 // op_sel.  Written out by hand because the compiler does not use op_sel here: from the plain expression
 // below it keeps every twiddle duplicated as (x, x) and (y, y) register pairs -- 28 extra VGPRs in the FIR
 // variants of the frame kernel.
-typedef float v2f __attribute__((ext_vector_type(2)));
 DEV c2 cmul(c2 a, cf w)
 {
     const v2f are = {a.re.x, a.re.y}, aim = {a.im.x, a.im.y}, ww = {w.x, w.y};
@@ -204,14 +211,62 @@ template <int S> DEV c2 rot3(c2 b)
     return c2{(-b.re - (float)S * b.im) * kSqrtHalf, ((float)S * b.re - b.im) * kSqrtHalf};
 }
 
+// a + S i b,  a - S i b: for cf and c2 a multiplication by +-i (register renames and sign modifiers) and a sum; the
+// packed single-complex type pc (below) does both in ONE instruction through op_sel
+template <int S> DEV cf caddi(cf a, cf b) { return cadd(a, mul_i<S>(b)); }
+template <int S> DEV cf csubi(cf a, cf b) { return csub(a, mul_i<S>(b)); }
+template <int S> DEV c2 caddi(c2 a, c2 b) { return cadd(a, mul_i<S>(b)); }
+template <int S> DEV c2 csubi(c2 a, c2 b) { return csub(a, mul_i<S>(b)); }
+
+// ---------------------------------------------------------------------------
+// pc: ONE complex number as a packed pair (re, im) -- the transforms of the single-symbol kernels (one IFFT per symbol:
+// no second transform to pair with as in c2).  Sums and differences are one v_pk_add_f32; a + i b, -a + i b and
+// a + k i b take the swap of b's halves and the sign from op_sel / neg_lo / neg_hi of the same instruction; a twiddle
+// product is v_pk_mul_f32 + v_pk_fma_f32.  Half the instructions of the scalar form and none of the v_mov_b32 shuffles
+// the SLP vectoriser needs to get there.  Written as asm because the compiler does not use op_sel on its own.
+struct pc {
+    v2f v;
+};
+DEV pc cadd(pc a, pc b) { return pc{a.v + b.v}; }
+DEV pc csub(pc a, pc b) { return pc{a.v - b.v}; }
+template <int S> DEV pc caddi(pc a, pc b)          // (a.x - S b.y, a.y + S b.x)
+{
+    v2f r;
+    if (S > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_hi:[0,1]" : "=v"(r) : "v"(a.v), "v"(b.v));
+    return pc{r};
+}
+template <int S> DEV pc csubi(pc a, pc b) { return caddi<-S>(a, b); }
+template <int S> DEV pc mul_i(pc a) { return S > 0 ? pc{v2f{-a.v.y, a.v.x}} : pc{v2f{a.v.y, -a.v.x}}; }
+template <int S> DEV pc urot1(pc b) { return caddi<S>(b, b); }               // sqrt(2) exp(S i pi/4) b
+template <int S> DEV pc urot3(pc b)                                          // sqrt(2) exp(S 3 i pi/4) b = -b + S i b
+{
+    v2f r;
+    if (S > 0) asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,1] neg_hi:[1,0]" : "=v"(r) : "v"(b.v), "v"(b.v));
+    else asm("v_pk_add_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,0] neg_lo:[1,0] neg_hi:[1,1]" : "=v"(r) : "v"(b.v), "v"(b.v));
+    return pc{r};
+}
+template <int S> DEV pc rot1(pc b) { const pc u = urot1<S>(b); return pc{u.v * kSqrtHalf}; }
+template <int S> DEV pc rot3(pc b) { const pc u = urot3<S>(b); return pc{u.v * kSqrtHalf}; }
+DEV pc cmul(pc a, cf w)
+{
+    const v2f ww = {w.x, w.y};
+    v2f t, r;
+    // (one statement: between two asm statements that depend on each other the compiler puts an s_nop)
+    asm("v_pk_mul_f32 %1, %2, %3 op_sel:[0,0] op_sel_hi:[1,0]\n\t"                                    // t = (a.x w.x, a.y w.x)
+        "v_pk_fma_f32 %0, %2, %3, %1 op_sel:[1,1,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]"                  // (-a.y w.y, a.x w.y) + t
+        : "=v"(r), "=&v"(t) : "v"(a.v), "v"(ww));
+    return pc{r};
+}
+
 // 4-point DFT, exp(S 2 pi i nk/4), natural order in place
 template <int S, typename V> DEV void dft4(V &x0, V &x1, V &x2, V &x3)
 {
-    const V s0 = cadd(x0, x2), s1 = csub(x0, x2), s2 = cadd(x1, x3), s3 = mul_i<S>(csub(x1, x3));
+    const V s0 = cadd(x0, x2), s1 = csub(x0, x2), s2 = cadd(x1, x3), d3 = csub(x1, x3);
     x0 = cadd(s0, s2);
     x2 = csub(s0, s2);
-    x1 = cadd(s1, s3);
-    x3 = csub(s1, s3);
+    x1 = caddi<S>(s1, d3);
+    x3 = csubi<S>(s1, d3);
 }
 
 // The odd half of an 8-point DFT: b1 and b3 are due a rotation by exp(S i pi/4) resp. exp(S 3 i pi/4), i.e. a
@@ -222,6 +277,18 @@ template <int S, typename V> DEV void dft4(V &x0, V &x1, V &x2, V &x3)
 #endif
 DEV cf axpy(cf a, float c, cf b) { return mk(fmaf(c, b.x, a.x), fmaf(c, b.y, a.y)); }          // a + c b
 DEV c2 axpy(c2 a, float c, c2 b) { return c2{pk_fma(b.re, make_float2(c, c), a.re), pk_fma(b.im, make_float2(c, c), a.im)}; }
+// a + c S i b
+template <int S> DEV cf axpyi(cf a, float c, cf b) { return axpy(a, c, mul_i<S>(b)); }
+template <int S> DEV c2 axpyi(c2 a, float c, c2 b) { return axpy(a, c, mul_i<S>(b)); }
+DEV pc axpy(pc a, float c, pc b) { return pc{__builtin_elementwise_fma(b.v, v2f{c, c}, a.v)}; }
+template <int S> DEV pc axpyi(pc a, float c, pc b)             // (a.x - S c b.y, a.y + S c b.x)
+{
+    const v2f cc = {c, c};
+    v2f r;
+    if (S > 0) asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_lo:[1,0,0]" : "=v"(r) : "v"(b.v), "v"(cc), "v"(a.v));
+    else asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[1,0,0] op_sel_hi:[0,1,1] neg_hi:[1,0,0]" : "=v"(r) : "v"(b.v), "v"(cc), "v"(a.v));
+    return pc{r};
+}
 template <int S> DEV cf urot1(cf b) { return mk(b.x - S * b.y, S * b.x + b.y); }                // sqrt(2) exp(S i pi/4) b
 template <int S> DEV cf urot3(cf b) { return mk(-b.x - S * b.y, S * b.x - b.y); }               // sqrt(2) exp(S 3 i pi/4) b
 template <int S> DEV c2 urot1(c2 b) { return c2{b.re - (float)S * b.im, (float)S * b.re + b.im}; }
@@ -235,12 +302,12 @@ template <int S, typename V> DEV void dft8_odd(V &b0, V &b1, V &b2, V &b3)
         dft4<S>(b0, b1, b2, b3);
         return;
     }
-    const V p1 = urot1<S>(b1), p2 = mul_i<S>(b2), p3 = urot3<S>(b3);
-    const V s0 = cadd(b0, p2), s1 = csub(b0, p2), s2 = cadd(p1, p3), s3 = mul_i<S>(csub(p1, p3));
+    const V p1 = urot1<S>(b1), p3 = urot3<S>(b3);
+    const V s0 = caddi<S>(b0, b2), s1 = csubi<S>(b0, b2), s2 = cadd(p1, p3), d3 = csub(p1, p3);
     b0 = axpy(s0, kSqrtHalf, s2);
     b2 = axpy(s0, -kSqrtHalf, s2);
-    b1 = axpy(s1, kSqrtHalf, s3);
-    b3 = axpy(s1, -kSqrtHalf, s3);
+    b1 = axpyi<S>(s1, kSqrtHalf, d3);
+    b3 = axpyi<S>(s1, -kSqrtHalf, d3);
 }
 
 // 8-point DFT (decimation in frequency), natural order in place
@@ -291,6 +358,12 @@ DEV c2 cfma(c2 t, c2 x, cf w)          // t + x * w
 DEV c2 cfma(c2 t, c2 x, cf w) { return cadd(t, cmul(x, w)); }
 #endif
 template <int S> DEV void twiddle_dft8(cf *v, const cf *w)
+{
+#pragma unroll
+    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
+    dft8<S>(v);
+}
+template <int S> DEV void twiddle_dft8(pc *v, const cf *w)
 {
 #pragma unroll
     for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
@@ -1770,7 +1843,17 @@ void tf_kernel(const TfArgs a)
                 for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
             }
             place(val, v);
-            F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
+            if (DABGPU_PC_FFT && !CFR) {
+                // the single transform on packed (re, im) pairs (struct pc)
+                pc pv[8];
+#pragma unroll
+                for (int m = 0; m < 8; ++m) pv[m] = pc{v2f{v[m].x, v[m].y}};
+                F::template run<+1, DBUF, pc, kU8, TW64 ? 1 : 0>(pv, reinterpret_cast<pc *>(fbuf), fpar, tw, tt, tw8_l, tw64_l);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) v[m] = mk(pv[m].v.x, pv[m].v.y);
+            } else {
+                F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
+            }
             if (CFR) {
                 cf refv[8];
                 place(val, refv);
