@@ -173,11 +173,14 @@ DEV c2 cmul(c2 a, cf w)
 {
     const v2f are = {a.re.x, a.re.y}, aim = {a.im.x, a.im.y}, ww = {w.x, w.y};
     v2f t0, t1, re, im;
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,1] op_sel_hi:[1,1]" : "=v"(t0) : "v"(aim), "v"(ww));          // im * w.y
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"
-        : "=v"(re) : "v"(are), "v"(ww), "v"(t0));                                                         // re * w.x - t0
-    asm("v_pk_mul_f32 %0, %1, %2 op_sel:[0,0] op_sel_hi:[1,0]" : "=v"(t1) : "v"(aim), "v"(ww));          // im * w.x
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(im) : "v"(are), "v"(ww), "v"(t1));   // re * w.y + t1
+    // (a product and the FMA that consumes it are ONE statement: between two asm statements that depend on each other the
+    // compiler puts an s_nop -- 39 of them per hop in the resampler)
+    asm("v_pk_mul_f32 %1, %3, %4 op_sel:[0,1] op_sel_hi:[1,1]\n\t"                                                    // t0 = im * w.y
+        "v_pk_fma_f32 %0, %2, %4, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1] neg_lo:[0,0,1] neg_hi:[0,0,1]"                   // re * w.x - t0
+        : "=v"(re), "=&v"(t0) : "v"(are), "v"(aim), "v"(ww));
+    asm("v_pk_mul_f32 %1, %3, %4 op_sel:[0,0] op_sel_hi:[1,0]\n\t"                                                    // t1 = im * w.x
+        "v_pk_fma_f32 %0, %2, %4, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1]"                                                 // re * w.y + t1
+        : "=v"(im), "=&v"(t1) : "v"(are), "v"(aim), "v"(ww));
     return c2{make_float2(re.x, re.y), make_float2(im.x, im.y)};
 }
 #else
@@ -347,11 +350,12 @@ DEV c2 cfma(c2 t, c2 x, cf w)          // t + x * w
 {
     const v2f tre = {t.re.x, t.re.y}, tim = {t.im.x, t.im.y}, xre = {x.re.x, x.re.y}, xim = {x.im.x, x.im.y}, ww = {w.x, w.y};
     v2f r0, re, i0, im;
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(r0) : "v"(xre), "v"(ww), "v"(tre));      // t.re + x.re w.x
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"
-        : "=v"(re) : "v"(xim), "v"(ww), "v"(r0));                                                                        // - x.im w.y
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,1,0] op_sel_hi:[1,1,1]" : "=v"(i0) : "v"(xre), "v"(ww), "v"(tim));      // t.im + x.re w.y
-    asm("v_pk_fma_f32 %0, %1, %2, %3 op_sel:[0,0,0] op_sel_hi:[1,0,1]" : "=v"(im) : "v"(xim), "v"(ww), "v"(i0));       // + x.im w.x
+    asm("v_pk_fma_f32 %1, %2, %4, %5 op_sel:[0,0,0] op_sel_hi:[1,0,1]\n\t"                                             // r0 = t.re + x.re w.x
+        "v_pk_fma_f32 %0, %3, %4, %1 op_sel:[0,1,0] op_sel_hi:[1,1,1] neg_lo:[1,0,0] neg_hi:[1,0,0]"                    // - x.im w.y
+        : "=v"(re), "=&v"(r0) : "v"(xre), "v"(xim), "v"(ww), "v"(tre));
+    asm("v_pk_fma_f32 %1, %2, %4, %5 op_sel:[0,1,0] op_sel_hi:[1,1,1]\n\t"                                             // i0 = t.im + x.re w.y
+        "v_pk_fma_f32 %0, %3, %4, %1 op_sel:[0,0,0] op_sel_hi:[1,0,1]"                                                  // + x.im w.x
+        : "=v"(im), "=&v"(i0) : "v"(xre), "v"(xim), "v"(ww), "v"(tim));
     return c2{make_float2(re.x, re.y), make_float2(im.x, im.y)};
 }
 #else
@@ -1005,16 +1009,24 @@ template <int NTP, int R> DEV void fir_block(const cf *__restrict__ lane, const 
 // ---------------------------------------------------------------------------
 // f-2 fused into the chain's last store: cf32 -> s16 with FormatConverter's range test, truncation toward zero and
 // clipped-component count (reference src/FormatConverter.cpp:111-143), one 4-byte word per complex sample.
-DEV int s16_one(float x, unsigned &clipped)
+// FormatConverter s16 on one sample (src/FormatConverter.cpp:111-139: compare against INT16_MIN / MAX in float, count,
+// else truncate toward zero) in 9 instructions instead of 16:
+//   value: v_cvt_i32_f32 (toward zero, saturating, NaN -> 0) on both parts, then v_cvt_pk_i16_i32, which saturates to
+//          16 bits and packs -- the clipped values are exactly the saturated ones;
+//   count: x > 32767 or x < -32768  <=>  |x + 0.5| > 32767.5 (the sum is exact wherever the comparison is close: |x| <
+//          2^16 has an ulp of 2^-8 or finer), one addition, one compare with |.|, one add-with-carry per part.
+DEV int cvt_i32_sat(float x)
 {
-    if (x < -32768.0f) { ++clipped; return -32768; }
-    if (x > 32767.0f) { ++clipped; return 32767; }
-    return (int)x;                        // v_cvt_i32_f32: toward zero, NaN -> 0
+    int r;
+    asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));     // (a C cast of an out-of-range float is undefined; the instruction is not)
+    return r;
 }
 DEV uint32_t s16_pack(cf y, unsigned &clipped)
 {
-    const int re = s16_one(y.x, clipped), im = s16_one(y.y, clipped);
-    return (uint32_t)(re & 0xffff) | ((uint32_t)im << 16);
+    clipped += (__builtin_fabsf(y.x + 0.5f) > 32767.5f ? 1u : 0u) + (__builtin_fabsf(y.y + 0.5f) > 32767.5f ? 1u : 0u);
+    typedef short s2_ __attribute__((ext_vector_type(2)));
+    const s2_ p = __builtin_amdgcn_cvt_pk_i16(cvt_i32_sat(y.x), cvt_i32_sat(y.y));
+    return __builtin_bit_cast(uint32_t, p);
 }
 // per-workgroup epilogue of a kernel that stored s16: the lanes' clip counts, summed per wave, onto the call's counter
 DEV void s16_flush_count(unsigned nclip, unsigned long long *total)
