@@ -16,9 +16,13 @@
 //   * gain statistics come from the SPECTRUM (population variance through Parseval on carrier pairs),
 //     counted with ballots; modes max / fix reduce over the FFT output with DPP;
 //   * the cyclic prefix is a second store of the same registers;
-//   * the FIR is spectral: the unfiltered and the filtered IFFT of a symbol run as ONE packed dual
-//     transform (struct c2), the unfiltered half pruned to the 88 samples the 44-tap boundary FIR
-//     between two symbols reads (Fft::run_dual_zonly); only those boundary outputs are a direct FIR.
+//   * the FIR is spectral: inside a symbol it is the factor H[k] on the carriers.  Mode I coded-bits chain with the
+//     45-tap filter (EQ): ONE transform per symbol, of X H; the 44 outputs per symbol boundary that the cyclic
+//     filtering gets wrong are corrected from the filtered symbols alone through a host-designed inverse of the
+//     taps on the occupied carriers.  Every other FIR variant: the unfiltered and the filtered IFFT of a symbol as
+//     ONE packed dual transform (struct c2), the unfiltered half pruned to the 88 samples the boundary FIR reads
+//     (Fft::run_dual_zonly), those boundary outputs a direct FIR;
+//   * OFDM windowing without FIR (WIN): the raised-cosine seams between symbols through LDS.
 // HBM traffic is therefore the compulsory 28.8 kB in + 1.57 MB out per frame.
 //
 // No MFMA (no dense contraction in this path), wave64 throughout.
