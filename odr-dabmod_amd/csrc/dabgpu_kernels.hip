@@ -3148,250 +3148,10 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     if (S16) s16_flush_count(nclip, a.clipped);
 }
 
-// ---------------------------------------------------------------------------
-// a10 + a11, the BASELINE config 4 shape (x4, nin = 4096, polynomial predistorter) with MORE THAN ONE workgroup per
-// CU -- a measured experiment, off by default (DABGPU_RS4_WIDE = 0 keeps resampler_kernel above).
-// resampler_kernel is a 512-lane workgroup with 152 KB of LDS: one per CU, its eight waves in lockstep between
-// barriers -- butterflies (VALU busy, LDS idle), then exchange (LDS busy, VALU idle): the two add up (rocprofv3:
-// VALU 56 %, LDS 36 %).  Here a lane carries NU "virtual lanes" of that scheme, with ONE exchange buffer (74 KB, two
-// barriers per exchange), no window copy in LDS and no resident twiddles, so that two workgroups share a CU:
-//   NU = 2: 256-lane workgroups, 234 VGPRs, 2 waves per SIMD from two INDEPENDENT workgroups: 264 k TF/s for cfg 4;
-//   NU = 1: 512-lane workgroups held to 128 VGPRs (19 dwords of scratch), 4 waves per SIMD:  237 k TF/s;
-//   resampler_kernel (one workgroup per CU, two buffers, one barrier per exchange):           311 k TF/s.
-// Why decoupling does not pay (tools/microbench/issue_cost.hip): ONE wave issues at most one packed VALU
-// instruction per ~6.7 cycles while the SIMD retires one per ~3.5 -- it takes two waves in their butterfly phase on
-// a SIMD to fill it.  With two waves per SIMD from different workgroups, a wave that computes while its neighbour
-// exchanges runs at half rate, so the overlap buys nothing and the second barrier per exchange costs; with four
-// waves per SIMD the register budget (128) does not hold the packed dual transform plus the hop state.
-#ifndef DABGPU_RS4_WIDE
-#define DABGPU_RS4_WIDE 0          // 0: resampler_kernel; 1 / 2: resampler4w_kernel with NU = 1 / 2 virtual lanes per lane
-#endif
-// NU = virtual lanes per lane: 2 (256-lane workgroups, 2 waves per SIMD) or 1 (512-lane workgroups held to 128
-// registers: 4 waves per SIMD, two workgroups per CU)
-template <bool POLY, int NU> __global__ __launch_bounds__(512 / NU, NU == 1 ? 4 : 2)
-void resampler4w_kernel(const ResamplerArgs a, int hops_per_run)
-{
-    typedef Fft<12> F;
-    constexpr int NIN = 4096, TV = 512, TP = 512 / NU, HIN = NIN / 2, Q = 4, HOUT = HIN * Q, NOUT = NIN * Q;
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    c2 *xb = reinterpret_cast<c2 *>(smem);                          // one exchange buffer (two barriers per exchange)
-    cf *nyq = reinterpret_cast<cf *>(xb + F::LDS_ELEMS);            // [2]: Nyquist bin per hop parity
-    cf *tw8_l = nyq + 2;                                            // 7 x 8 twiddles of the stride-8 stage
-    const int t = threadIdx.x;
-    const long h0 = (long)blockIdx.x * hops_per_run;
-    const long h1 = min((long)a.nhops, h0 + hops_per_run);
-    if (h0 >= (long)a.nhops) return;
-
-    // twiddles: none resident.  The stride-8 and stride-64 stages' depend on lane % 8 / lane % 64 (shared by both
-    // virtual lanes) and come from small LDS tables; the stride-512 stage's depend on the virtual lane and are read
-    // from the (L2-resident) table while the exchange before that stage is in flight -- 42 registers that would
-    // otherwise push the kernel into scratch
-    cf *tw64_l = tw8_l + 56;                                        // 7 x 64
-    F::fill_tw64(a.tw_in, tw64_l, t, TP);
-    F::fill_tw8(a.tw_in, tw8_l, t);
-    cf wp[Q];
-#pragma unroll
-    for (int p = 1; p < Q; ++p) wp[p] = a.tw_out[(t * p) & (NOUT - 1)];
-    PolyCoef pc{};
-    if (POLY) {
-        pc.a0 = a.poly[0]; pc.a1 = a.poly[1]; pc.a2 = a.poly[2]; pc.a3 = a.poly[3]; pc.a4 = a.poly[4];
-        pc.p0 = a.poly[8]; pc.p1 = a.poly[9]; pc.p2 = a.poly[10]; pc.p3 = a.poly[11]; pc.p4 = a.poly[12];
-    }
-    lds_barrier();
-
-    // Global memory through buffer resources (scalar base + scalar offset + 32-bit lane offset): no 64-bit lane
-    // addresses to keep or to add, and an access outside a resource's range reads as zero / is dropped -- the halo
-    // and the stream are then two loads whose sum is the sample, with no per-lane select of a pointer.
-    // S = [halo (2 hops) | in]; hop h uses S[(h+1)*HIN .. (h+3)*HIN); the stream resource is based at hop h0 - 1
-    // (the address below the buffer it yields for h0 = 0 is never dereferenced: those offsets are out of range).
-    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
-    typedef unsigned v4u_ __attribute__((ext_vector_type(4)));
-    const int run_hops = (int)(h1 - h0);
-    const __amdgpu_buffer_rsrc_t r_win = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(a.window), 0, NIN * 4, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_halo = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.halo), 0, NIN * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_twi = __builtin_amdgcn_make_buffer_rsrc(const_cast<cf *>(a.tw_in), 0, NIN * 8, 0x00020000);
-    // stream positions [(h0 + 1) HIN - NIN, ...) as offsets 0 ... of the resource; only offsets >= the start of `in` are in range
-    const long in_first = (h0 + 1) * HIN - NIN;               // stream index of the resource's offset 0 (may be < 0)
-    const long in_skip = in_first < 0 ? -in_first : 0;        // samples at the front that belong to the halo
-    const __amdgpu_buffer_rsrc_t r_in = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<cf *>(a.in) + (in_first + in_skip), 0, (int)(((long)run_hops + 2) * HIN - in_skip) * 8, 0x00020000);
-    const __amdgpu_buffer_rsrc_t r_out = __builtin_amdgcn_make_buffer_rsrc(a.out + (size_t)h0 * HOUT, 0, run_hops * HOUT * 8, 0x00020000);
-    const bool uses_halo = h0 <= 1;
-    auto wnd = [&](int u, int m) __attribute__((always_inline)) -> float {
-        const int vt = t + TP * u;
-        return __builtin_bit_cast(float, m < 4 ? __builtin_amdgcn_raw_buffer_load_b32(r_win, vt * 4, TV * m * 4, 0)
-                                               : __builtin_amdgcn_raw_buffer_load_b32(r_win, (TV - 1 - vt) * 4, TV * (7 - m) * 4, 0));
-    };
-    auto sample = [&](long h, int u, int m) __attribute__((always_inline)) -> cf {
-        const int vt = t + TP * u;
-        const int rel = (int)((h + 1) * HIN - in_first - in_skip) + TV * m;      // wave-uniform; negative inside the halo
-        v2u_ x = __builtin_amdgcn_raw_buffer_load_b64(r_in, (rel + vt) * 8, 0, 0);   // (negative -> huge unsigned -> zero)
-        if (uses_halo) {
-            const v2u_ y = __builtin_amdgcn_raw_buffer_load_b64(r_halo, (int)((h + 1) * HIN + TV * m + vt) * 8, 0, 0);
-            x = v2u_{x.x | y.x, x.y | y.y};
-        }
-        return mk(__builtin_bit_cast(float, x.x), __builtin_bit_cast(float, x.y));
-    };
-    // the packed dual transform of both virtual lanes (Fft<12>::run, two lanes per lane, one buffer)
-    auto fft2v = [&](c2 (&v)[NU][8]) __attribute__((always_inline)) {
-        cf w8[7];
-#pragma unroll
-        for (int r = 0; r < 7; ++r) w8[r] = tw8_l[r * 8 + (t & 7)];
-#pragma unroll
-        for (int u = 0; u < NU; ++u) dft8<+1>(v[u]);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) F::template xwrite<1, c2>(v[u], xb, t + TP * u);
-        xbarrier();
-#pragma unroll
-        for (int u = 0; u < NU; ++u) F::template xread<1, c2>(v[u], xb, t + TP * u);
-        xbarrier();
-#pragma unroll
-        for (int u = 0; u < NU; ++u) twiddle_dft8<+1>(v[u], w8);
-#pragma unroll
-        for (int u = 0; u < NU; ++u) F::template xwrite<8, c2>(v[u], xb, t + TP * u);
-        xbarrier();
-#pragma unroll
-        for (int u = 0; u < NU; ++u) F::template xread<8, c2>(v[u], xb, t + TP * u);
-        xbarrier();
-        {
-            cf w64[7];
-#pragma unroll
-            for (int r = 0; r < 7; ++r) w64[r] = tw64_l[r * 64 + (t & 63)];
-#pragma unroll
-            for (int u = 0; u < NU; ++u) twiddle_dft8<+1>(v[u], w64);
-        }
-#pragma unroll
-        for (int u = 0; u < NU; ++u) F::template xwrite<64, c2>(v[u], xb, t + TP * u);
-        int to = t;
-        asm volatile("" : "+v"(to));                     // (opaque: keeps the loads below inside the hop loop)
-        cf w512[NU][7];
-#pragma unroll
-        for (int r = 1; r < 8; ++r) {
-#pragma unroll
-            for (int u = 0; u < NU; ++u) {
-                const v2u_ wv = __builtin_amdgcn_raw_buffer_load_b64(r_twi, ((r * (to + TP * u)) & (NIN - 1)) * 8, 0, 0);
-                w512[u][r - 1] = mk(__builtin_bit_cast(float, wv.x), __builtin_bit_cast(float, wv.y));
-            }
-        }
-        xbarrier();
-#pragma unroll
-        for (int u = 0; u < NU; ++u) F::template xread<64, c2>(v[u], xb, t + TP * u);
-        xbarrier();
-#pragma unroll
-        for (int u = 0; u < NU; ++u) twiddle_dft8<+1>(v[u], w512[u]);
-    };
-
-    const float sgn = (t & 1) ? -1.0f : 1.0f;
-    const float sc = (float)NIN * a.factor;
-    cf G[NU][8], Fc[NU][8];
-    {
-        // run prologue: F_{h0-1} and F_{h0} as one dual forward transform
-        c2 v2[NU][8];
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const cf xa = sample(h0 - 1, u, m), xn = sample(h0, u, m);
-                const float w = wnd(u, m);
-                v2[u][m] = c2{make_float2(xa.x * w, xn.x * w), make_float2(-xa.y * w, -xn.y * w)};
-            }
-        fft2v(v2);
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                Fc[u][m] = mk(v2[u][m].re.y * a.factor, -v2[u][m].im.y * a.factor);
-                G[u][m] = mk(fmaf(sgn * a.factor, v2[u][m].re.x, Fc[u][m].x), fmaf(-sgn * a.factor, v2[u][m].im.x, Fc[u][m].y));
-            }
-    }
-    lds_barrier();
-
-    // branch twiddle of bin vt + 512 m for branch p: W_nout^{kappa p} = wp[p] (lane part, W^{t p}) times a
-    // compile-time rotation: e^{2 pi i (256 u + 512 m) p / nout}, and (-i)^p for the negative-frequency half
-    auto branch_rot = [](int p, int u, int m) __attribute__((always_inline)) -> cf {
-        const double ang = 2.0 * 3.14159265358979323846 * (double)(((u * (TP / 256) + 2 * m) * p) % 64) / 64.0
-                           - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
-        return mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
-    };
-    auto nyq_scale = [](int p) __attribute__((always_inline)) -> float {
-        return 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q);
-    };
-
-    for (long h = h0; h < h1; ++h) {
-        const int slot = (int)(h & 1);
-        if (t == 0) nyq[slot] = G[0][HIN / TV];          // bin nin/2: virtual lane 0, slot 4
-        const bool more = h + 1 < h1;
-        cf o12[NU][4][2];                                  // branches 1 and 2 of the lane's 2 x 4 output samples
-        c2 v2[NU][8];
-        // ---- pass 0: branches 1 and 2
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const float2 wr = make_float2(wp[1].x, wp[2].x), wi = make_float2(wp[1].y, wp[2].y);
-                const cf ra = branch_rot(1, u, m), rb = branch_rot(2, u, m);
-                const float2 rr = make_float2(ra.x, rb.x), ri = make_float2(ra.y, rb.y);
-                const float2 yr = G[u][m].x * wr - G[u][m].y * wi, yi = G[u][m].x * wi + G[u][m].y * wr;
-                v2[u][m] = c2{yr * rr - yi * ri, yr * ri + yi * rr};
-                if (u == 0 && m == HIN / TV && t == 0) {
-                    const float2 ny2 = make_float2(nyq_scale(1), nyq_scale(2));
-                    v2[u][m] = c2{G[u][m].x * ny2, G[u][m].y * ny2};
-                }
-            }
-        fft2v(v2);
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                o12[u][m][0] = mk(v2[u][m].re.x, v2[u][m].im.x);
-                o12[u][m][1] = mk(v2[u][m].re.y, v2[u][m].im.y);
-            }
-        // ---- pass 1: branch 3 and the forward transform of the next hop (conjugate trick)
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                cf xa = cmul(cmul(G[u][m], wp[3]), branch_rot(3, u, m));
-                if (u == 0 && m == HIN / TV && t == 0) xa = cscale(G[u][m], nyq_scale(3));
-                const cf xn = more ? sample(h + 1, u, m) : mk(0.f, 0.f);
-                const float w = wnd(u, m);
-                v2[u][m] = c2{make_float2(xa.x, xn.x * w), make_float2(xa.y, -xn.y * w)};
-            }
-        fft2v(v2);
-        // item b = conj(F_{h+1}); the overlap-add with F_h gives the next hop's spectrum
-        cf o3[NU][4];
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) o3[u][m] = mk(v2[u][m].re.x, v2[u][m].im.x);
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 8; ++m) {
-                const cf fn = mk(v2[u][m].re.y * a.factor, -v2[u][m].im.y * a.factor);
-                G[u][m] = mk(fmaf(sgn, Fc[u][m].x, fn.x), fmaf(sgn, Fc[u][m].y, fn.y));
-                Fc[u][m] = fn;
-            }
-        // branch 0 needs no transform: IDFT(DFT(u)) = NIN u -- the input samples under the sum of the two window
-        // halves -- plus the second copy of the Nyquist bin, G[NIN/2] e^{i pi q} (q = vt + 512 m, even offsets)
-        const cf ny = nyq[slot];
-        const int ho = (int)(h - h0) * HOUT * 8;
-#pragma unroll
-        for (int u = 0; u < NU; ++u)
-#pragma unroll
-            for (int m = 0; m < 4; ++m) {
-                const cf c = sample(h, u, m);
-                const float ws = (wnd(u, m) + wnd(u, m + 4)) * sc;
-                cf a0 = mk(fmaf(sgn, ny.x, c.x * ws), fmaf(sgn, ny.y, c.y * ws));
-                cf a1 = o12[u][m][0], a2 = o12[u][m][1], a3 = o3[u][m];
-                if (POLY) { poly_apply2(a0, a1, pc); poly_apply2(a2, a3, pc); }
-                const int vo = Q * (t + TP * u) * 8, so = ho + Q * TV * m * 8;
-                auto bits = [](float f) __attribute__((always_inline)) { return __builtin_bit_cast(unsigned, f); };
-                __builtin_amdgcn_raw_buffer_store_b128(v4u_{bits(a0.x), bits(a0.y), bits(a1.x), bits(a1.y)}, r_out, vo, so, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(v4u_{bits(a2.x), bits(a2.y), bits(a3.x), bits(a3.y)}, r_out, vo + 16, so, 0);
-            }
-    }
-}
+// (Two experiments with MORE THAN ONE workgroup of this shape per CU -- resampler4w_kernel: 256-lane workgroups carrying two
+// "virtual lanes" per lane, 234 VGPRs, 264 k TF/s; 512-lane workgroups held to 128 VGPRs, 19 dwords of scratch, 237 k TF/s;
+// against 311 k for the kernel above -- were measured in round 2 and removed again; DESIGN.md section 4.3 has the numbers and
+// the reason, the code is in the history up to commit "DESIGN numbers follow the committed bench line".)
 
 // ---------------------------------------------------------------------------
 // a10 for rational ratios L / M (M a power of two dividing nin, L > M): nout = S L with S = nin / M.
@@ -3800,16 +3560,6 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
                     break;
                 }
                 return hipErrorInvalidValue;
-            }
-            if (LOGNIN == 12 && DABGPU_RS4_WIDE) {
-                // two 256-lane workgroups per CU (74 KB of LDS each) instead of one 512-lane workgroup
-                const size_t lds4 = (size_t)Fft<12>::LDS_ELEMS * 16 + (2 + 56 + 448) * sizeof(float2);
-                constexpr int NU = DABGPU_RS4_WIDE ? DABGPU_RS4_WIDE : 2;
-                hipError_t e = poly ? allow_lds(resampler4w_kernel<true, NU>, lds4) : allow_lds(resampler4w_kernel<false, NU>, lds4);
-                if (e != hipSuccess) return e;
-                if (poly) hipLaunchKernelGGL((resampler4w_kernel<true, NU>), grid, dim3(512 / NU), lds4, s, a, hpr);
-                else hipLaunchKernelGGL((resampler4w_kernel<false, NU>), grid, dim3(512 / NU), lds4, s, a, hpr);
-                break;
             }
             if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
             else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
