@@ -3148,6 +3148,167 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     if (S16) s16_flush_count(nclip, a.clipped);
 }
 
+// ---------------------------------------------------------------------------
+// a10 + a11, the BASELINE config 4 shape (x4, nin = 4096) on UNPACKED transforms: the same hop arithmetic as
+// resampler_kernel<12, 4> -- out_h = first_half(IDFT_nout(stuff(G_h))), G_h = F_h + (-1)^k F_{h-1}, three branch IFFTs per
+// hop, branch 0 straight from the input samples, the forward transform of the next hop through conj(IDFT(conj .)) -- but
+// one transform at a time on plain (re, im) registers, ONE exchange buffer (two barriers per exchange) and the
+// stride-64 twiddles in LDS: 49 KB and <= 128 VGPRs per 512-lane workgroup, i.e. TWO independent workgroups (four
+// waves per SIMD) per CU where the packed kernel has one (two waves per SIMD in lockstep between its barriers).
+// The idea (from cfg 3): a packed instruction occupies the SIMD for two plain ones, so unpacking costs
+// no VALU time, and the lighter workgroup doubles the number of independent waves that can fill each other's LDS phases.
+// MEASURED (same box, B = 4096, parity tests green): 238 k TF/s against 293 k for the packed kernel with the polynomial,
+// 248 k against 330 k without -- SLOWER by 19 ... 25 %.  Unlike the frame kernel's packed pair, the packed resampler
+// transform carries no wasted half: unpacking doubles the instructions issued, the LDS instructions and the barriers per
+// hop (24 instead of 12) for the same arithmetic, and four waves per SIMD instead of two do not buy that back (7 dwords
+// of scratch on top).  Off; kept as a knob (complexf output only).
+// Outputs leave as 16-byte pairs of branches (0, 1) and (2, 3), a transform apart.
+#ifndef DABGPU_RS4_UNPACKED
+#define DABGPU_RS4_UNPACKED 0
+#endif
+template <bool POLY, bool S16> __global__ __launch_bounds__(512, 4)
+void resampler_u_kernel(const ResamplerArgs a, int hops_per_run)
+{
+    unsigned nclip = 0;
+    typedef Fft<12> F;
+    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, Q = 4, HOUT = HIN * Q, NOUT = NIN * Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *xbuf = reinterpret_cast<cf *>(smem);                       // one exchange buffer of 8-byte elements
+    cf *nyq = xbuf + F::LDS_ELEMS;                                 // [2]: Nyquist bin per hop parity
+    cf *tw8_l = nyq + 2;                                           // 7 x 8 twiddles of the stride-8 stage
+    cf *tw64_l = tw8_l + 56;                                       // 7 x 64 twiddles of the stride-64 stage
+    float *win = reinterpret_cast<float *>(tw64_l + 448);          // first half of the (symmetric) Hann window
+    int fpar = 0;
+    const int t = threadIdx.x;
+    const long h0 = (long)blockIdx.x * hops_per_run;
+    const long h1 = min((long)a.nhops, h0 + hops_per_run);
+    if (h0 >= (long)a.nhops) return;
+
+    cf tw[F::NTW];
+    F::template load_twiddles<true, true>(a.tw_in, t, tw);         // (the stride-512 stage's seven stay resident)
+    F::fill_tw8(a.tw_in, tw8_l, t);
+    F::fill_tw64(a.tw_in, tw64_l, t, T);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) win[t + T * m] = a.window[t + T * m];
+    auto wnd = [&](int m) __attribute__((always_inline)) -> float {
+        return m < 4 ? win[t + T * m] : win[T * (7 - m) + (T - 1 - t)];
+    };
+    cf wp[Q];
+#pragma unroll
+    for (int p = 1; p < Q; ++p) wp[p] = a.tw_out[(t * p) & (NOUT - 1)];
+    PolyCoef pc{};
+    if (POLY) {
+        pc.a0 = a.poly[0]; pc.a1 = a.poly[1]; pc.a2 = a.poly[2]; pc.a3 = a.poly[3]; pc.a4 = a.poly[4];
+        pc.p0 = a.poly[8]; pc.p1 = a.poly[9]; pc.p2 = a.poly[10]; pc.p3 = a.poly[11]; pc.p4 = a.poly[12];
+    }
+    lds_barrier();
+
+    auto fetch = [&](long h, cf *x) __attribute__((always_inline)) {
+        const long base = (h + 1) * HIN;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const long i = base + t + T * m;
+            x[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
+        }
+    };
+    auto transform = [&](cf *v) __attribute__((always_inline)) {
+        F::template run<+1, false, cf, 1, 1>(v, xbuf, fpar, tw, t, tw8_l, tw64_l);
+    };
+    // forward transform of one window of input samples: conj(IDFT(conj(w x))) * factor, kept as (re, -im) * factor
+    auto forward = [&](const cf *x, cf *f) __attribute__((always_inline)) {
+        cf v[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { const float w = wnd(m); v[m] = mk(x[m].x * w, -x[m].y * w); }
+        transform(v);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) f[m] = mk(v[m].x * a.factor, -v[m].y * a.factor);
+    };
+    const float sgn = (t & 1) ? -1.0f : 1.0f;
+    const float sc = (float)NIN * a.factor;
+    cf G[8], Fc[8], b0[4];
+    {
+        cf x[8], fp[8];
+        fetch(h0 - 1, x);
+        forward(x, fp);
+        fetch(h0, x);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b0[m] = cscale(x[m], (wnd(m) + wnd(m + 4)) * sc);
+        forward(x, Fc);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) G[m] = mk(fmaf(sgn, fp[m].x, Fc[m].x), fmaf(sgn, fp[m].y, Fc[m].y));
+    }
+    auto branch_rot = [](int p, int m) __attribute__((always_inline)) -> cf {
+        const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (8 * Q)) / (double)(8 * Q)
+                           - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
+        return mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
+    };
+    auto nyq_scale = [](int p) __attribute__((always_inline)) -> float {
+        return 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q);
+    };
+    // branch p of the hop: IDFT of G[k] W_nout^{kappa p}; the lane's first four samples come back in v[0 .. 3]
+    auto branch_in = [&](auto pc_, cf *v) __attribute__((always_inline)) {
+        constexpr int p = decltype(pc_)::value;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            v[m] = cmul(cmul(G[m], wp[p]), branch_rot(p, m));
+            if (m == HIN / T && t == 0) v[m] = cscale(G[m], nyq_scale(p));
+        }
+    };
+    // two branches of the lane's four output samples: 16 bytes (8 with s16) per sample, MemlessPoly before the store
+    auto store_pair = [&](long h, int p, cf *oa, cf *ob) __attribute__((always_inline)) {
+        cf *dst = a.out + (size_t)h * HOUT;
+        uint32_t *dst16 = reinterpret_cast<uint32_t *>(a.out) + (size_t)h * HOUT;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            cf a0 = oa[m], a1 = ob[m];
+            if (POLY) poly_apply2(a0, a1, pc);
+            const size_t q = (size_t)Q * (t + T * m) + p;
+            if (S16) *reinterpret_cast<uint2 *>(dst16 + q) = make_uint2(s16_pack(a0, nclip), s16_pack(a1, nclip));
+            else *reinterpret_cast<float4 *>(dst + q) = make_float4(a0.x, a0.y, a1.x, a1.y);
+        }
+    };
+
+    for (long h = h0; h < h1; ++h) {
+        const int slot = (int)(h & 1);
+        if (t == 0) nyq[slot] = G[HIN / T];        // bin HIN lives in lane 0; read back behind the first transform's barriers
+        const bool more = h + 1 < h1;
+        cf v[8], o[4];
+        branch_in(std::integral_constant<int, 1>{}, v);
+        transform(v);
+        {
+            // branch 0 needs no transform: IDFT(DFT(u)) = NIN u, the input samples under the sum of the two window halves
+            // (b0, prepared a hop ahead), plus the second copy of the Nyquist bin, G[NIN/2] e^{i pi q}
+            const cf ny = nyq[slot];
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[m] = mk(fmaf(sgn, ny.x, b0[m].x), fmaf(sgn, ny.y, b0[m].y));
+        }
+        store_pair(h, 0, o, v);
+        branch_in(std::integral_constant<int, 2>{}, v);
+        transform(v);
+#pragma unroll
+        for (int m = 0; m < 4; ++m) o[m] = v[m];
+        branch_in(std::integral_constant<int, 3>{}, v);
+        // the next hop's window of input: requested behind the first pair's stores (long retired when it is waited for)
+        // and once this hop's spectrum is dead
+        cf xn[8];
+        if (more) fetch(h + 1, xn);
+        transform(v);
+        store_pair(h, 2, o, v);
+        if (more) {
+#pragma unroll
+            for (int m = 0; m < 4; ++m) b0[m] = cscale(xn[m], (wnd(m) + wnd(m + 4)) * sc);
+            cf fn[8];
+            forward(xn, fn);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                G[m] = mk(fmaf(sgn, Fc[m].x, fn[m].x), fmaf(sgn, Fc[m].y, fn[m].y));
+                Fc[m] = fn[m];
+            }
+        }
+    }
+    if (S16) s16_flush_count(nclip, a.clipped);
+}
+
 // (Two experiments with MORE THAN ONE workgroup of this shape per CU -- resampler4w_kernel: 256-lane workgroups carrying two
 // "virtual lanes" per lane, 234 VGPRs, 264 k TF/s; 512-lane workgroups held to 128 VGPRs, 19 dwords of scratch, 237 k TF/s;
 // against 311 k for the kernel above -- were measured in round 2 and removed again; DESIGN.md section 4.3 has the numbers and
@@ -3560,6 +3721,12 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
                     break;
                 }
                 return hipErrorInvalidValue;
+            }
+            if (LOGNIN == 12 && DABGPU_RS4_UNPACKED) {
+                const size_t ldsu = (size_t)Fft<12>::LDS_ELEMS * sizeof(float2) + (2 + 56 + 448) * sizeof(float2) + 2048 * sizeof(float);
+                if (poly) hipLaunchKernelGGL((resampler_u_kernel<true, false>), grid, block, ldsu, s, a, hpr);
+                else hipLaunchKernelGGL((resampler_u_kernel<false, false>), grid, block, ldsu, s, a, hpr);
+                break;
             }
             if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
             else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
