@@ -758,6 +758,15 @@ def test_chain_tii_windowed_guard(pkg):
                     dict(gain_mode=2, normalise=1.0 / 50000.0, window_overlap=10), setup)
 
 
+def test_chain_tii_windowed_guard_without_fir(pkg):
+    """TII on the chain whose guard interval the frame kernel windows itself: the cached TII segment (null symbol through
+    the unfused windowed guard, its suffix spilling into symbol 1's seam) adds onto the fused kernel's output."""
+    def setup(md):
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_window_overlap(10)
+    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN, dict(gain_mode=2, normalise=1.0 / 50000.0, window_overlap=10), setup)
+
+
 def test_chain_cfg4_with_tii(pkg):
     def setup(md):
         md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
