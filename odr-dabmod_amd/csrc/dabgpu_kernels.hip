@@ -100,6 +100,9 @@
                                 // instruction occupies the SIMD for two scalar ones, and the compiler fences every asm statement whose
                                 // result is used next with an s_nop.  Kept as a knob.
 #endif
+#ifndef DABGPU_BLOCKPAD8
+#define DABGPU_BLOCKPAD8 1
+#endif
 #ifndef DABGPU_EQ_R
 #define DABGPU_EQ_R 4           // EQ variant: outputs of the inverse filter per lane (4: 176 lanes at work, 2.63 M TF/s; 3: 240 lanes, 2.58 M)
 #endif
@@ -439,6 +442,8 @@ template <int LOGN> struct Fft {
     // every value once).  Both sides conflict-free; every address still base + immediate.
     static constexpr int X1_PITCH = T + 4;
     static constexpr bool X1_ROWS = DABGPU_X1_ROWS && T >= 32;      // (8 (T + 4) elements must fit in LDS_ELEMS)
+    // stride-8 exchange of 8-byte elements with one pad block of 8 per 64 elements (see xwrite)
+    template <int NS, typename V> static constexpr bool BLOCKPAD8() { return DABGPU_BLOCKPAD8 && NS == 8 && sizeof(V) == 8 && T % 64 == 0; }
     template <int NS, typename V> static DEV void xwrite(const V *v, V *lds, int t)
     {
         if (DABGPU_SPLIT_W128 && sizeof(V) == 16) {
@@ -462,6 +467,16 @@ template <int LOGN> struct Fft {
             for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[r * X1_PITCH] = v[r];
             return;
         }
+        if (BLOCKPAD8<NS, V>()) {
+            // 8-byte elements, stride 8: element i at i + 8 (i >> 6) -- the lane's eight elements 64 a + b + 8 r share one
+            // block of 64, so the scatter is base + 8 r (bank pairs 16 a + 2 b + 16 r: distinct over the 32 lanes of a pass) and
+            // the gather of t + T m is t + 8 (t >> 6) + m (T + T/8): 32 consecutive elements, conflict-free too.  (One pad per
+            // 8 elements, i + (i >> 3), made the gather 2-way conflicted: lanes 29 - 31 of a pass wrapped onto lanes 0 - 2.)
+            V *wp = lds + ((t >> 3) * 72 + (t & 7));
+#pragma unroll
+            for (int r = 0; r < DABGPU_EXPERIMENT_XR; ++r) wp[8 * r] = v[r];
+            return;
+        }
         // (the padded read address base + m (T + T/P) needs T to be a multiple of P: tiny transforms go unpadded)
         constexpr int PS = sizeof(V) == 8 ? 3 : DABGPU_C2_PAD_SHIFT, P = 1 << PS;
         constexpr bool PAD = (T % P == 0) && (sizeof(V) == 8 ? (NS < 64) : (NS == 1));
@@ -476,6 +491,12 @@ template <int LOGN> struct Fft {
             const V *rp = lds + ((t & 7) * X1_PITCH + (t >> 3));
 #pragma unroll
             for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[m * (T / 8)];
+            return;
+        }
+        if (BLOCKPAD8<NS, V>()) {
+            const V *rp = lds + (t + 8 * (t >> 6));
+#pragma unroll
+            for (int m = 0; m < DABGPU_EXPERIMENT_XR; ++m) v[m] = rp[m * (T + T / 8)];
             return;
         }
         constexpr int PS = sizeof(V) == 8 ? 3 : DABGPU_C2_PAD_SHIFT, P = 1 << PS;
