@@ -709,9 +709,10 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         a.out = native_out;
         a.out_stride = native;
         HIPCHK(c, launch_tf(a, flags, s));
-    } else if (!(mask & DABGPU_STAGE_FIR) && tf_has_window(a, flags | TF_GUARD)) {
-        // OFDM windowing without FIR on the coded-bits chain: the frame kernel windows the guard interval itself
-        flags |= TF_GUARD | TF_WINDOW;
+    } else if (tf_has_window(a, flags | TF_GUARD | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0))) {
+        // OFDM windowing on the coded-bits chain, with or without FIRFilter: the frame kernel windows the guard interval
+        // itself (and filters across the seams)
+        flags |= TF_GUARD | TF_WINDOW | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0);
         a.chunks_per_frame = auto_chunks(c, n_frames);
         a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
         a.out = native_out;

@@ -72,7 +72,7 @@ enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR =
                TF_OUT_S16 = 64, TF_LEAN = 128 /* internal */, TF_WINDOW = 256, TF_EQ = 512 };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
-size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0);
+size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0, int overlap = 0, int ntaps = 0);
 int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
 bool tf_has_eq(const TfArgs &a, unsigned flags);     // the equalised-boundary variant exists for this chain (TF_EQ; needs t.eq_g)
 bool tf_has_window(const TfArgs &a, unsigned flags); // a frame-kernel variant windows the guard interval itself (TF_WINDOW)

@@ -22,7 +22,8 @@
 //     taps on the occupied carriers.  Every other FIR variant: the unfiltered and the filtered IFFT of a symbol as
 //     ONE packed dual transform (struct c2), the unfiltered half pruned to the 88 samples the boundary FIR reads
 //     (Fft::run_dual_zonly), those boundary outputs a direct FIR;
-//   * OFDM windowing without FIR (WIN): the raised-cosine seams between symbols through LDS.
+//   * OFDM windowing (WIN): the raised-cosine seams between symbols through LDS; with FIR as well, the windowed stream
+//     around every seam is built in LDS and the outputs that look into it are a direct FIR (packed dual transform).
 // HBM traffic is therefore the compulsory 28.8 kB in + 1.57 MB out per frame.
 //
 // No MFMA (no dense contraction in this path), wave64 throughout.
@@ -1139,7 +1140,9 @@ void tf_kernel(const TfArgs a)
     static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR && DABGPU_DUAL_FFT && !DABGPU_FFT_DBUF),
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
-    static_assert(!WIN || (FROM_BITS && GUARD && !FIR && !CFR && OFMT == 0), "WIN: coded-bits chain, guard interval, no FIR");
+    static_assert(!WIN || (FROM_BITS && GUARD && !CFR && OFMT == 0), "WIN: coded-bits chain with guard interval");
+    static_assert(!(WIN && FIR) || (DABGPU_DUAL_FFT && !ZONLY && !EQ && NT == 0 && !GVAR),
+                  "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count");
     static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY && !WIN),
                   "EQ: the Mode I coded-bits chain with the 45-tap filter");
     typedef ModeGeom<LOGN> G;
@@ -1173,7 +1176,7 @@ void tf_kernel(const TfArgs a)
     constexpr int KB = NT ? NT - 1 : kBnd;      // slots per half buffer: the look-ahead C when it is a compile-time constant
     // WIN: two seam buffers [last W | first W samples of a symbol], the rising 2W samples of the next one, the window
     cf *wbuf = bnd;
-    float *win_l = reinterpret_cast<float *>(wbuf + 6 * kWinMax);
+    float *win_l = reinterpret_cast<float *>(wbuf + 6 * kWinMax);     // (WIN with FIR: moved behind the other tables below)
     // EQ: two windows of the previous filtered symbol (index q + kEqQL, q in [-kEqQL, kEqQH]), the difference w, the
     // 44 unfiltered differences d, the inverse filter
     // (kEqW: the matrix-core form reads w up to index 175 + 32; the tail past kEqQL + kEqQH stays zero)
@@ -1186,7 +1189,7 @@ void tf_kernel(const TfArgs a)
     // four waves, [wave][output m < 48][re | im]
     float *gp_l = g_l + (kEqTaps + 8);
     [[maybe_unused]] float *eq_part = gp_l + 192;
-    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : FIR ? 4 * KB : (WIN ? 7 * kWinMax : 0)));
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : (FIR && !WIN) ? 4 * KB : ((WIN && !FIR) ? 7 * kWinMax : 0)));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
     // small read-only tables copied to LDS once: read through global memory they compile to
@@ -1222,6 +1225,13 @@ void tf_kernel(const TfArgs a)
         for (int i = t; i < 3 * kEqW; i += blockDim.x) eq_zp[i] = mk(0.f, 0.f);     // (both windows, w: the tails stay zero)
     }
     const int W = WIN ? a.overlap : 0;
+    // WIN with FIR: behind everything else, sized at run time (C = ntaps - 1): two stashes of a symbol's
+    // [x[N-W-C .. N) | x[0 .. W)] (C + 2W each), the next symbol's x[N-cp-W .. N-cp+W+C) (2W + C), the windowed stream
+    // U around the seam (2W + 2C), the window
+    const int wfC = (WIN && FIR) ? a.ntaps - 1 : 0, wfLP = wfC + 2 * W;
+    cf *wfb = tw64_l + 448;
+    cf *wf_cur = wfb + 2 * wfLP, *wf_U = wf_cur + (2 * W + wfC);
+    if (WIN && FIR) win_l = reinterpret_cast<float *>(wf_U + (2 * W + 2 * wfC));
     if (WIN)
         for (int i = t; i < 2 * W; i += blockDim.x) win_l[i] = a.t.window[i];
     if (FROM_BITS)
@@ -1633,6 +1643,24 @@ void tf_kernel(const TfArgs a)
         }
     };
 
+    // the same for n_out outputs at stream position out_pos .. (WIN with FIR): output i = sum_j taps[j] src[i + j]
+    auto boundary_n = [&](const cf *src, int n_out, int out_pos) __attribute__((always_inline)) {
+        for (int i0 = 0; i0 < n_out; i0 += kThreads / 4) {
+            const int i = i0 + (t >> 2), q = t & 3;
+            const int ii = i < n_out ? i : 0;
+            cf acc = mk(0.f, 0.f);
+            for (int j = q; j < ntaps; j += 4) {
+                const cf x = src[ii + j];
+                const float tp = taps_l[j];
+                acc.x = fmaf(x.x, tp, acc.x);
+                acc.y = fmaf(x.y, tp, acc.y);
+            }
+            acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);
+            acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);
+            if (i < n_out && q == 0) put(out_pos + i0, t >> 2, acc);
+        }
+    };
+
     // EQ: the 44 boundary outputs of the previous segment from the filtered symbols (see the template's comment).
     // zp = the previous symbol's windows; eq_w holds w (written by the lanes that own those samples, a barrier ago).
     auto eq_boundary = [&](const cf *zp) __attribute__((always_inline)) {
@@ -1770,7 +1798,7 @@ void tf_kernel(const TfArgs a)
             if (i0 + t < nz) put(i0, t, mk(0.f, 0.f));
         if (EQ) {
             for (int i = t; i < kEqW; i += (int)blockDim.x) eq_zp[cur * kEqW + i] = mk(0.f, 0.f);
-        } else if (FIR) {
+        } else if (FIR && !WIN) {
             for (int i = t; i < KB; i += (int)blockDim.x) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
         }
         if (FIR) {
@@ -1778,7 +1806,9 @@ void tf_kernel(const TfArgs a)
             prev_pos = 0;
             prev_seg = len0;
         }
-        if (WIN) {
+        if (WIN && FIR) {
+            for (int i = t; i < wfLP; i += (int)blockDim.x) wfb[cur * wfLP + i] = mk(0.f, 0.f);
+        } else if (WIN) {
             for (int i = t; i < 2 * W; i += (int)blockDim.x) wbuf[cur * 2 * kWinMax + i] = mk(0.f, 0.f);
             have_prev = true;
         }
@@ -1938,7 +1968,7 @@ void tf_kernel(const TfArgs a)
         // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the
         // (unfiltered, filtered) pairs the dual transform left side by side; everything below uses v and z as is
         constexpr bool PRESCALED = (DUAL || WIN || EQ) && GAIN;
-        if ((WIN || EQ) && GAIN) {
+        if (((WIN && !FIR) || EQ) && GAIN) {
 #pragma unroll
             for (int m = 0; m < 8; ++m) v[m] = cscale(v[m], g);
         } else if (PRESCALED && ZONLY) {
@@ -1975,6 +2005,44 @@ void tf_kernel(const TfArgs a)
             if (t <= kEqQH) zp_new[kEqQL + t] = v[0];
             lds_barrier();
             // (the boundary outputs follow the symbol's own stores, below: its samples are dead registers by then)
+        } else if constexpr (WIN && FIR) {
+            // ---- windowed seam AND look-ahead filter: the C + 2W outputs whose 45 samples touch the seam ----
+            // U = [x_prev[N-W-C .. N-W) | the 2W seam samples (as without FIR) | x_cur[N-cp+W .. N-cp+W+C)] is the stream as the
+            // reference's FIRFilter sees it; output i of them, at stream position pos - W - C + i, is sum_j taps[j] U[i + j].
+            cf *pprev = wfb + cur * wfLP, *pnew = wfb + (cur ^ 1) * wfLP;
+            if (lane_on) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int n = t + T * m, ta = n - (N - W - C), r = n - (N - cpl - W);
+                    if (ta >= 0) pnew[ta] = v[m];
+                    if (n < W) pnew[C + W + n] = v[m];
+                    if (r >= 0 && r < 2 * W + C) wf_cur[r] = v[m];
+                }
+            }
+            lds_barrier();
+            if (have_prev) {
+                for (int i = t; i < 2 * W + 2 * C; i += kThreads) {
+#pragma clang fp contract(off)  // seam: products and sum rounded separately, like the reference (see guard_window_at)
+                    cf u;
+                    if (i < C) {
+                        u = pprev[i];
+                    } else if (i < C + 2 * W) {
+                        const int j = i - C;
+                        const cf xp = pprev[i], xr = wf_cur[j];
+                        const float fp = win_l[2 * W - 1 - j], fr = win_l[j];
+                        const float ar = xp.x * fp, ai = xp.y * fp, br = xr.x * fr, bi = xr.y * fr;
+                        u = mk(ar + br, ai + bi);
+                    } else {
+                        u = wf_cur[i - C];
+                    }
+                    wf_U[i] = u;
+                }
+                lds_barrier();
+                boundary_n(wf_U, C + 2 * W, pos - W - C);
+            }
+            cur ^= 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = z[m];
         } else if (FIR) {
             // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
             cf *tail_new = bnd + (cur ^ 1) * 2 * KB, *tail_prev = bnd + cur * 2 * KB, *head = tail_prev + C;
@@ -2026,7 +2094,7 @@ void tf_kernel(const TfArgs a)
                 F::template run<+1, DBUF, cf, kU8, TW64 ? 1 : 0>(v, fbuf, fpar, tw, tt, tw8_l, tw64_l);
             }
         }
-        if (WIN) {
+        if (WIN && !FIR) {
             // ---- seam between the previous symbol and this one -------------------------
             cf *pprev = wbuf + cur * 2 * kWinMax, *pnew = wbuf + (cur ^ 1) * 2 * kWinMax, *rise = wbuf + 4 * kWinMax;
             if (lane_on) {
@@ -2059,8 +2127,8 @@ void tf_kernel(const TfArgs a)
             for (int m = 0; m < 8; ++m) {
                 const int n = t + T * m;
                 const cf y = scaled(v[m]);
-                // FIR: the last C belong to `boundary`
-                if ((!FIR || n < N - C) && (keep_tail || n < N - W)) put(pos + cpl + T * m, t, y);
+                // FIR: the last C belong to `boundary`; WIN: the last W to the seam (with both: the last C + W)
+                if (FIR ? n < N - C - (keep_tail ? 0 : W) : (keep_tail || n < N - W)) put(pos + cpl + T * m, t, y);
                 if ((m > m_cp || (m == m_cp && n >= N - cpl)) && (!WIN || n - (N - cpl) >= W)) put(pos, n - (N - cpl), y);
             }
         }
@@ -2082,6 +2150,13 @@ void tf_kernel(const TfArgs a)
         for (int i = t; i < kEqW; i += (int)blockDim.x) eq_w[i] = mk(-zp[i].x, -zp[i].y);
         lds_barrier();
         eq_boundary(zp);
+    } else if (WIN && FIR && s_end == nsym && have_prev) {
+        // end of the frame: the last symbol keeps its (unwindowed) tail, nothing follows it
+        const cf *stash = wfb + cur * wfLP;
+        lds_barrier();
+        for (int i = t; i < 2 * C; i += (int)blockDim.x) wf_U[i] = i < C ? stash[W + i] : mk(0.f, 0.f);
+        lds_barrier();
+        boundary_n(wf_U, C, prev_pos + prev_seg - C);
     } else if (FIR && s_end == nsym && have_prev) {
         // end of the frame: the look-ahead runs off the buffer, missing terms are
         // dropped (reference src/FIRFilter.cpp:186-191)
@@ -2105,7 +2180,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const bool gvar = !(flags & TF_FROM_BITS) && (flags & TF_GAIN) && !(flags & TF_CFR) && a.gain.mode == 2;
     const bool lean = DABGPU_TF_LEAN && LOGN == 11 && NT == 45 && (flags & TF_FROM_BITS) && (flags & TF_FIR) && (flags & TF_GUARD) &&
                       DABGPU_ZONLY && !(flags & TF_CFR) && (!(flags & TF_GAIN) || a.gain.mode != 1);
-    size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0) | (lean ? TF_LEAN : 0), (flags & TF_FIR) ? NT : 0);
+    size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0) | (lean ? TF_LEAN : 0), (flags & TF_FIR) ? NT : 0, a.overlap, a.ntaps);
     // (tuning aid: DABGPU_EXTRA_LDS=<bytes> pads the allocation, i.e. lowers the number of workgroups a CU holds)
     static const size_t extra_lds = [] { const char *e = getenv("DABGPU_EXTRA_LDS"); return e ? (size_t)atol(e) : (size_t)0; }();
     lds += extra_lds;
@@ -2144,8 +2219,13 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 #undef TF_LAUNCH_GVAR
     if (flags & TF_WINDOW) {
         if (!tf_has_window(a, flags) || NT != 0) return hipErrorInvalidValue;
-        if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+        if (fr) {
+            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, true, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, true, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+        } else {
+            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+        }
         return hipGetLastError();
     }
     if (LOGN == 11 && NT == 45 && !fb && !gn && fr && gd && DABGPU_ZONLY) {
@@ -2189,7 +2269,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 
 }  // namespace
 
-size_t tf_lds_bytes(int logN, unsigned flags, int nt)
+size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
 {
     const size_t N = (size_t)1 << logN;
     if (flags & TF_LEAN) {
@@ -2205,8 +2285,9 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
                     : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
     b += 16 * sizeof(double);
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
+    const bool wf = (flags & TF_WINDOW) && (flags & TF_FIR);
     if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter
-    else if (flags & TF_FIR) b += 4 * (nt ? nt - 1 : DABGPU_KBND) * sizeof(float2);  // 2 x [tail | next head]
+    else if ((flags & TF_FIR) && !wf) b += 4 * (nt ? nt - 1 : DABGPU_KBND) * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
     b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
 #if DABGPU_TW8_LDS
@@ -2214,7 +2295,14 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
 #endif
     if ((flags & TF_FIR) && (DABGPU_TW64_LDS || ((flags & TF_GVAR) && DABGPU_GVAR_TW64))) b += 448 * sizeof(float2);
     if (flags & TF_CFR) b += (448 * sizeof(float2)) + 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red sits behind the tw64 slot
-    if (flags & TF_WINDOW) b += 7 * kWinMax * sizeof(float2);                                     // seam buffers + window
+    if (wf) {
+        // behind the (always laid out) stride-64 twiddle slot: two stashes, the next symbol's samples, the windowed stream, the window
+        const size_t C = (size_t)std::max(ntaps - 1, 0), W = (size_t)std::max(overlap, 0);
+        if (!(flags & TF_CFR) && !((flags & TF_FIR) && (DABGPU_TW64_LDS || ((flags & TF_GVAR) && DABGPU_GVAR_TW64)))) b += 448 * sizeof(float2);
+        b += (2 * (C + 2 * W) + (2 * W + C) + (2 * W + 2 * C)) * sizeof(float2) + 2 * W * sizeof(float) + 16;
+    } else if (flags & TF_WINDOW) {
+        b += 7 * kWinMax * sizeof(float2);                                     // seam buffers + window
+    }
     return b;
 }
 
@@ -2222,9 +2310,13 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt)
 // without FIR / CFR / s16 store, overlap up to kWinMax (and inside the cyclic prefix)
 bool tf_has_window(const TfArgs &a, unsigned flags)
 {
-    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_FIR | TF_CFR | TF_OUT_S16;
-    return (flags & want) == want && !(flags & never) && a.overlap >= 1 && a.overlap <= kWinMax &&
-           a.overlap <= a.g.sym_size - a.g.N;
+    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_CFR | TF_OUT_S16;
+    if ((flags & want) != want || (flags & never) || a.overlap < 1 || a.overlap > kWinMax) return false;
+    // with FIR: the filter's look-ahead and the window must both fit into the cyclic prefix
+    if (flags & TF_FIR)
+        return DABGPU_DUAL_FFT && a.ntaps >= 1 && a.ntaps <= DABGPU_KBND && a.ntaps <= kMaxTaps &&
+               a.overlap + a.ntaps - 1 <= a.g.sym_size - a.g.N;
+    return a.overlap <= a.g.sym_size - a.g.N;
 }
 
 int tf_max_fused_taps() { return DABGPU_KBND < kMaxTaps ? DABGPU_KBND : kMaxTaps; }
@@ -2260,7 +2352,7 @@ hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
         case 9: return launch_tf_n<9, 0>(a, flags, s);
         case 10: return launch_tf_n<10, 0>(a, flags, s);
         case 11:
-            return ((flags & TF_FIR) && a.ntaps == 45 && !(flags & TF_CFR)) ? launch_tf_n<11, 45>(a, flags, s)
+            return ((flags & TF_FIR) && a.ntaps == 45 && !(flags & (TF_CFR | TF_WINDOW))) ? launch_tf_n<11, 45>(a, flags, s)
                                                        : launch_tf_n<11, 0>(a, flags, s);
     }
     return hipErrorInvalidValue;

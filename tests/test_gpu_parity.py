@@ -540,6 +540,41 @@ def test_chain_windowed_guard_without_fir_is_windowed_by_the_frame_kernel(pkg, m
                         % (mode, overlap, chunks, gain_mode), np.abs(y - ref).max() / np.abs(ref).max(), 5e-7)
 
 
+@pytest.mark.parametrize("mode,overlap", [(1, 10), (1, 1), (1, 128), (2, 10), (2, 80), (3, 7), (3, 19), (4, 10)])
+@pytest.mark.parametrize("chunks", [1, 3, 77])
+@pytest.mark.parametrize("gain_mode", [None, 2, 1])
+def test_chain_windowed_guard_with_fir_is_one_kernel_too(pkg, mode, overlap, chunks, gain_mode):
+    """ofdmwindowing > 0 AND FIRFilter: the frame kernel (packed dual transform) builds the windowed stream around every
+    seam in LDS and filters the C + 2W outputs whose look-ahead touches it directly; frame start, frame end (the last
+    symbol keeps its tail) and every chunking."""
+    if chunks == 77 and (mode != 1 or gain_mode == 1):
+        pytest.skip("one symbol per workgroup is exercised on Mode I")
+    def setup(md):
+        if gain_mode is not None:
+            md.set_gain(gain_mode, 1.0, 1.0 / 50000.0 if gain_mode == 2 else 1.0, 4.0)
+        md.set_window_overlap(overlap)
+    kw = dict(window_overlap=overlap)
+    if gain_mode is not None:
+        kw.update(gain_mode=gain_mode, normalise=1.0 / 50000.0 if gain_mode == 2 else 1.0)
+    stages = pkg.STAGE_FIR | (pkg.STAGE_GAIN if gain_mode is not None else 0)
+    y, ref = _chain_case(pkg, mode, stages, chunks, 2, kw, setup)
+    assert record_bound("a6+a7+a8+a9 windowed chain with FIR max-abs / |out|_inf, mode %d overlap %d chunks %d gain %s"
+                        % (mode, overlap, chunks, gain_mode), np.abs(y - ref).max() / np.abs(ref).max(), 7e-7)
+
+
+def test_chain_windowed_guard_with_a_short_and_a_long_filter(pkg):
+    """Other tap counts with a windowed guard interval: 13 taps (fused), 100 taps (fused: 99 + 10 fit the 504-sample
+    prefix), 300 taps (beyond the fused kernel's tap table: IFFT kernel -> guard + FIR kernel)."""
+    for ntaps in (13, 100, 300):
+        taps = (synth_signal(ntaps, seed=ntaps).real * np.float32(1 / 200)).astype(np.float32)
+        def setup(md):
+            md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_fir_taps(taps)
+            md.set_window_overlap(10)
+        _chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, 3, 2,
+                    dict(gain_mode=2, normalise=1.0 / 50000.0, taps=taps, window_overlap=10), setup)
+
+
 def test_chain_windowed_guard_fused_equals_the_guard_kernel(pkg):
     """The fused seams against GuardIntervalInserter's own kernel (bit-exact against the reference golden) fed with
     the chain's symbols: the same two products and one sum per seam sample."""
