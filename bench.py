@@ -132,9 +132,89 @@ def cpu_baseline(workload, seconds_budget=14.0):
                          nn, dtn, np1, dtp1, n1, dt1)}
 
 
+def free_port():
+    import socket
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    return port
+
+
+def rank_devices(n):
+    """Device ordinal of every local rank.  Default: rank r -> GPU r.  DABGPU_BENCH_DEVICES="0,0" maps ranks onto
+    explicit ordinals (tests put two ranks on the one leased GPU)."""
+    spec = os.environ.get("DABGPU_BENCH_DEVICES")
+    if spec:
+        devs = [int(x) for x in spec.split(",")]
+        if len(devs) < n:
+            raise SystemExit("bench.py: DABGPU_BENCH_DEVICES names %d devices for %d ranks" % (len(devs), n))
+        return devs[:n]
+    return list(range(n))
+
+
+def launch_ranks(n, argv, dry_run):
+    """`python bench.py --gpus N` outside torch.distributed.run: start N ranks of this script, one per GPU
+    (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_* in their environment, as the driver's launcher sets them), rank 0's
+    stdout on ours, the others' on stderr.  Returns the exit status of the job."""
+    import subprocess
+    devs = rank_devices(n)
+    if not dry_run:
+        import torch
+        have = torch.cuda.device_count() if torch.cuda.is_available() else 0
+        if have <= max(devs):
+            raise SystemExit("bench.py: --gpus %d needs devices %s, this node has %d GPU(s)" % (n, devs, have))
+    port = free_port()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DABGPU_BENCH_CHILD="1")
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
+                                      stdout=None if r == 0 else sys.stderr))
+    rc = 0
+    try:
+        pending = list(procs)
+        while pending:
+            for p in list(pending):
+                st = p.poll()
+                if st is None:
+                    continue
+                pending.remove(p)
+                if st != 0 and rc == 0:
+                    rc = st
+                    for q in pending:            # one rank failed: the others would wait in a barrier for ever
+                        q.terminate()
+            time.sleep(0.05)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    return rc
+
+
+def dry_run(args, streams):
+    """--dry-run: the launcher, the process group (gloo when there is no GPU), the barrier-bracketed timing and the
+    one-line contract with a sleep standing in for the kernels -- what the CPU tests exercise at N = 2."""
+    grp = streams.StreamGroup(backend=os.environ.get("DABGPU_DIST_BACKEND", "gloo"))
+    B = args.frames
+    wall = grp.timed(lambda: time.sleep(0.01 * (1 + grp.rank)), args.steps, lambda: None)
+    line = {"metric": "Mode-I TX frames/sec (196608 IQ/frame)", "value": round(grp.job_frames_per_second(B, args.steps, wall), 2),
+            "unit": "frames/s", "n_gpus": grp.world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(wall / args.steps * 1e3, 4), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f32", "data": "dry-run (no kernels)",
+            "config": {"workload": "dry run of the %d-rank harness" % grp.world, "frames_per_step_per_gpu": B,
+                       "devices": rank_devices(grp.world), "stream_seed": grp.stream_seed(42)}}
+    if grp.rank == 0:
+        grp.emit(json.dumps(line))
+    grp.close()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--dry-run", action="store_true",
+                    help="run the N-rank harness (launcher, process group, timing, JSON line) without any kernel")
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--workload", default="cfg3", choices=sorted(ALGO_BYTES))
@@ -147,18 +227,39 @@ def main():
                     help="after the timed region, gather FRAMES frames of IQ from every rank on rank 0 (the optional "
                          "final IQ gather over RCCL / xGMI) and report its time separately; 0 = off")
     args = ap.parse_args()
+    if args.gpus < 1:
+        raise SystemExit("bench.py: --gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None:
+        if args.gpus > 1:
+            # not under torch.distributed.run: be the launcher (one rank per GPU, rank 0's line on our stdout)
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:], args.dry_run))
+    elif int(env_world) != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE=%s: launch one rank per GPU (python -m torch.distributed.run "
+                         "--nproc-per-node %d bench.py --gpus %d ..., or plain `python bench.py --gpus %d`)"
+                         % (args.gpus, env_world, args.gpus, args.gpus, args.gpus))
+
+    streams = importlib.import_module("odr-dabmod_amd.streams")
+    if args.dry_run:
+        return dry_run(args, streams)
 
     import numpy as np
     import torch
 
     P = pkg()
-    streams = importlib.import_module("odr-dabmod_amd.streams")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (there is no CPU fallback)")
-    grp = streams.StreamGroup(backend="nccl")     # torch.distributed over RCCL when N > 1
-    rank, local_rank, world = grp.rank, grp.local_rank, grp.world
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    devs = rank_devices(args.gpus)
+    device_index = devs[int(os.environ.get("LOCAL_RANK", "0"))]
+    if device_index >= torch.cuda.device_count():
+        raise SystemExit("bench.py: rank %s wants GPU %d, this node has %d" % (os.environ.get("RANK", "0"), device_index,
+                                                                              torch.cuda.device_count()))
+    torch.cuda.set_device(device_index)
+    # torch.distributed over RCCL when N > 1 (DABGPU_DIST_BACKEND=gloo: ranks that share a GPU in the tests)
+    grp = streams.StreamGroup(backend=os.environ.get("DABGPU_DIST_BACKEND", "nccl"), device_index=device_index)
+    rank, world = grp.rank, grp.world
+    local_rank = device_index
+    dev = torch.device("cuda", device_index)
 
     def run_workload(workload, B, steps, warmup, fmt=None):
         md = P.Modulator(mode=1, device=local_rank, max_frames=B, chunks_per_frame=args.chunks)

@@ -9,12 +9,14 @@ import time
 
 
 class StreamGroup:
-    def __init__(self, backend=None):
+    def __init__(self, backend=None, device_index=None):
         import torch
         import torch.distributed as dist
         self.rank = int(os.environ.get("RANK", "0"))
         self.local_rank = int(os.environ.get("LOCAL_RANK", "0"))
         self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        # the GPU this rank drives (default: its local rank)
+        self.device_index = self.local_rank if device_index is None else int(device_index)
         self._dist = dist
         self._torch = torch
         self.backend = backend
@@ -27,7 +29,7 @@ class StreamGroup:
             self.backend = backend
             kw = {}
             if backend == "nccl":
-                kw["device_id"] = torch.device("cuda", self.local_rank)
+                kw["device_id"] = torch.device("cuda", self.device_index)
             # RCCL prints its version banner on the C-level stdout whenever it first creates a communicator -- at
             # init, at the first collective of a kind, or as late as teardown.  The bench's stdout carries exactly
             # one JSON line, so for the life of the group file descriptor 1 points at stderr and the line goes out
@@ -54,7 +56,7 @@ class StreamGroup:
         """The job's elapsed time is the slowest rank's."""
         if not self._collective:
             return float(seconds)
-        dev = "cuda:%d" % self.local_rank if self.backend == "nccl" else "cpu"
+        dev = "cuda:%d" % self.device_index if self.backend == "nccl" else "cpu"
         t = self._torch.tensor([float(seconds)], dtype=self._torch.float64, device=dev)
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())

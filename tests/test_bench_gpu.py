@@ -44,3 +44,29 @@ def test_bench_with_a_real_rccl_communicator_on_one_rank():
     assert d["n_gpus"] == 1 and d["value"] > 0 and d["scaling"] == "weak"
     g = d["iq_gather"]
     assert g["frames_per_rank"] == 8 and g["bytes_per_rank"] == 8 * 196608 * 8 and g["ranks"] == 1 and g["ms"] > 0
+
+
+def test_bench_gpus_2_launches_two_ranks():
+    """`python bench.py --gpus 2` with no launcher around it starts two ranks itself.  One GPU is leased here, so both
+    ranks drive device 0 (DABGPU_BENCH_DEVICES) and talk over gloo; the line must say n_gpus = 2 and its value must be
+    both ranks' frames over the slower rank's time."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DABGPU_BENCH_DEVICES="0,0", DABGPU_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "4", "--warmup", "1",
+                        "--frames", "256", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 4 and d["config"]["frames_per_step_per_gpu"] == 256
+    assert abs(d["value"] - 2 * 256 * 4 / (d["ms_per_step"] * 4e-3)) / d["value"] < 1e-3
+    one = run_bench([], {})                       # the one-rank line is what it was
+    assert one["n_gpus"] == 1
+
+
+def test_bench_gpus_beyond_the_node_fails_loudly():
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DABGPU_BENCH_DEVICES")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "needs devices" in r.stderr and not r.stdout.strip()

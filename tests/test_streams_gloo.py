@@ -111,3 +111,37 @@ def test_two_ranks_modulate_their_own_streams_and_gather(tmp_path):
     assert outs[0]["seed"] != outs[1]["seed"] and outs[0]["sha"] != outs[1]["sha"]      # two different streams
     assert outs[0]["gathered"] == [outs[0]["sha"], outs[1]["sha"]]                      # rank order on the root
     assert abs(outs[0]["fps"] - outs[1]["fps"]) < 1e-6 and outs[0]["fps"] > 0
+
+
+def test_bench_launches_n_ranks_itself_dry_run():
+    """`python bench.py --gpus 2` outside torch.distributed.run is its own launcher: two ranks over gloo, ONE JSON
+    line (rank 0's) with n_gpus = 2 and the whole-job value (--dry-run: a sleep stands in for the kernels)."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run", "--steps", "3",
+                        "--warmup", "1", "--frames", "100"], env=env, capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["scaling"] == "weak"
+    # rank 1 sleeps 20 ms per step, rank 0 10 ms: the job's time is the slow rank's, the value both ranks' frames
+    assert 0.02 * 3 <= d["ms_per_step"] * 3e-3 < 0.5
+    assert abs(d["value"] - 2 * 100 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+    assert d["config"]["devices"] == [0, 1]
+
+
+def test_bench_refuses_a_world_size_that_contradicts_gpus():
+    env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode != 0 and "WORLD_SIZE=4" in r.stderr and not r.stdout.strip()
+
+
+def test_bench_one_rank_dry_run_needs_no_process_group():
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--dry-run", "--steps", "2"], env=env,
+                       capture_output=True, text=True, timeout=60)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert json.loads(r.stdout.strip())["n_gpus"] == 1
