@@ -47,7 +47,9 @@ def source_hash():
     (profiles/traffic.json) to the kernels they were collected on."""
     import hashlib
     h = hashlib.sha256()
-    for name in ("dabgpu_kernels.hip", "dabgpu_api.hip", "dabgpu_internal.h", "Makefile"):
+    names = sorted(n for n in os.listdir(_CSRC) if n.endswith((".hip", ".h")) or n == "Makefile")
+    for name in names:
+        h.update(name.encode())
         h.update(open(os.path.join(_CSRC, name), "rb").read())
     h.update(open(os.path.join(os.path.dirname(_CSRC), "..", "include", "dabgpu.h"), "rb").read())
     return h.hexdigest()[:16]
@@ -55,7 +57,7 @@ def source_hash():
 
 def build(verbose=False):
     """Compile the HIP library for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
-    cmd = ["make", "-C", _CSRC, "-j2"]
+    cmd = ["make", "-C", _CSRC, "-j%d" % max(2, min(8, os.cpu_count() or 2))]
     if not verbose:
         cmd.insert(1, "-s")
     subprocess.check_call(cmd)

@@ -205,7 +205,7 @@ template <typename T> hipError_t upload(DevBuf &b, const std::vector<T> &v, hipS
 }
 
 // Inverse of the FIR filter on the occupied carriers, for the equalised-boundary variant of the frame kernel
-// (tf_kernel<..., EQ>, dabgpu_kernels.hip): real g[0 .. L) with
+// (tf_kernel<..., EQ>, tf_kernel.h): real g[0 .. L) with
 //     x[n] = sum_j g[j] z[n - (j - c)]      (z = x filtered cyclically, z[n] = sum_j taps[j] x[n + j]),
 // i.e. G[k] H[k] = 1 on the K occupied bins, G[k] = sum_j g[j] exp(-2 pi i k (j - c) / N), and little gain in the empty
 // band (stop-band rows weighted sqrt(lambda); the transition bins are free, which is what lets a short g fit to 1e-8).

@@ -69,7 +69,7 @@ struct TfArgs {
 };
 
 enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */,
-               TF_OUT_S16 = 64, TF_LEAN = 128 /* internal */, TF_WINDOW = 256, TF_EQ = 512 };
+               TF_OUT_S16 = 64, TF_WINDOW = 256, TF_EQ = 512 };
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0, int overlap = 0, int ntaps = 0);

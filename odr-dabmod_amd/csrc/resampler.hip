@@ -1,0 +1,338 @@
+// resampler.hip -- a10 Resampler + a11 MemlessPoly: the x2 / x4 kernel of BASELINE config 4 (resampler_kernel) and the
+// dispatch of every ratio (the general kernels live in resampler_rational.h, one translation unit per FFT size).
+#include "device_common.h"
+
+namespace dabgpu {
+
+// defined in resampler_rational_inst.hip, one per input FFT size
+hipError_t launch_resampler_rational_9(const ResamplerArgs &a, hipStream_t s);
+hipError_t launch_resampler_rational_10(const ResamplerArgs &a, hipStream_t s);
+hipError_t launch_resampler_rational_11(const ResamplerArgs &a, hipStream_t s);
+hipError_t launch_resampler_rational_12(const ResamplerArgs &a, hipStream_t s);
+
+namespace {
+
+
+// ===========================================================================
+// a10 Resampler (src/Resampler.cpp:131-195), up-sampling by Q = nout/nin.
+//
+// Stateless restatement: out_h = second_half(Y_{h-1}) + first_half(Y_h),
+// Y_h = IDFT_nout( stuff( DFT_nin( w * [c_{h-1} | c_h] ) ) * factor ).
+// The zero-stuffed nout-point IDFT is never formed: because only the nin lowest
+// |frequencies| are occupied, Y[Q q + p] = IDFT_nin_k( F[k] * W_nout^{kappa(k) p} )
+// with kappa the signed frequency of bin k -- Q independent nin-point IFFTs of
+// the same spectrum under a per-branch twiddle (the Nyquist bin, which the
+// reference places at both +nin/2 and -nin/2, gets the sum of both twiddles).
+// A workgroup walks a run of consecutive hops; the overlap-add tail (second
+// half of Y) never leaves registers: lane t produces q = t + T m in every hop,
+// m < 4 being the first half and m >= 4 the tail.
+// MemlessPoly polynomial (reference src/MemlessPoly.cpp:237-276) on one sample; shared by the
+// stand-alone kernel and the resampler's fused epilogue.
+struct PolyCoef { float a0, a1, a2, a3, a4, p0, p1, p2, p3, p4; };
+DEV cf poly_apply(cf x, const PolyCoef &c)
+{
+    const float m = x.x * x.x + x.y * x.y;
+    const float a = c.a0 + m * (c.a1 + m * (c.a2 + m * (c.a3 + m * c.a4)));
+    const float p = -1.0f * (c.p0 + m * (c.p1 + m * (c.p2 + m * (c.p3 + m * c.p4))));
+    const float q = p * p;
+    const float cr = (1.0f - q * (-0.5f + q * (0.486666f + q * (-0.00138888f))));
+    const float ci = p * (1.0f + q * (0.166666f + q * (0.00833333f)));
+    const float sr = x.x * a, si = x.y * a;
+    return mk(sr * cr - si * ci, sr * ci + si * cr);
+}
+// two samples at a time: every operation is a packed fp32 instruction (v_pk_fma_f32 / v_pk_mul_f32)
+DEV void poly_apply2(cf &s0, cf &s1, const PolyCoef &c)
+{
+    // (every multiply-add spelled as an explicit packed FMA: see pk_fma)
+    auto k = [](float v) __attribute__((always_inline)) { return make_float2(v, v); };
+    const float2 x = make_float2(s0.x, s1.x), y = make_float2(s0.y, s1.y);
+    const float2 m = pk_fma(x, x, y * y);
+    const float2 a = pk_fma(m, pk_fma(m, pk_fma(m, pk_fma(m, k(c.a4), k(c.a3)), k(c.a2)), k(c.a1)), k(c.a0));
+    const float2 p = pk_neg(pk_fma(m, pk_fma(m, pk_fma(m, pk_fma(m, k(c.p4), k(c.p3)), k(c.p2)), k(c.p1)), k(c.p0)));
+    const float2 q = p * p;
+    const float2 cr = pk_fma(pk_neg(q), pk_fma(q, pk_fma(q, k(-0.00138888f), k(0.486666f)), k(-0.5f)), k(1.0f));
+    const float2 ci = p * pk_fma(q, pk_fma(q, k(0.00833333f), k(0.166666f)), k(1.0f));
+    const float2 sr = x * a, si = y * a;
+    const float2 re = pk_fma(sr, cr, pk_neg(si * ci)), im = pk_fma(sr, ci, si * cr);
+    s0 = mk(re.x, im.x);
+    s1 = mk(re.y, im.y);
+}
+
+// S16: FormatConverter fused into the store (4-byte s16 pairs, clipped components counted into *a.clipped)
+template <int LOGNIN, int Q, bool POLY, bool S16 = false> __global__ __launch_bounds__((1 << LOGNIN) / 8)
+void resampler_kernel(const ResamplerArgs a, int hops_per_run)
+{
+    unsigned nclip = 0;
+    typedef Fft<LOGNIN> F;
+    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q, NOUT = NIN * Q;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    // two exchange buffers of 16-byte elements (packed dual transforms, one barrier per exchange)
+    c2 *fbuf2 = reinterpret_cast<c2 *>(smem);
+    cf *nyq = reinterpret_cast<cf *>(fbuf2 + 2 * F::LDS_ELEMS);   // [2]: Nyquist bin per hop parity
+    cf *tw8_l = nyq + 2;                                           // 7 x 8 twiddles of the stride-8 stage
+    // first half of the (symmetric) Hann window; w[i] = w[NIN-1-i] serves the second half
+    float *win = reinterpret_cast<float *>(tw8_l + 56);
+    int fpar = 0;
+    const int t = threadIdx.x;
+    const long h0 = (long)blockIdx.x * hops_per_run;
+    const long h1 = min((long)a.nhops, h0 + hops_per_run);
+    if (h0 >= (long)a.nhops) return;
+
+    cf tw[F::NTW];
+    F::template load_twiddles<true>(a.tw_in, t, tw);
+    F::fill_tw8(a.tw_in, tw8_l, t);
+#pragma unroll
+    for (int m = 0; m < 4; ++m) win[t + T * m] = a.window[t + T * m];
+    auto wnd = [&](int m) __attribute__((always_inline)) -> float {
+        return m < 4 ? win[t + T * m] : win[T * (7 - m) + (T - 1 - t)];
+    };
+    // per-branch twiddle of bin k = t + T m:  W_nout^{kappa p} = W_nout^{t p} * e^{2 pi i m p / (8Q)}
+    // (* (-i)^p for the negative-frequency half, kappa = k - NIN): one table value per branch
+    // and lane, the rest are compile-time rotations.
+    cf wp[Q];
+#pragma unroll
+    for (int p = 1; p < Q; ++p) wp[p] = a.tw_out[(t * p) & (NOUT - 1)];
+    PolyCoef pc{};
+    if (POLY) {
+        pc.a0 = a.poly[0]; pc.a1 = a.poly[1]; pc.a2 = a.poly[2]; pc.a3 = a.poly[3]; pc.a4 = a.poly[4];
+        pc.p0 = a.poly[8]; pc.p1 = a.poly[9]; pc.p2 = a.poly[10]; pc.p3 = a.poly[11]; pc.p4 = a.poly[12];
+    }
+    lds_barrier();
+
+    // S = [halo (2 hops) | in]; hop h uses S[(h+1)*HIN .. (h+3)*HIN)
+    auto fetch = [&](long h, cf *x) __attribute__((always_inline)) {
+        const long base = (h + 1) * HIN;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const long i = base + t + T * m;
+            x[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
+        }
+    };
+    // out_h = second_half(Y_{h-1}) + first_half(Y_h).  A shift by half the period is a sign
+    // flip of the odd bins, so out_h = first_half(IDFT_nout(stuff(G_h))) with
+    //     G_h[k] = F_h[k] + (-1)^k F_{h-1}[k]:
+    // the overlap-add happens on the nin-point spectra in registers ((-1)^k = (-1)^t for every
+    // bin of lane t) and no time-domain tail is carried from hop to hop.
+    // Transforms run two at a time as one packed dual IFFT (struct c2): the Q-1 branch IFFTs
+    // of hop h plus the FORWARD transform of hop h+1 (DFT(x) = conj(IDFT(conj(x)))).
+    const float sgn = (t & 1) ? -1.0f : 1.0f;
+    const float sc = (float)NIN * a.factor;
+    cf xn[8], G[8], Fc[8], b0[4];
+    {
+        // run prologue: F_{h0-1} and F_{h0} as one dual forward transform
+        cf xa[8];
+        fetch(h0 - 1, xa);
+        fetch(h0, xn);
+        c2 v2[8];
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float w = wnd(m);
+            v2[m] = c2{make_float2(xa[m].x * w, xn[m].x * w), make_float2(-xa[m].y * w, -xn[m].y * w)};
+        }
+#pragma unroll
+        for (int m = 0; m < 4; ++m) b0[m] = cscale(xn[m], (wnd(m) + wnd(m + 4)) * sc);
+        F::template run<+1, true, c2, true>(v2, fbuf2, fpar, tw, t, tw8_l);
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            Fc[m] = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
+            G[m] = mk(fmaf(sgn * a.factor, v2[m].re.x, Fc[m].x), fmaf(-sgn * a.factor, v2[m].im.x, Fc[m].y));
+        }
+    }
+    if (h0 + 1 < h1) fetch(h0 + 1, xn);
+
+    // branch twiddle of bin t + T m for branch p (see above); Nyquist bin gets both copies
+    auto branch_rot = [](int p, int m) __attribute__((always_inline)) -> cf {
+        const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (8 * Q)) / (double)(8 * Q)
+                           - (m >= 4 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
+        return mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
+    };
+    auto nyq_scale = [](int p) __attribute__((always_inline)) -> float {
+        return 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q);
+    };
+    auto branch_in = [&](int p, int m) __attribute__((always_inline)) -> cf {
+        // (G * wp) * rot, in this order: G changes every hop, so nothing is loop-invariant and
+        // the products cannot be hoisted into long-lived registers
+        cf y = cmul(cmul(G[m], wp[p]), branch_rot(p, m));
+        if (m == HIN / T && t == 0) y = cscale(G[m], nyq_scale(p));
+        return y;
+    };
+
+    for (long h = h0; h < h1; ++h) {
+        const int slot = (int)(h & 1);
+        // bin HIN lives in lane 0; every lane reads it back after the first transform of the
+        // hop (at least one barrier later; the slot is rewritten two hops later)
+        if (t == 0) nyq[slot] = G[HIN / T];
+        const bool more = h + 1 < h1;
+
+        cf o[4 * Q];                              // all Q branches of the lane's 4 output samples
+        // item a of pass i: branch 2i+1; item b: branch 2i+2, or (last pass) the forward transform of the next hop
+        auto build = [&](auto passc, c2 *v2) __attribute__((always_inline)) {
+            constexpr int pa = 2 * decltype(passc)::value + 1, pb = pa + 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                if (pb < Q) {
+                    // two branches: both twiddle products as packed fp32 operations
+                    const float2 wr = make_float2(wp[pa].x, wp[pb < Q ? pb : 0].x), wi = make_float2(wp[pa].y, wp[pb < Q ? pb : 0].y);
+                    const cf ra = branch_rot(pa, m), rb = branch_rot(pb, m);
+                    const float2 rr = make_float2(ra.x, rb.x), ri = make_float2(ra.y, rb.y);
+                    const float2 gx = make_float2(G[m].x, G[m].x), gy = make_float2(G[m].y, G[m].y);
+                    const float2 yr = pk_fma(gx, wr, pk_neg(gy * wi)), yi = pk_fma(gx, wi, gy * wr);
+                    v2[m] = c2{pk_fma(yr, rr, pk_neg(yi * ri)), pk_fma(yr, ri, yi * rr)};
+                    if (m == HIN / T && t == 0) {
+                        const float2 ny2 = make_float2(nyq_scale(pa), nyq_scale(pb));
+                        v2[m] = c2{G[m].x * ny2, G[m].y * ny2};
+                    }
+                    continue;
+                }
+                const cf xa = branch_in(pa, m);
+                cf xb;
+                {
+                    // conjugated windowed input of the next hop (zeros past the end of the run)
+                    const float w = more ? wnd(m) : 0.0f;
+                    xb = mk(xn[m].x * w, -xn[m].y * w);
+                }
+                v2[m] = c2{make_float2(xa.x, xb.x), make_float2(xa.y, xb.y)};
+            }
+        };
+        auto consume = [&](auto passc, const c2 *v2) __attribute__((always_inline)) {
+            constexpr int pa = 2 * decltype(passc)::value + 1, pb = pa + 1;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) o[m * Q + pa] = mk(v2[m].re.x, v2[m].im.x);
+            if (pb < Q) {
+#pragma unroll
+                for (int m = 0; m < 4; ++m) o[m * Q + (pb < Q ? pb : 0)] = mk(v2[m].re.y, v2[m].im.y);
+            } else {
+                // branch p = 0 needs no transform: IDFT(DFT(u)) = NIN u, i.e. the input samples
+                // under the sum of the two window halves (b0, prepared a hop ahead), plus the
+                // second copy of the Nyquist bin, G[NIN/2] e^{i pi q}  (q = t + T m, T even)
+                const cf ny = nyq[slot];
+#pragma unroll
+                for (int m = 0; m < 4; ++m) {
+                    o[m * Q] = mk(fmaf(sgn, ny.x, b0[m].x), fmaf(sgn, ny.y, b0[m].y));
+                    b0[m] = cscale(xn[m], (wnd(m) + wnd(m + 4)) * sc);
+                }
+                // item b = conj(F_{h+1}); the overlap-add with F_h gives the next hop's spectrum
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const cf fn = mk(v2[m].re.y * a.factor, -v2[m].im.y * a.factor);
+                    G[m] = mk(fmaf(sgn, Fc[m].x, fn.x), fmaf(sgn, Fc[m].y, fn.y));
+                    Fc[m] = fn;
+                }
+            }
+        };
+        {
+            c2 v2[8];
+            build(std::integral_constant<int, 0>{}, v2);
+            F::template run<+1, true, c2, true>(v2, fbuf2, fpar, tw, t, tw8_l);
+            consume(std::integral_constant<int, 0>{}, v2);
+            if constexpr (Q == 4) {
+                build(std::integral_constant<int, 1>{}, v2);
+                F::template run<+1, true, c2, true>(v2, fbuf2, fpar, tw, t, tw8_l);
+                consume(std::integral_constant<int, 1>{}, v2);
+            }
+        }
+        // the input after next is requested before this hop's stores (vmcnt retires in order) ...
+        // (only the NEW half: the window of hop h + 2 starts with the second half of hop h + 1's, and sample t + T m of
+        // the one is sample t + T (m + 4) of the other -- the same lane.  Every input sample is read once, not twice.)
+        if (h + 2 < h1) {
+            const long base = (h + 3) * HIN;
+#pragma unroll
+            for (int m = 0; m < 4; ++m) xn[m] = xn[m + 4];
+#pragma unroll
+            for (int m = 4; m < 8; ++m) {
+                const long i = base + t + T * m;
+                xn[m] = i < NIN ? a.halo[i] : a.in[i - NIN];
+            }
+        }
+        // ... and the Q branches of an output sample leave together: 8Q contiguous bytes per lane and
+        // slot, so HBM sees whole 32-byte sectors (16-byte pairs stored a transform apart cost 1.5x
+        // the write traffic)
+        cf *dst = a.out + (size_t)h * HOUT;
+        uint32_t *dst16 = reinterpret_cast<uint32_t *>(a.out) + (size_t)h * HOUT;
+#pragma unroll
+        for (int m = 0; m < 4; ++m) {
+            float4 *d4 = reinterpret_cast<float4 *>(dst + (size_t)Q * (t + T * m));
+            uint32_t w16[Q];
+#pragma unroll
+            for (int p = 0; p < Q; p += 2) {
+                cf a0 = o[m * Q + p], a1 = o[m * Q + p + 1];
+                if (POLY) poly_apply2(a0, a1, pc);
+                if (S16) { w16[p] = s16_pack(a0, nclip); w16[p + 1] = s16_pack(a1, nclip); }
+                else d4[p / 2] = make_float4(a0.x, a0.y, a1.x, a1.y);
+            }
+            if (S16) {
+                uint32_t *d = dst16 + (size_t)Q * (t + T * m);
+                if (Q == 4) *reinterpret_cast<uint4 *>(d) = make_uint4(w16[0], w16[1], w16[2 % Q], w16[3 % Q]);
+                else *reinterpret_cast<uint2 *>(d) = make_uint2(w16[0], w16[1]);
+            }
+        }
+    }
+    if (S16) s16_flush_count(nclip, a.clipped);
+}
+
+template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipStream_t s)
+{
+    constexpr int NIN = 1 << LOGNIN;
+    const int Q = a.nout / a.nin;
+    // runs of hops: every run starts with one dual forward transform (half a hop's work).  Long streams
+    // get runs of 96 hops (one Mode-I frame); short ones are cut finer so that the launch still covers the
+    // chip (>= 512 workgroups when there are that many pairs of hops) -- latency, not efficiency, counts there
+    int hpr = (int)std::max<size_t>(2, std::min<size_t>(96, a.nhops / 512));
+    const dim3 grid((unsigned)((a.nhops + hpr - 1) / hpr)), block(NIN / 8);
+    const size_t lds = 2 * (size_t)(NIN + NIN / 8) * 16 + (2 + 56) * sizeof(float2) + (size_t)(NIN / 2) * sizeof(float);
+    const bool poly = a.poly != nullptr;
+    switch (Q) {
+        case 2:
+            if (a.clipped) {
+                if constexpr (LOGNIN == 12) {
+                    if (poly) hipLaunchKernelGGL((resampler_kernel<12, 2, true, true>), grid, block, lds, s, a, hpr);
+                    else hipLaunchKernelGGL((resampler_kernel<12, 2, false, true>), grid, block, lds, s, a, hpr);
+                    break;
+                }
+                return hipErrorInvalidValue;
+            }
+            if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, true>), grid, block, lds, s, a, hpr);
+            else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
+            break;
+        case 4:
+            if (a.clipped) {
+                if constexpr (LOGNIN == 12) {
+                    if (poly) hipLaunchKernelGGL((resampler_kernel<12, 4, true, true>), grid, block, lds, s, a, hpr);
+                    else hipLaunchKernelGGL((resampler_kernel<12, 4, false, true>), grid, block, lds, s, a, hpr);
+                    break;
+                }
+                return hipErrorInvalidValue;
+            }
+            if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
+            else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
+            break;
+        default: return hipErrorInvalidValue;
+    }
+    return hipGetLastError();
+}
+
+}  // namespace
+
+// the kernels that store s16 themselves: x2 and x4 at nin = 4096 (Mode I)
+bool resampler_has_s16(const ResamplerArgs &a)
+{
+    return a.nin == 4096 && a.nout % a.nin == 0 && (a.nout / a.nin == 2 || a.nout / a.nin == 4);
+}
+
+hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s)
+{
+    if (a.nhops == 0) return hipSuccess;
+    if (a.clipped && !resampler_has_s16(a)) return hipErrorInvalidValue;
+    if (a.nout == a.nin || a.nout < 2 || (a.nout & 1)) return hipErrorInvalidValue;
+    const bool fast = a.nout % a.nin == 0 && (a.nout / a.nin == 2 || a.nout / a.nin == 4);
+    if (!fast && a.poly) return hipErrorInvalidValue;        // the general kernel has no fused predistorter
+    switch (a.nin) {
+        case 512: return fast ? launch_resampler_n<9>(a, s) : launch_resampler_rational_9(a, s);
+        case 1024: return fast ? launch_resampler_n<10>(a, s) : launch_resampler_rational_10(a, s);
+        case 2048: return fast ? launch_resampler_n<11>(a, s) : launch_resampler_rational_11(a, s);
+        case 4096: return fast ? launch_resampler_n<12>(a, s) : launch_resampler_rational_12(a, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace dabgpu

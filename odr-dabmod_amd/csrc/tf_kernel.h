@@ -1,0 +1,1116 @@
+// tf_kernel.h -- the frame kernel of the DAB COFDM hot path and its launcher template.
+//
+// tf_kernel: ONE launch takes the coded bits of a batch
+// of transmission frames and produces the finished I/Q stream, i.e. the
+// reference's QpskSymbolMapper -> FrequencyInterleaver -> DifferentialModulator
+// -> SignalMultiplexer -> OfdmGenerator -> GainControl -> GuardIntervalInserter
+// -> FIRFilter sub-graph (src/DabModulator.cpp:385-419) with no intermediate in
+// HBM.  A workgroup owns a run of consecutive OFDM symbols of one frame:
+//   * the differential-modulation state lives in registers as integer phases (six 4-bit fields of one
+//     register per lane); each lane's six carriers are exactly its inputs of the first FFT stage, so
+//     nothing is scattered through LDS;
+//   * the N-point backward FFT is a Stockham radix-8 autosort (8 . 8 . 8 . 4 for N = 2048), 8 points
+//     per lane, three exchanges through one padded LDS buffer (row layout for the first, additive
+//     padding for the stride-8 one; every access is base + immediate), twiddles in registers / a small
+//     LDS table;
+//   * gain statistics come from the SPECTRUM (population variance through Parseval on carrier pairs),
+//     counted with ballots; modes max / fix reduce over the FFT output with DPP;
+//   * the cyclic prefix is a second store of the same registers;
+//   * the FIR is spectral: inside a symbol it is the factor H[k] on the carriers.  Mode I coded-bits chain with the
+//     45-tap filter (EQ): ONE transform per symbol, of X H; the 44 outputs per symbol boundary that the cyclic
+//     filtering gets wrong are corrected from the filtered symbols alone through a host-designed inverse of the
+//     taps on the occupied carriers.  Every other FIR variant: the unfiltered and the filtered IFFT of a symbol as
+//     ONE packed dual transform (struct c2), the unfiltered half pruned to the 88 samples the boundary FIR reads
+//     (Fft::run_dual_zonly), those boundary outputs a direct FIR;
+//   * OFDM windowing (WIN): the raised-cosine seams between symbols through LDS; with FIR as well, the windowed stream
+//     around every seam is built in LDS and the outputs that look into it are a direct FIR (packed dual transform).
+// HBM traffic is therefore the compulsory 28.8 kB in + 1.57 MB out per frame.
+//
+// No MFMA (no dense contraction in this path), wave64 throughout.
+#pragma once
+#include "device_common.h"
+#include "tf_layout.h"
+
+namespace dabgpu {
+namespace {
+
+// ---------------------------------------------------------------------------
+// cos/sin of p*45deg as {-1,0,+1} codes: (CX >> 2p) & 3 = value + 1
+constexpr unsigned kCX = 0x901Au;
+
+// FIR inside the fused kernel ("spectral FIR").
+// The stream is a chain of cyclically extended symbols, and the FIR looks AHEAD
+// (out[n] = sum_j taps[j] in[n+j]), so every output whose ntaps-1 look-ahead
+// samples stay inside its own segment is a CIRCULAR convolution of the symbol:
+//     out[p] = g_s * IDFT_N( X_s[k] * H[k] )[(p - cp) mod N],  H[k] = sum_j taps[j] e^{+2 pi i jk/N}
+// i.e. a second IFFT of the same carriers under a per-bin factor.  Only the last
+// C = ntaps-1 samples of a segment see the next symbol; those 44 outputs are
+// computed directly from the C-sample tail of this symbol and the C-sample head
+// of the next one (unfiltered, gain applied), kept in LDS.  Cost per symbol:
+// 2 FFTs + C*ntaps MACs instead of 1 FFT + N*ntaps MACs.
+
+// The transmission-mode geometry is a function of the FFT size (reference
+// src/DabModulator.cpp:84-122), so it is compile-time here; NT is the number of FIR taps
+// when known at compile time (the default 45-tap filter) or 0 for "read it from the args".
+template <int LOGN> struct ModeGeom;
+template <> struct ModeGeom<11> { static constexpr int nb_symbols = 76, K = 1536, null_size = 2656, sym_size = 2552; };
+template <> struct ModeGeom<9> { static constexpr int nb_symbols = 76, K = 384, null_size = 664, sym_size = 638; };
+template <> struct ModeGeom<8> { static constexpr int nb_symbols = 153, K = 192, null_size = 345, sym_size = 319; };
+template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768, null_size = 1328, sym_size = 1276; };
+
+// CFR (f-3; either with the whole fused epilogue GUARD + FIR or with neither: then the chain continues with the stand-alone guard and FIR
+// kernels): crest-factor reduction of every symbol right after its IFFT, in registers -- clip, forward
+// FFT, error clip against the lane's own input bins, IFFT again -- plus the reference's statistics.
+// GVAR (carriers path with GAIN only): the gain mode is known to be "var" -- the statistics come from
+// the spectrum and the time-domain reduction (which keeps both transforms of a symbol live and costs
+// the third workgroup per CU) is compiled out.
+// ZONLY (Mode I with the fused FIR and no gain statistics over the time domain: the coded-bits path with gain fix / var,
+// the carriers path with gain var or none): the unfiltered transform is formed only where
+// the boundary FIR reads it (Fft::run_dual_zonly).
+// OFMT = 1: the output is s16 (4 bytes per sample, FormatConverter semantics) instead of cf32 -- instantiated for the
+// production variants only (Mode I coded-bits chain, default filter); everything else converts in format_kernel.
+// WIN (coded-bits chain with guard interval, no FIR): the guard interval is windowed (ofdmwindowing > 0, f-4,
+// src/GuardIntervalInserter.cpp:149-300).  Every sample outside the 2W-wide seams is the copy it is without a window;
+// seam sample j between symbols s-1 and s is  prev[j] * w[2W-1-j] + rise[j] * w[j], with prev = the last W samples of
+// symbol s-1 followed by its first W (the suffix written past its end) and rise = samples [N-cp-W, N-cp+W) of symbol
+// s.  The 2W + 2W samples go through LDS; the seam before a run's first symbol is written by the run before it,
+// which transforms that symbol too (look-ahead, as with the FIR).
+// EQ (Mode I coded-bits chain with the 45-tap FIR, gain none / fix / var -- the cfg 3 chain): ONE transform per symbol,
+// of the FILTERED spectrum X H, instead of the packed (unfiltered, filtered) pair.  The 44 outputs between two symbols
+// that the cyclic filtering gets wrong are corrected from the filtered symbols alone:
+//     y[N-44+i] = z_prev[N-44+i] + sum_{j >= 44-i} taps[j] d[i+j-44],   d[m] = x_cur[N-cp+m] - x_prev[m]
+// (the cyclic result looked into x_prev's own start where the stream continues with x_cur's prefix), and the
+// unfiltered difference d comes out of a short inverse filter g of the taps (G H = 1 on the occupied bins -- the only
+// ones a symbol has energy in; designed on the host, dabgpu_api.hip design_inverse_filter):
+//     d[m] = sum_j g[j] w[m - (j - c)],   w[q] = z_cur[N-cp+q] - z_prev[q mod N],   q in [-103, 99].
+// 44 x 160 + 990 real-by-complex multiply-adds per symbol replace half of a packed 2048-point transform, its 16-byte
+// exchanges and the pack / unpack around it.
+template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
+          bool ZONLY = false, int OFMT = 0, bool WIN = false, bool EQ = false>
+// Waves per SIMD asked of the register allocator: EQ 4 (128 VGPRs, 28 KB of LDS: four workgroups per CU); CFR 2; no
+// FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
+// 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
+__global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
+                             EQ ? 4 : CFR ? 2 : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+void tf_kernel(const TfArgs a)
+{
+    static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
+    static_assert(!CFR || (GUARD == FIR), "CFR variants: the full fused epilogue, or none of it");
+    static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR),
+                  "ZONLY: the dual transform of the Mode I chain with the fused FIR");
+    static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
+    static_assert(!WIN || (FROM_BITS && GUARD && !CFR && OFMT == 0), "WIN: coded-bits chain with guard interval");
+    static_assert(!(WIN && FIR) || (!ZONLY && !EQ && NT == 0 && !GVAR),
+                  "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count");
+    static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY && !WIN),
+                  "EQ: the Mode I coded-bits chain with the 45-tap filter");
+    typedef ModeGeom<LOGN> G;
+    typedef Fft<LOGN> F;
+    constexpr int N = F::N, T = F::T;
+    // exchange buffers: the variants without FIR alternate between two (one barrier per exchange); the FIR variants
+    // keep one (two barriers per exchange) -- 36 KB of LDS per workgroup and three workgroups per CU, EQ 28 KB and four
+    constexpr bool DBUF = !FIR;
+    const int t = threadIdx.x;
+    const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
+    const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
+    const int tt = lane_on ? t : 0;
+
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
+    int fpar = 0;                                                       // which half the next exchange uses
+    // packed dual transforms (FIR variants other than EQ) exchange 16-byte elements
+    constexpr int kXElems = (FIR && !EQ) ? 2 * F::LDS_ELEMS : (DBUF ? 2 : 1) * F::LDS_ELEMS;
+    double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
+    // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
+    // that the boundary outputs read in[i + j] without a tail/head case split
+    // frequency-domain gain statistics (coded-bits path): one packed word of phases per lane
+    uint32_t *phw = reinterpret_cast<uint32_t *>(red + 16);          // [T]
+    // (carriers path: three complex bins per lane instead -- the general form of the same statistic)
+    cf *bnd = reinterpret_cast<cf *>(phw + (GAIN ? (FROM_BITS ? T : 6 * T) : 0));
+    // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
+    constexpr int KB = NT ? NT - 1 : kBnd;      // slots per half buffer: the look-ahead C when it is a compile-time constant
+    // WIN: two seam buffers [last W | first W samples of a symbol], the rising 2W samples of the next one, the window
+    cf *wbuf = bnd;
+    float *win_l = reinterpret_cast<float *>(wbuf + 6 * kWinMax);     // (WIN with FIR: moved behind the other tables below)
+    // EQ: two windows of the previous filtered symbol (index q + kEqQL, q in [-kEqQL, kEqQH]), the difference w, the
+    // 44 unfiltered differences d, the inverse filter
+    // (kEqW: the tail past kEqQL + kEqQH stays zero)
+    constexpr int kEqQL = kEqTaps - 1 - kEqCentre, kEqQH = 43 + kEqCentre, kEqW = 208;
+    static_assert(kEqQL + kEqQH + 1 <= kEqW && kEqTaps == 160, "EQ window");
+    static_assert(kEqElems == 3 * kEqW + 48 + (kEqTaps + 8) / 2, "LDS share of the EQ variant (tf_lds_bytes)");
+    cf *eq_zp = bnd, *eq_w = bnd + 2 * kEqW, *eq_d = eq_w + kEqW;
+    float *g_l = reinterpret_cast<float *>(eq_d + 48);
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : (FIR && !WIN) ? 4 * KB : ((WIN && !FIR) ? 7 * kWinMax : 0)));
+    constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
+    constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
+    // small read-only tables copied to LDS once: read through global memory they compile to
+    // vector loads (the output stores may alias them), and every such load drags an
+    // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
+    float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
+    constexpr int kTapsL = kMaxTaps, kMagL = 160;
+    float *mag_l = taps_l + kTapsL;
+    // exp(i p pi/4) with exact 0 / +-1 entries, in 8 rotated copies: entry [rot * 8 + p] = exp(i (p + rot) pi/4).
+    // The coded-bits path keeps its differential phases without the common "+1 eighth per symbol" term and
+    // unreduced (see advance); the rotation is the symbol's share, picked through the table's base address.
+    cf *unit8 = reinterpret_cast<cf *>(mag_l + kMagL);
+    cf *tw8_l = unit8 + 64;                             // 7 x 8 twiddles of the stride-8 stage (Fft::fill_tw8)
+    F::fill_tw8(a.t.twiddle, tw8_l, t);
+    // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
+    float *cfr_red = reinterpret_cast<float *>(tw8_l + 56);
+    if (t < 64) {
+        const unsigned p = ((unsigned)t + ((unsigned)t >> 3)) & 7u;
+        const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
+        const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
+        unit8[t] = mk(cx, cy);
+    }
+    for (int i = t; i < kTapsL; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
+    if (EQ)
+        for (int i = t; i < kEqTaps + 8; i += blockDim.x) g_l[i] = i < kEqTaps ? a.t.eq_g[i] : 0.f;
+    if (EQ) {
+        for (int i = t; i < 3 * kEqW; i += blockDim.x) eq_zp[i] = mk(0.f, 0.f);     // (both windows, w: the tails stay zero)
+    }
+    const int W = WIN ? a.overlap : 0;
+    // WIN with FIR: behind everything else, sized at run time (C = ntaps - 1): two stashes of a symbol's
+    // [x[N-W-C .. N) | x[0 .. W)] (C + 2W each), the next symbol's x[N-cp-W .. N-cp+W+C) (2W + C), the windowed stream
+    // U around the seam (2W + 2C), the window
+    const int wfC = (WIN && FIR) ? a.ntaps - 1 : 0, wfLP = wfC + 2 * W;
+    cf *wfb = tw8_l + 56;
+    cf *wf_cur = wfb + 2 * wfLP, *wf_U = wf_cur + (2 * W + wfC);
+    if (WIN && FIR) win_l = reinterpret_cast<float *>(wf_U + (2 * W + 2 * wfC));
+    if (WIN)
+        for (int i = t; i < 2 * W; i += blockDim.x) win_l[i] = a.t.window[i];
+    if (FROM_BITS)
+        for (int i = t; i < G::nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
+    lds_barrier();
+
+    constexpr int K = G::K, nsym = G::nb_symbols + 1;
+    const int frame = blockIdx.x / a.chunks_per_frame;
+    const int chunk = blockIdx.x - frame * a.chunks_per_frame;
+    const int s_begin = chunk * a.syms_per_chunk;
+    const int s_end = min(nsym, s_begin + a.syms_per_chunk);
+    if (frame >= a.n_frames || s_begin >= nsym) return;
+
+    const int ntaps = NT ? NT : a.ntaps;
+    const int C = FIR ? ntaps - 1 : 0;  // FIR look-ahead
+    constexpr int cp0 = GUARD ? G::null_size - N : 0, cp = GUARD ? G::sym_size - N : 0;
+    constexpr int len0 = N + cp0, len = N + cp;
+
+    // ---- per-lane constants ------------------------------------------------
+    cf tw[F::NTW > 0 ? F::NTW : 1];
+    F::template load_twiddles<true>(a.t.twiddle, tt, tw);
+
+    // the lane's 6 active first-stage inputs: r = {0|3,1,2,5,6,7}; bin = t + T*r
+    // interleaved position k: bins 1..K/2 -> k = bin-1 ; bins N-K/2.. -> k = bin-N+K
+    const int r0 = (tt == 0) ? 3 : 0;
+    int kpos[6];
+    cf hk[6];
+    cf hk8[CFR && FIR ? 8 : 1];      // CFR: the corrected spectrum is dense, all eight bins of the lane are filtered
+    {
+        const int rr[6] = {r0, 1, 2, 5, 6, 7};
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int bin = tt + T * rr[c];
+            kpos[c] = (bin <= K / 2) ? bin - 1 : bin - N + K;
+            if (FIR) hk[c] = a.t.fir_h[bin];
+        }
+    }
+    if (CFR && FIR) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) hk8[m] = a.t.fir_h[tt + T * m];
+    }
+    int bitpos[6];
+    // differential state of the lane's carriers, without the
+    // "+1 eighth" every data block adds to every carrier: phase of symbol s = 2 q_c + s - 1 eighths.
+    // Kept as six 4-bit fields of ONE register, in quarter turns (every increment is an even number of eighths): the
+    // block update and the pair sums of the gain statistic work on all fields at once.  Field of carrier c at bit
+    // fpos[c]: the positive carriers 0, 1, 2 at bits 0, 4, 8; the negative ones so that bits 12.. read (-k0, -k1, -k2)
+    // in the lane that holds them -- carriers (5, 4, 3) at bits (12, 16, 20), lane 0 (which pairs with itself and has
+    // bin 3T in slot 0): carriers (3, 5, 4).
+    unsigned P = 0u;
+    unsigned fpos[6] = {0u, 4u, 8u, tt == 0 ? 12u : 20u, tt == 0 ? 20u : 16u, tt == 0 ? 16u : 12u};
+    const uint8_t *fbits = nullptr;
+    if (FROM_BITS) {
+        fbits = a.bits + (size_t)frame * (size_t)(G::nb_symbols - 1) * (size_t)(K / 4);
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            bitpos[c] = a.t.src_carrier[kpos[c]];
+            P |= ((unsigned)a.t.phase_q[kpos[c]] & 3u) << fpos[c];
+        }
+    }
+    const cf *fcar = FROM_BITS ? nullptr
+                               : a.carriers + (size_t)frame * (size_t)nsym * (size_t)K;
+    // The frame's output through a buffer resource: every store is "scalar base + scalar offset + 32-bit lane offset"
+    // (buffer_store ... offen).  Flat 64-bit addresses cost a register pair and a 64-bit add per store, and were
+    // what the register allocator spilled first.  soff: wave-uniform sample index inside the frame (>= 0), voff: the
+    // lane's; out-of-range lanes are exec-masked by the callers (the hardware would drop them as well).
+    constexpr int kOutBytes = OFMT == 1 ? 4 : 8;
+    const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<char *>(a.out) + (size_t)frame * a.out_stride * kOutBytes, 0, (int)(a.out_stride * kOutBytes), 0x00020000);
+    unsigned nclip = 0;
+    typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    auto put = [&](int soff, int voff, cf y) __attribute__((always_inline)) {
+        if (OFMT == 1) {
+            __builtin_amdgcn_raw_buffer_store_b32(s16_pack(y, nclip), orsrc, voff * 4, soff * 4, 0);
+        } else {
+            const v2u_ d = {__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.y)};
+            __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, voff * 8, soff * 8, 0);
+        }
+    };
+
+    // advance the differential state over one data block (K/4 bytes: I bits, then Q bits)
+    // held in LDS or in global memory; the 12 byte reads are issued together
+    auto advance = [&](const uint8_t *blk) __attribute__((always_inline)) {
+        unsigned ib[6], qb[6];
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const int bp = bitpos[c];
+            ib[c] = blk[bp >> 3];
+            qb[c] = blk[(K >> 3) + (bp >> 3)];
+        }
+        unsigned I = 0u, Q = 0u;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) {
+            const unsigned sh = 7u - ((unsigned)bitpos[c] & 7u);
+            I |= __builtin_amdgcn_ubfe(ib[c], sh, 1u) << fpos[c];
+            Q |= __builtin_amdgcn_ubfe(qb[c], sh, 1u) << fpos[c];
+        }
+        // (I, Q) = 00 -> 0, 10 -> 1, 11 -> 2, 01 -> 3 quarter turns, in every field at once; the guard bits absorb the carry
+        P = (P + ((I ^ Q) | (Q << 1))) & 0x333333u;
+    };
+    // global -> register half of the staging of block d: lanes 0 .. K/16-1 fetch one dword
+    // each.  Kept free of divergent control flow on purpose (the other lanes re-read word 0
+    // and later park it in a dummy LDS slot): a load or its wait inside an exec-masked
+    // branch makes the compiler re-wait vmcnt(0) -- i.e. for the previous symbol's stores --
+    // at the top of the next iteration.
+    auto fetch_block = [&](int d) __attribute__((always_inline)) -> uint32_t {
+        const int dd = min(max(d, 0), G::nb_symbols - 2);
+        return reinterpret_cast<const uint32_t *>(fbits + (size_t)dd * (size_t)(K / 4))[t < kBitWords ? t : 0];
+    };
+    const int bit_slot = t < kBitWords ? t : kBitWords;   // kBitWords = dummy slot
+
+    // the lane's 6 active carriers of symbol s
+    auto load_active = [&](int s, cf *val) __attribute__((always_inline)) {
+        if (FROM_BITS) {
+            const float mg = s >= 1 ? mag_l[s - 1] : 0.f;
+#pragma unroll
+            for (int c = 0; c < 6; ++c) {
+                const unsigned rot64 = ((unsigned)(s - 1) & 7u) << 6;        // (byte offset of the rotated copy)
+                const cf u = *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) +
+                                                          ((__builtin_amdgcn_ubfe(P, fpos[c], 2u) << 4) | rot64));
+                val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
+            }
+        } else {
+            // position of bin tt + T r: r <= 3 -> bin - 1 (positive carriers first), r >= 5 -> bin - N + K.
+            // Spelled out as lane + constant so that the six loads share one address register.
+            const cf *sym = fcar + (size_t)min(s, nsym - 1) * (size_t)K + tt;
+            val[0] = sym[(tt == 0 ? 3 * T : 0) - 1];
+            val[1] = sym[T - 1];
+            val[2] = sym[2 * T - 1];
+            val[3] = sym[5 * T - N + K];
+            val[4] = sym[6 * T - N + K];
+            val[5] = sym[7 * T - N + K];
+        }
+    };
+    // scatter them into the first-stage register layout
+    const float m_r0 = r0 == 0 ? 1.0f : 0.0f, m_r3 = 1.0f - m_r0;       // (two multiplies are two packed instructions
+    auto place = [&](const cf *val, cf *v) __attribute__((always_inline)) {   //  per pair; two selects are four)
+        v[0] = cscale(val[0], m_r0);
+        v[3] = cscale(val[0], m_r3);
+        v[4] = mk(0.f, 0.f);
+        v[1] = val[1]; v[2] = val[2]; v[5] = val[3]; v[6] = val[4]; v[7] = val[5];
+    };
+
+    if (FROM_BITS) {
+        // the loop below applies block s-2 on entering symbol s; bring the state to
+        // "blocks 0 .. s_begin-3 applied"
+        // A chunk that starts deep inside the frame replays up to 74 blocks here.  Gathering their bits straight from
+        // global memory costs 12 scattered byte loads per lane and block -- 3500 load instructions per workgroup whose
+        // 64 lanes each touch their own byte: 27 of the 35 us of a one-frame launch went into the texture addresser.
+        // So the blocks are copied to LDS first (coalesced dwords into the exchange buffer, which is idle until the
+        // first transform) and the bytes are gathered from there, in slabs of as many blocks as the buffer holds.
+        {
+            const int nblk = s_begin - 2;                        // blocks 0 .. s_begin - 3
+            uint32_t *stage = reinterpret_cast<uint32_t *>(fbuf);
+            constexpr int kBlkWords = K / 16;                    // K / 4 bytes per block
+            constexpr int kSlab = (kXElems * (int)sizeof(cf)) / (kBlkWords * 4);
+            static_assert(kSlab >= 1, "the exchange buffer holds at least one block");
+            for (int d0 = 0; d0 < nblk; d0 += kSlab) {
+                const int nb = min(kSlab, nblk - d0);
+                const uint32_t *src = reinterpret_cast<const uint32_t *>(fbits + (size_t)d0 * (size_t)(K / 4));
+                for (int i = t; i < nb * kBlkWords; i += (int)blockDim.x) stage[i] = src[i];
+                lds_barrier_vm();
+                for (int j = 0; j < nb; ++j) advance(reinterpret_cast<const uint8_t *>(stage + j * kBlkWords));
+                lds_barrier();                                   // the slab is consumed (next slab / first exchange)
+            }
+        }
+        // stage the block of the first symbol (block s_begin-2) into bitbuf[0]
+        bitbuf[bit_slot] = fetch_block(s_begin - 2);   // (clamped; unused when the loop starts at s <= 1)
+    }
+
+    // f-3 crest-factor reduction of one symbol held 8 samples per lane (reference
+    // src/OfdmGenerator.cpp:222-277 and cfr_one_iteration :310-373).  v: IFFT output in, CFR output
+    // out; refv: the lane's 8 input bins (a forward transform returns every bin to the lane it came
+    // from, so the error is formed in place).  stats: also the side statistics of symbol s.
+    auto cfr_symbol = [&](cf *v, cf *zf, const cf *refv, int s, bool stats) __attribute__((always_inline)) {
+        const float clip2 = a.cfr_clip * a.cfr_clip, eclip2 = a.cfr_errclip * a.cfr_errclip;   // :315, :339
+        const bool mer_sym = stats && s > 0 && s == (a.cfr_mer_base + frame) % nsym;             // :198, :250
+        constexpr int NW = (T + 63) / 64;
+        cf before[8];
+        float pk = 0.f, sm = 0.f;
+        unsigned nclip = 0, neclip = 0;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
+            pk = fmaxf(pk, mag2);
+            sm += mag2;
+            before[m] = v[m];
+            if (mag2 > clip2) {                                   // :320-330
+                const float f = sqrtf(clip2 / mag2);
+                v[m] = cscale(v[m], f);
+                ++nclip;
+            }
+        }
+        if (stats) {
+            // PAPRStats::process_block before CFR (src/PAPRStats.cpp:41-60): per-wave partials now,
+            // combined by lane 0 behind the forward transform's barriers
+            pk = wave_max_dpp(lane_on ? pk : 0.f);
+            sm = wave_sum_dpp(lane_on ? sm : 0.f);
+            if ((t & 63) == 0) { cfr_red[2 * (t >> 6)] = pk; cfr_red[2 * (t >> 6) + 1] = sm; }
+        }
+        F::template run<-1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
+        if (stats && t == 0) {
+            float p = 0.f;
+            double q = 0.;
+#pragma unroll
+            for (int w = 0; w < NW; ++w) { p = fmaxf(p, cfr_red[2 * w]); q += (double)cfr_red[2 * w + 1]; }
+            double *pp = a.cfr_papr + ((size_t)frame * nsym + s) * 4;
+            pp[0] = (double)p;
+            pp[1] = q / (double)N;
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const cf c = cscale(v[m], 1.0f / (float)N);         // :349-350 (a power of two: exact)
+            cf e = csub(refv[m], c);
+            const float mag2 = e.x * e.x + e.y * e.y;
+            if (mag2 > eclip2) {                                  // :357-360
+                e = cscale(e, sqrtf(eclip2 / mag2));
+                ++neclip;
+            }
+            v[m] = cadd(c, e);
+        }
+        if (FIR) {
+            // the corrected spectrum and its filtered copy go back to the time domain as one packed transform;
+            // zf receives the filtered symbol
+            c2 v2[8];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const cf f = cmul(v[m], hk8[CFR && FIR ? m : 0]);
+                v2[m] = c2{make_float2(v[m].x, f.x), make_float2(v[m].y, f.y)};
+            }
+            F::template run<+1, DBUF, c2, true>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                v[m] = mk(v2[m].re.x, v2[m].im.x);
+                zf[m] = mk(v2[m].re.y, v2[m].im.y);
+            }
+        } else {
+            F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
+        }
+        if (stats) {
+            unsigned n1 = lane_on ? nclip : 0u, n2 = lane_on ? neclip : 0u;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { n1 += __shfl_xor(n1, o, 64); n2 += __shfl_xor(n2, o, 64); }
+            if ((t & 63) == 0) {
+                if (n1) atomicAdd(a.cfr_counts + 2 * (size_t)frame, n1);
+                if (n2) atomicAdd(a.cfr_counts + 2 * (size_t)frame + 1, n2);
+            }
+            if (s > 0) {                                          // :246-248: symbol 0 is skipped
+                float pk2 = 0.f, sm2 = 0.f, siq = 0.f, sdl = 0.f;
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
+                    pk2 = fmaxf(pk2, mag2);
+                    sm2 += mag2;
+                    const cf d = csub(v[m], before[m]);
+                    siq += before[m].x * before[m].x + before[m].y * before[m].y;
+                    sdl += d.x * d.x + d.y * d.y;
+                }
+                pk2 = wave_max_dpp(lane_on ? pk2 : 0.f);
+                sm2 = wave_sum_dpp(lane_on ? sm2 : 0.f);
+                siq = wave_sum_dpp(lane_on ? siq : 0.f);
+                sdl = wave_sum_dpp(lane_on ? sdl : 0.f);
+                float *r2 = cfr_red + 2 * NW;
+                if ((t & 63) == 0) {
+                    r2[4 * (t >> 6)] = pk2; r2[4 * (t >> 6) + 1] = sm2;
+                    r2[4 * (t >> 6) + 2] = siq; r2[4 * (t >> 6) + 3] = sdl;
+                }
+                lds_barrier();
+                if (t == 0) {
+                    float p = 0.f;
+                    double q = 0., iq = 0., dl = 0.;
+#pragma unroll
+                    for (int w = 0; w < NW; ++w) {
+                        p = fmaxf(p, r2[4 * w]);
+                        q += (double)r2[4 * w + 1];
+                        iq += (double)r2[4 * w + 2];
+                        dl += (double)r2[4 * w + 3];
+                    }
+                    double *pp = a.cfr_papr + ((size_t)frame * nsym + s) * 4;
+                    pp[2] = (double)p;
+                    pp[3] = q / (double)N;
+                    if (mer_sym) {                                // :250-273
+                        a.cfr_mer[2 * (size_t)frame] = iq;
+                        a.cfr_mer[2 * (size_t)frame + 1] = dl;
+                    }
+                }
+            }
+        }
+    };
+
+    // Carriers path, gain mode var: the statistic of the coded-bits path for arbitrary carriers
+    // (zero DC bin, so zero mean):
+    //   var(re) = (P + Re Q) / 2,  var(im) = (P - Re Q) / 2,
+    //   P = sum_k |X[k]|^2,  Q = sum_k X[k] X[-k] = 2 sum over pairs {k, -k}.
+    // Bin -k of the lane's three positive bins lives in lane T - t: exchange three values, leave the
+    // per-wave partial sums in redf (combined by spectral_gain after at least one more barrier).
+    auto spectral_partial = [&](const cf *val, float *redf) __attribute__((always_inline)) {
+        cf *pw = reinterpret_cast<cf *>(phw);
+        lds_barrier();                         // the previous symbol's partner reads are done
+        pw[tt] = (tt == 0) ? val[3] : val[5];
+        pw[T + tt] = (tt == 0) ? val[5] : val[4];
+        pw[2 * T + tt] = (tt == 0) ? val[4] : val[3];
+        lds_barrier();
+        const int o = (T - tt) & (T - 1);
+        const cf oa = pw[o], ob = pw[T + o], oc = pw[2 * T + o];
+        float q = (val[0].x * oa.x - val[0].y * oa.y) + (val[1].x * ob.x - val[1].y * ob.y) +
+                  (val[2].x * oc.x - val[2].y * oc.y);
+        float pwr = 0.f;
+#pragma unroll
+        for (int c = 0; c < 6; ++c) pwr += val[c].x * val[c].x + val[c].y * val[c].y;
+        q = wave_sum_dpp(lane_on ? 2.0f * q : 0.f);
+        pwr = wave_sum_dpp(lane_on ? pwr : 0.f);
+        if ((t & 63) == 0) { redf[2 * (t >> 6)] = pwr; redf[2 * (t >> 6) + 1] = q; }
+    };
+    auto spectral_gain = [&](const float *redf) __attribute__((always_inline)) -> float {
+        float P = 0.f, Q = 0.f;
+#pragma unroll
+        for (int w = 0; w < (T + 63) / 64; ++w) { P += redf[2 * w]; Q += redf[2 * w + 1]; }
+        const float vr = fast_sqrt(fmaxf(0.5f * (P + Q), 0.f)) * a.gain.var_variance;
+        const float vi = fast_sqrt(fmaxf(0.5f * (P - Q), 0.f)) * a.gain.var_variance;
+        return ((int)vr == 0) ? 1.0f : 32767.0f * fast_rcp(fmaxf(vr, vi));
+    };
+
+    // gain of the NULL symbol = gain computed on symbol 1 (reference
+    // src/GainControl.cpp:139-144); only matters when symbol 0 is not blank.
+    float g_null = 1.0f;
+    if (GVAR && s_begin == 0) {
+        cf val[6];
+        load_active(1, val);
+        float *redf = reinterpret_cast<float *>(red + 8);
+        spectral_partial(val, redf);
+        lds_barrier();
+        g_null = spectral_gain(redf);
+    } else if (GAIN && !FROM_BITS && s_begin == 0) {
+        cf val[6], v[8];
+        load_active(1, val);
+        place(val, v);
+        F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
+        if (CFR) {
+            cf refv[8], zdummy[8];
+            place(val, refv);
+            cfr_symbol(v, zdummy, refv, 1, false);
+        }
+        g_null = symbol_gain_fused<T>(v, a.gain, red + 8, tt, lane_on);
+    }
+
+    // With FIR the symbol after the chunk is transformed too (first IFFT only) to
+    // obtain the head that the chunk's last boundary outputs look into.
+    const int s_stop = ((FIR || WIN) && s_end < nsym) ? s_end + 1 : s_end;
+    int cur = 0;               // which tail buffer holds the previous symbol's tail
+    int prev_pos = 0;          // stream position of the previous segment
+    int prev_seg = 0;
+    bool have_prev = false;
+
+    // boundary outputs of the previous segment: 4 lanes per output, shuffle-reduced
+    constexpr int kThreads = T < 64 ? 64 : T;      // == blockDim.x (a compile-time constant keeps it out of the loop)
+    auto boundary = [&](const cf *src) __attribute__((always_inline)) {
+        // src = [tail (C) | head (C)]; output i of the C boundary outputs = sum_j taps[j] src[i + j].
+        // Four lanes (one DPP quad) share an output, lane q taking taps q, q+4, ...
+        for (int i0 = 0; i0 < C; i0 += kThreads / 4) {
+            const int i = i0 + (t >> 2), q = t & 3;
+            const int ii = i < C ? i : 0;
+            cf acc = mk(0.f, 0.f);
+            if (NT > 0) {
+                // tap count known: all reads of a lane at base + immediate, issued together and waited for
+                // once (the rolled loop below pays one LDS round trip per tap).  The last group of four
+                // runs past the filter for q > 0: the zero padding of the tap table cancels it, and its
+                // sample read is redirected to an address inside the buffer.
+                constexpr int KT = NT > 0 ? (NT + 3) / 4 : 1, REM = NT - 4 * (KT - 1);    // lanes q < REM own a tap in the last group
+                const cf *sp = src + ii + q;
+                const float *tq = taps_l + q;
+                cf x[KT];
+                float tp[KT];
+#pragma unroll
+                for (int k = 0; k < KT - 1; ++k) { x[k] = sp[4 * k]; tp[k] = tq[4 * k]; }
+                x[KT - 1] = (REM == 4 || q < REM) ? sp[4 * (KT - 1)] : sp[0];
+                tp[KT - 1] = tq[4 * (KT - 1)];
+#pragma unroll
+                for (int k = 0; k < KT; ++k) {
+                    acc.x = fmaf(x[k].x, tp[k], acc.x);
+                    acc.y = fmaf(x[k].y, tp[k], acc.y);
+                }
+            } else {
+                // (rolled or lightly unrolled: fully unrolling its iterations pushes the kernel into spilling)
+#pragma unroll 1
+                for (int j = q; j < ntaps; j += 4) {
+                    const cf x = src[ii + j];
+                    const float tp = taps_l[j];
+                    acc.x = fmaf(x.x, tp, acc.x);
+                    acc.y = fmaf(x.y, tp, acc.y);
+                }
+            }
+            acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);   // the 4 lanes of an output
+            acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);   // are one DPP quad
+            if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, t >> 2, acc);
+        }
+    };
+
+    // the same for n_out outputs at stream position out_pos .. (WIN with FIR): output i = sum_j taps[j] src[i + j]
+    auto boundary_n = [&](const cf *src, int n_out, int out_pos) __attribute__((always_inline)) {
+        for (int i0 = 0; i0 < n_out; i0 += kThreads / 4) {
+            const int i = i0 + (t >> 2), q = t & 3;
+            const int ii = i < n_out ? i : 0;
+            cf acc = mk(0.f, 0.f);
+            for (int j = q; j < ntaps; j += 4) {
+                const cf x = src[ii + j];
+                const float tp = taps_l[j];
+                acc.x = fmaf(x.x, tp, acc.x);
+                acc.y = fmaf(x.y, tp, acc.y);
+            }
+            acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);
+            acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);
+            if (i < n_out && q == 0) put(out_pos + i0, t >> 2, acc);
+        }
+    };
+
+    // EQ: the 44 boundary outputs of the previous segment from the filtered symbols (see the template's comment).
+    // zp = the previous symbol's windows; eq_w holds w (written by the lanes that own those samples, a barrier ago).
+    auto eq_boundary = [&](const cf *zp) __attribute__((always_inline)) {
+        // d = g (*) w: 11 blocks of four outputs x 16 groups of ten taps = 176 lanes, the 16 groups of a block being one
+        // DPP row.  Output m = m0 + r, tap jj = j0 + u reads w[q] at index q + kEqQL = m + (kEqTaps - 1 - jj).
+        // (four outputs per lane over 176 lanes measured 2 % faster than three over 240)
+        constexpr int kEqR = 4, kEqLanes = 16 * ((44 + kEqR - 1) / kEqR);
+        static_assert(!EQ || kEqLanes <= T, "EQ: outputs per lane");
+        cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+        if (t < kEqLanes) {
+            const int m0 = kEqR * (t >> 4), j0 = 10 * (t & 15);
+            const cf *wp = eq_w + (m0 + (kEqTaps - 1 - 9) - j0);
+            const float2 *g2 = reinterpret_cast<const float2 *>(g_l + j0);
+            cf wv[kEqR + 9];
+            float gg[10];
+#pragma unroll
+            for (int i = 0; i < kEqR + 9; ++i) wv[i] = wp[i];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { const float2 g = g2[u]; gg[2 * u] = g.x; gg[2 * u + 1] = g.y; }
+#pragma unroll
+            for (int u = 0; u < 10; ++u)
+#pragma unroll
+                for (int r = 0; r < kEqR; ++r) acc[r] = axpy(acc[r], gg[u], wv[r + 9 - u]);
+        }
+        // sum over the 16 lanes of a row: x += x(lane ^ 1), x += x(lane ^ 2), x += x(ror 4), x += x(ror 8) as v_add_f32 with
+        // the DPP operand in place -- four instructions per float.  (Through update_dpp the compiler spends a
+        // v_mov_b32_dpp plus a zeroing v_mov_b32 per term, and an addition.)  Hazard: a DPP read needs two wait states
+        // after the VALU write of its source -- the s_nop covers the first step, the independent additions of a step
+        // the following ones.
+#define DABGPU_DPP6(CTRL)                                                                       \
+        "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define DABGPU_DPP2(CTRL)                                                                       \
+        "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+        asm volatile("s_nop 1\n\t"
+                     DABGPU_DPP6("quad_perm:[1,0,3,2]") DABGPU_DPP2("quad_perm:[1,0,3,2]")
+                     DABGPU_DPP6("quad_perm:[2,3,0,1]") DABGPU_DPP2("quad_perm:[2,3,0,1]")
+                     DABGPU_DPP6("row_ror:4") DABGPU_DPP2("row_ror:4") DABGPU_DPP6("row_ror:8") DABGPU_DPP2("row_ror:8")
+                     : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
+                       "+v"(acc[3].x), "+v"(acc[3].y));
+#undef DABGPU_DPP6
+#undef DABGPU_DPP2
+        if (t < kEqLanes && (t & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < kEqR; ++r) eq_d[kEqR * (t >> 4) + r] = acc[r];
+        }
+        lds_barrier();
+        // y[N-44+i] = z_prev[N-44+i] + sum_{jd <= i} taps[44-i+jd] d[jd]: four lanes (one DPP quad) per output, lane q
+        // taking jd = q, q+4, ...; past jd = i the tap index runs into the table's zero padding
+        {
+            const int i = min(t >> 2, C - 1), q = t & 3;
+            const float *tq = taps_l + (C - i) + q;
+            const cf *dq = eq_d + q;
+            cf y = mk(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
+            asm volatile("s_nop 1\n\t"
+                         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                         "s_nop 0\n\t"
+                         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                         "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                         : "+v"(y.x), "+v"(y.y));
+            if (t < 4 * C && q == 0) put(prev_pos + prev_seg - C, t >> 2, cadd(y, zp[kEqQL - C + i]));
+        }
+    };
+
+    // Input of symbol s+1 is requested while symbol s is being transformed and BEFORE
+    // symbol s is stored: vmcnt retires in order, so a load issued after the stores would
+    // make every symbol wait for the previous symbol's HBM writes.
+    int bb = 0;                 // which bitbuf half holds the block of the current symbol
+    cf nval[6];                 // carriers path: the next symbol's active carriers
+    if (!FROM_BITS) load_active(s_begin, nval);
+
+    // Coded-bits path: the NULL symbol is blank (no TII), its segment is exact zeros and its
+    // tail is a zero tail.  Peeling it off makes the guard length a loop constant, so the
+    // lane predicates of the prefix copy and of the boundary samples hoist out of the loop.
+    int s_loop = s_begin;
+    if (FROM_BITS && s_begin == 0) {
+        const int nz = len0 - C - W;                  // the last C outputs belong to `boundary` (W: to the seam)
+        for (int i0 = 0; i0 < nz; i0 += kThreads)
+            if (i0 + t < nz) put(i0, t, mk(0.f, 0.f));
+        if (EQ) {
+            for (int i = t; i < kEqW; i += (int)blockDim.x) eq_zp[cur * kEqW + i] = mk(0.f, 0.f);
+        } else if (FIR && !WIN) {
+            for (int i = t; i < KB; i += (int)blockDim.x) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
+        }
+        if (FIR) {
+            have_prev = true;
+            prev_pos = 0;
+            prev_seg = len0;
+        }
+        if (WIN && FIR) {
+            for (int i = t; i < wfLP; i += (int)blockDim.x) wfb[cur * wfLP + i] = mk(0.f, 0.f);
+        } else if (WIN) {
+            for (int i = t; i < 2 * W; i += (int)blockDim.x) wbuf[cur * 2 * kWinMax + i] = mk(0.f, 0.f);
+            have_prev = true;
+        }
+        // bring the staged block to the state the loop expects at s = 1 (block index -1: none)
+        s_loop = 1;
+    }
+
+    for (int s = s_loop; s < s_stop; ++s) {
+        if (FROM_BITS) __builtin_assume(s >= 1);    // (the blank null symbol was peeled off above)
+        const bool lookahead = s >= s_end;      // FIR / WIN only: no output for this symbol
+        cf val[6], v[8];
+        uint32_t pf = 0u;
+        if (FROM_BITS) {
+            lds_barrier();                    // bitbuf[bb] written (prologue / previous iteration)
+            if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
+            pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
+            load_active(s, val);
+            if (GAIN && !CFR && a.gain.mode == 2) {
+                // Gain statistics without touching the time domain.  With every carrier on the
+                // unit circle (times |y_s|) and a zero DC bin:
+                //   var(re) = |X|^2 (K/2 + S),  var(im) = |X|^2 (K/2 - S),
+                //   S = sum over carrier pairs {k, -k} of cos(pi/4 (p_k + p_-k)),
+                // because sum_n x[n]^2 = N sum_k X[k] X[-k].  Carrier -k of the lane's three positive
+                // carriers lives in lane T - t (lane 0 pairs with itself): exchange one packed word.
+                phw[tt] = P >> 12;                        // fields (-k0, -k1, -k2) of this lane
+                lds_barrier();
+                const unsigned o = phw[(T - tt) & (T - 1)];
+                // Every carrier of a symbol has the same phase parity (each block adds an odd number of eighths
+                // to all of them), so a pair's phase sum is an even number of eighths and its cosine is +1, 0 or -1:
+                // S = #(sum = 0 mod 4 quarter turns) - #(sum = 2 mod 4).  Both phases of a pair carry the symbol's
+                // rotation, s - 1 quarter turns in all.  The three sums in one addition (fields cannot carry into each
+                // other: 3 + 3 + 3 < 16); counted per wave with ballots -- the additions run on the scalar unit.
+                const unsigned sums = P + o + (((unsigned)(s - 1) & 3u) * 0x111u);
+                int cnt = 0;
+#pragma unroll
+                for (int j = 0; j < 3; ++j) {
+                    const unsigned f = sums & (3u << (4 * j));
+                    // (v_cmp_eq_u32 straight into an SGPR pair: 32 = ICMP_EQ)
+                    cnt += __builtin_popcountll(__builtin_amdgcn_uicmp(f, 0u, 32) & on_mask);
+                    cnt -= __builtin_popcountll(__builtin_amdgcn_uicmp(f, 2u << (4 * j), 32) & on_mask);
+                }
+                const float part = (float)cnt;
+                float *redf = reinterpret_cast<float *>(red + 8 * (s & 1));
+                if ((t & 63) == 0) redf[t >> 6] = part;      // combined after the transform's barriers
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) val[c] = nval[c];
+            if (s + 1 < s_stop) load_active(s + 1, nval);
+            if (GAIN && !CFR && (GVAR || a.gain.mode == 2) && s > 0)
+                spectral_partial(val, reinterpret_cast<float *>(red + 8 * (s & 1)));   // combined after the transform
+        }
+        constexpr bool DUAL = FIR && !EQ;         // unfiltered and filtered IFFT of a symbol as ONE packed transform
+        cf z[8];                                  // DUAL: the filtered symbol
+        cf uedge = mk(0.f, 0.f);                  // ZONLY: the lane's boundary sample of the unfiltered symbol
+        if (DUAL && CFR) {
+            // IFFT alone, crest-factor reduction on it, and back through the packed pair (inside cfr_symbol)
+            cf refv[8];
+            place(val, v);
+            F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
+            place(val, refv);
+            cfr_symbol(v, z, refv, s, !lookahead);
+        } else if (DUAL) {
+            // unfiltered and filtered transform of the symbol in lockstep (see struct c2)
+            cf valf[6];
+#pragma unroll
+            for (int c = 0; c < 6; ++c) valf[c] = cmul(val[c], hk[c]);
+            place(val, v);
+            place(valf, z);
+            c2 v2[8];
+#pragma unroll
+            for (int r = 0; r < 8; ++r) v2[r] = c2{make_float2(v[r].x, z[r].x), make_float2(v[r].y, z[r].y)};
+            if constexpr (ZONLY) {
+                F::template run_dual_zonly<+1>(v2, reinterpret_cast<c2 *>(fbuf), tw, tt, tw8_l, z, uedge);
+            } else {
+                F::template run<+1, DBUF, c2, true>(v2, reinterpret_cast<c2 *>(fbuf), fpar, tw, tt, tw8_l);
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    v[m] = mk(v2[m].re.x, v2[m].im.x);
+                    z[m] = mk(v2[m].re.y, v2[m].im.y);
+                }
+            }
+        } else {
+            if (EQ) {
+                // the filtered spectrum alone
+#pragma unroll
+                for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
+            }
+            place(val, v);
+            F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
+            if (CFR) {
+                cf refv[8];
+                place(val, refv);
+                cfr_symbol(v, z, refv, s, true);
+            }
+        }
+
+        if (FROM_BITS) {
+            // Park the prefetched block of the next symbol in LDS now, BEFORE anything of this iteration is
+            // stored: vmcnt retires in order and also counts stores, so a wait for this load placed after
+            // the boundary outputs' (conditional) store has to be vmcnt(0) -- every wave would sit out the
+            // full HBM write latency of that store once per symbol.  (Half bb^1 was last read an iteration ago.)
+            bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;
+        }
+
+        float g = 1.0f;
+        if (GAIN) {
+            if (FROM_BITS && !CFR && a.gain.mode == 2) {
+                const float *redf = reinterpret_cast<const float *>(red + 8 * (s & 1));
+                float S = 0.f;
+#pragma unroll
+                for (int w = 0; w < (T + 63) / 64; ++w) S += redf[w];
+                // |X| of the symbol: the table holds the COMPONENT magnitude; diagonal states
+                // (odd phase, the same parity on every carrier) have modulus sqrt(2) times that
+                const float mg = mag_l[s - 1];                               // the loop never sees s = 0 here
+                const float m2 = mg * mg * (float)(1u + ((unsigned)(s - 1) & 1u));   // (the carriers' own parts are even)
+                const float vr = fast_sqrt(m2 * fmaxf((float)(K / 2) + S, 0.f)) * a.gain.var_variance;
+                const float vi = fast_sqrt(m2 * fmaxf((float)(K / 2) - S, 0.f)) * a.gain.var_variance;
+                g = ((int)vr == 0) ? 1.0f : 32767.0f * fast_rcp(fmaxf(vr, vi));
+            } else if (!FROM_BITS && !CFR && (GVAR || a.gain.mode == 2) && s > 0) {
+                g = spectral_gain(reinterpret_cast<const float *>(red + 8 * (s & 1)));
+            } else if (GVAR) {
+                g = g_null;                                   // s == 0
+            } else if (ZONLY || EQ) {
+                g = 512.0f;                                   // mode fix (the launcher keeps mode max off this variant)
+            } else {
+                g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
+            }
+            g = g * a.gain.constant;
+            // TII (f-4): the null symbol of the coded-bits path is added afterwards, scaled by the
+            // multiplier of symbol 1 (src/GainControl.cpp:139-144)
+            if (FROM_BITS && a.gain1 != nullptr && s == 1 && t == 0) a.gain1[frame] = g;
+        }
+
+        // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the
+        // (unfiltered, filtered) pairs the dual transform left side by side; everything below uses v and z as is
+        constexpr bool PRESCALED = (DUAL || WIN || EQ) && GAIN;
+        if (((WIN && !FIR) || EQ) && GAIN) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = cscale(v[m], g);
+        } else if (PRESCALED && ZONLY) {
+            uedge = cscale(uedge, g);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) z[m] = cscale(z[m], g);
+        } else if (PRESCALED) {
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const float2 re = make_float2(v[m].x, z[m].x) * g, im = make_float2(v[m].y, z[m].y) * g;
+                v[m] = mk(re.x, im.x);
+                z[m] = mk(re.y, im.y);
+            }
+        }
+        auto scaled = [&](cf x) __attribute__((always_inline)) -> cf {
+            return (PRESCALED || !GAIN) ? x : cscale(x, g);
+        };
+
+        const int cpl = (!FROM_BITS && s == 0) ? cp0 : cp;
+        const int seg = N + cpl;
+        // position of this segment in the frame's output stream
+        const int pos = GUARD ? (s == 0 ? 0 : len0 + (s - 1) * len) : s * N;
+        if constexpr (EQ) {
+            // ---- the windows of the filtered, gain-scaled symbol that the boundary outputs need ----
+            // w[q] = z_cur[N - cp + q] - z_prev[q mod N] for q in [-kEqQL, kEqQH], written by the lanes that hold
+            // z_cur[N - cp + q] (slots 5 and 6); the symbol's own windows around its start (slots 7 and 0) are parked
+            // for the next symbol.  Index of q everywhere: q + kEqQL.
+            cf *zp_prev = eq_zp + cur * kEqW, *zp_new = eq_zp + (cur ^ 1) * kEqW;
+            constexpr int n0 = (N - cp) - kEqQL;              // first sample of the window in z_cur (1441)
+            static_assert(!EQ || (n0 >= 5 * T && n0 + kEqQL + kEqQH < 7 * T && kEqQL < T && kEqQH < T), "EQ windows: slots 5, 6, 7, 0");
+            if (t >= n0 - 5 * T) { const int iw = t - (n0 - 5 * T); eq_w[iw] = csub(v[5], zp_prev[iw]); }
+            if (t <= n0 + kEqQL + kEqQH - 6 * T) { const int iw = t + (6 * T - n0); eq_w[iw] = csub(v[6], zp_prev[iw]); }
+            if (t >= T - kEqQL) zp_new[t - (T - kEqQL)] = v[7];
+            if (t <= kEqQH) zp_new[kEqQL + t] = v[0];
+            lds_barrier();
+            // (the boundary outputs follow the symbol's own stores, below: its samples are dead registers by then)
+        } else if constexpr (WIN && FIR) {
+            // ---- windowed seam AND look-ahead filter: the C + 2W outputs whose 45 samples touch the seam ----
+            // U = [x_prev[N-W-C .. N-W) | the 2W seam samples (as without FIR) | x_cur[N-cp+W .. N-cp+W+C)] is the stream as the
+            // reference's FIRFilter sees it; output i of them, at stream position pos - W - C + i, is sum_j taps[j] U[i + j].
+            cf *pprev = wfb + cur * wfLP, *pnew = wfb + (cur ^ 1) * wfLP;
+            if (lane_on) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int n = t + T * m, ta = n - (N - W - C), r = n - (N - cpl - W);
+                    if (ta >= 0) pnew[ta] = v[m];
+                    if (n < W) pnew[C + W + n] = v[m];
+                    if (r >= 0 && r < 2 * W + C) wf_cur[r] = v[m];
+                }
+            }
+            lds_barrier();
+            if (have_prev) {
+                for (int i = t; i < 2 * W + 2 * C; i += kThreads) {
+#pragma clang fp contract(off)  // seam: products and sum rounded separately, like the reference (see guard_window_at)
+                    cf u;
+                    if (i < C) {
+                        u = pprev[i];
+                    } else if (i < C + 2 * W) {
+                        const int j = i - C;
+                        const cf xp = pprev[i], xr = wf_cur[j];
+                        const float fp = win_l[2 * W - 1 - j], fr = win_l[j];
+                        const float ar = xp.x * fp, ai = xp.y * fp, br = xr.x * fr, bi = xr.y * fr;
+                        u = mk(ar + br, ai + bi);
+                    } else {
+                        u = wf_cur[i - C];
+                    }
+                    wf_U[i] = u;
+                }
+                lds_barrier();
+                boundary_n(wf_U, C + 2 * W, pos - W - C);
+            }
+            cur ^= 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = z[m];
+        } else if (FIR) {
+            // ---- boundary samples of the unfiltered, gain-scaled symbol ---------------
+            cf *tail_new = bnd + (cur ^ 1) * 2 * KB, *tail_prev = bnd + cur * 2 * KB, *head = tail_prev + C;
+            if (lane_on) {
+                // The last C samples sit in the top register slot(s); the head of the segment (the
+                // first C samples of the cyclic prefix) in slot m_h0 and maybe the following ones.
+                // Slot tests are wave-uniform, only the lane tests are vector work.
+                const int m_h0 = (N - cpl) / T;
+                if (ZONLY) {
+                    // Tail = slot 7 of the last C lanes.  Head (cpl == cp: the head of symbol 0, whose prefix is
+                    // longer in the carriers path, is read by nobody -- there is no segment before it) = samples
+                    // [N - cp, N - cp + C) = slot 6 of lanes [h0, h0 + C), all in the first wave
+                    constexpr int h0 = (N - cp) - 6 * T;
+                    static_assert(!ZONLY || (h0 >= 0 && h0 + (NT - 1) <= 64 && NT - 1 <= 64), "boundary lanes");
+                    if (t >= T - C) tail_new[t - (T - C)] = uedge;
+                    if (t >= h0 && t < h0 + C) head[t - h0] = uedge;
+                } else if (C <= T) {      // the usual case (45 taps, T = 256): one tail slot, at most two head slots
+                    if (t >= T - C) tail_new[t - (T - C)] = scaled(v[7]);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        if (m == m_h0 || m == m_h0 + 1) {
+                            const int hn = t + T * m - (N - cpl);
+                            if (hn >= 0 && hn < C) head[hn] = scaled(v[m]);
+                        }
+                    }
+                } else {           // short FFTs (T = 32, 64) or long filters
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const int tn = t + T * m - (N - C), hn = t + T * m - (N - cpl);
+                        if (tn >= 0) tail_new[tn] = scaled(v[m]);
+                        if (hn >= 0 && hn < C) head[hn] = scaled(v[m]);
+                    }
+                }
+            }
+            lds_barrier();
+            if (have_prev) boundary(tail_prev);
+            cur ^= 1;
+#pragma unroll
+            for (int m = 0; m < 8; ++m) v[m] = z[m];        // the rest of the iteration stores the filtered symbol
+        }
+        if (WIN && !FIR) {
+            // ---- seam between the previous symbol and this one -------------------------
+            cf *pprev = wbuf + cur * 2 * kWinMax, *pnew = wbuf + (cur ^ 1) * 2 * kWinMax, *rise = wbuf + 4 * kWinMax;
+            if (lane_on) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int n = t + T * m, r = n - (N - cpl - W);
+                    if (n >= N - W) pnew[n - (N - W)] = v[m];
+                    if (n < W) pnew[W + n] = v[m];
+                    if (r >= 0 && r < 2 * W) rise[r] = v[m];
+                }
+            }
+            lds_barrier();
+            if (have_prev) {
+                for (int j = t; j < 2 * W; j += kThreads) {
+#pragma clang fp contract(off)  // products and sum rounded separately, like the reference (see guard_window_at)
+                    const cf xp = pprev[j], xr = rise[j];
+                    const float fp = win_l[2 * W - 1 - j], fr = win_l[j];
+                    const float ar = xp.x * fp, ai = xp.y * fp, br = xr.x * fr, bi = xr.y * fr;
+                    put(pos - W, j, mk(ar + br, ai + bi));
+                }
+            }
+            cur ^= 1;
+        }
+        if (FROM_BITS) bb ^= 1;
+        if (lookahead && !EQ) break;
+        if (lane_on && !(EQ && lookahead)) {
+            const int m_cp = (N - cpl) / T;   // first register slot that is also copied into the prefix
+            const bool keep_tail = !WIN || s == nsym - 1;    // WIN: the last W samples belong to the next seam
+#pragma unroll
+            for (int m = 0; m < 8; ++m) {
+                const int n = t + T * m;
+                const cf y = scaled(v[m]);
+                // FIR: the last C belong to `boundary`; WIN: the last W to the seam (with both: the last C + W)
+                if (FIR ? n < N - C - (keep_tail ? 0 : W) : (keep_tail || n < N - W)) put(pos + cpl + T * m, t, y);
+                if ((m > m_cp || (m == m_cp && n >= N - cpl)) && (!WIN || n - (N - cpl) >= W)) put(pos, n - (N - cpl), y);
+            }
+        }
+        if constexpr (EQ) {
+            if (have_prev) eq_boundary(eq_zp + cur * kEqW);
+            cur ^= 1;
+            if (lookahead) break;
+        }
+        have_prev = true;
+        prev_pos = pos;
+        prev_seg = seg;
+    }
+    if (EQ && s_end == nsym && have_prev) {
+        // end of the frame: nothing follows (a zero symbol: w = -z_prev), missing terms are dropped
+        const cf *zp = eq_zp + cur * kEqW;
+        lds_barrier();
+        for (int i = t; i < kEqW; i += (int)blockDim.x) eq_w[i] = mk(-zp[i].x, -zp[i].y);
+        lds_barrier();
+        eq_boundary(zp);
+    } else if (WIN && FIR && s_end == nsym && have_prev) {
+        // end of the frame: the last symbol keeps its (unwindowed) tail, nothing follows it
+        const cf *stash = wfb + cur * wfLP;
+        lds_barrier();
+        for (int i = t; i < 2 * C; i += (int)blockDim.x) wf_U[i] = i < C ? stash[W + i] : mk(0.f, 0.f);
+        lds_barrier();
+        boundary_n(wf_U, C, prev_pos + prev_seg - C);
+    } else if (FIR && s_end == nsym && have_prev) {
+        // end of the frame: the look-ahead runs off the buffer, missing terms are
+        // dropped (reference src/FIRFilter.cpp:186-191)
+        lds_barrier();
+        for (int i = t; i < C; i += (int)blockDim.x) bnd[cur * 2 * KB + C + i] = mk(0.f, 0.f);   // zero head
+        lds_barrier();
+        boundary(bnd + cur * 2 * KB);
+    }
+    if (OFMT == 1) s16_flush_count(nclip, a.clipped);
+}
+
+template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)
+{
+    constexpr int T = (1 << LOGN) / 8;
+    typedef ModeGeom<LOGN> G;
+    if (a.g.K != G::K || a.g.nb_symbols != G::nb_symbols || a.g.null_size != G::null_size ||
+        a.g.sym_size != G::sym_size)
+        return hipErrorInvalidValue;
+    const dim3 block(T < 64 ? 64 : T);
+    const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
+    const bool gvar = !(flags & TF_FROM_BITS) && (flags & TF_GAIN) && !(flags & TF_CFR) && a.gain.mode == 2;
+    const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0), (flags & TF_FIR) ? NT : 0, a.overlap, a.ntaps);
+#define TF_LAUNCH(FB, GN, GD, FR)                                                              \
+    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
+#define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
+    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, EPI, EPI, 0, true>), grid, block, lds, s, a)
+    const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
+               fr = flags & TF_FIR;
+    if (fr && !gd) return hipErrorInvalidValue;
+    if ((flags & TF_OUT_S16) && !tf_has_s16(a, flags)) return hipErrorInvalidValue;
+    if ((flags & TF_WINDOW) && !tf_has_window(a, flags)) return hipErrorInvalidValue;
+    if ((flags & TF_EQ) && !tf_has_eq(a, flags)) return hipErrorInvalidValue;
+    if (flags & TF_CFR) {
+        // with the whole fused epilogue (guard + FIR) or with none of it
+        if (gd != fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
+        if (fr) {
+            if (fb) { if (gn) TF_LAUNCH_CFR(true, true, true); else TF_LAUNCH_CFR(true, false, true); }
+            else    { if (gn) TF_LAUNCH_CFR(false, true, true); else TF_LAUNCH_CFR(false, false, true); }
+        } else {
+            if (fb) { if (gn) TF_LAUNCH_CFR(true, true, false); else TF_LAUNCH_CFR(true, false, false); }
+            else    { if (gn) TF_LAUNCH_CFR(false, true, false); else TF_LAUNCH_CFR(false, false, false); }
+        }
+        return hipGetLastError();
+    }
+#define TF_LAUNCH_GVAR(GD, FR)                                                                 \
+    hipLaunchKernelGGL((tf_kernel<LOGN, false, true, GD, FR, (FR ? NT : 0), false, true>), grid, block, lds, s, a)
+    if (gvar) {
+        if (LOGN == 11 && NT == 45 && fr && gd) {
+            hipLaunchKernelGGL((tf_kernel<11, false, true, true, true, 45, false, true, true>), grid, block, lds, s, a);
+            return hipGetLastError();
+        }
+        if (fr) TF_LAUNCH_GVAR(true, true); else if (gd) TF_LAUNCH_GVAR(true, false); else TF_LAUNCH_GVAR(false, false);
+        return hipGetLastError();
+    }
+#undef TF_LAUNCH_GVAR
+    if (flags & TF_WINDOW) {
+        if (!tf_has_window(a, flags) || NT != 0) return hipErrorInvalidValue;
+        if (fr) {
+            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, true, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, true, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+        } else {
+            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+        }
+        return hipGetLastError();
+    }
+    if (LOGN == 11 && NT == 45 && !fb && !gn && fr && gd) {
+        hipLaunchKernelGGL((tf_kernel<11, false, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        return hipGetLastError();
+    }
+    if (LOGN == 11 && NT == 45 && fb && fr && gd && (!gn || a.gain.mode != 1)) {
+        if (flags & TF_EQ) {
+            // ... or the one that runs the filtered transform alone and equalises the boundary (needs the taps' inverse)
+            if (!a.t.eq_g || ((flags & TF_OUT_S16) && !a.clipped)) return hipErrorInvalidValue;
+#define TF_LAUNCH_EQ(GN, OF) \
+            hipLaunchKernelGGL((tf_kernel<11, true, GN, true, true, 45, false, false, false, OF, false, true>), grid, block, lds, s, a)
+            if (flags & TF_OUT_S16) { if (gn) TF_LAUNCH_EQ(true, 1); else TF_LAUNCH_EQ(false, 1); }
+            else                    { if (gn) TF_LAUNCH_EQ(true, 0); else TF_LAUNCH_EQ(false, 0); }
+#undef TF_LAUNCH_EQ
+            return hipGetLastError();
+        }
+        // Mode I, default filter length, gain fix / var (or none): the variant that prunes the unfiltered transform
+        if (flags & TF_OUT_S16) {
+            if (!a.clipped) return hipErrorInvalidValue;
+            if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true, 1>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true, 1>), grid, block, lds, s, a);
+            return hipGetLastError();
+        }
+        if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        return hipGetLastError();
+    }
+    if (flags & TF_OUT_S16) return hipErrorInvalidValue;         // (callers ask tf_has_s16 first)
+    if (fb) {
+        if (gn) { if (fr) TF_LAUNCH(true, true, true, true); else if (gd) TF_LAUNCH(true, true, true, false); else TF_LAUNCH(true, true, false, false); }
+        else    { if (fr) TF_LAUNCH(true, false, true, true); else if (gd) TF_LAUNCH(true, false, true, false); else TF_LAUNCH(true, false, false, false); }
+    } else {
+        if (gn) { if (fr) TF_LAUNCH(false, true, true, true); else if (gd) TF_LAUNCH(false, true, true, false); else TF_LAUNCH(false, true, false, false); }
+        else    { if (fr) TF_LAUNCH(false, false, true, true); else if (gd) TF_LAUNCH(false, false, true, false); else TF_LAUNCH(false, false, false, false); }
+    }
+#undef TF_LAUNCH
+#undef TF_LAUNCH_CFR
+    return hipGetLastError();
+}
+
+
+}  // namespace
+}  // namespace dabgpu

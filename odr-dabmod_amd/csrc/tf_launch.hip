@@ -1,0 +1,94 @@
+// tf_launch.hip -- host side of the frame kernel: LDS size, which fused variants exist, and the dispatch to the
+// per-mode translation units (tf_inst.hip).
+#include "tf_layout.h"
+
+#include <algorithm>
+
+namespace dabgpu {
+
+// defined in tf_inst.hip, one per (FFT size, compile-time tap count)
+hipError_t launch_tf_8_0(const TfArgs &a, unsigned flags, hipStream_t s);
+hipError_t launch_tf_9_0(const TfArgs &a, unsigned flags, hipStream_t s);
+hipError_t launch_tf_10_0(const TfArgs &a, unsigned flags, hipStream_t s);
+hipError_t launch_tf_11_0(const TfArgs &a, unsigned flags, hipStream_t s);
+hipError_t launch_tf_11_45(const TfArgs &a, unsigned flags, hipStream_t s);
+
+size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
+{
+    const size_t N = (size_t)1 << logN;
+    const bool eq = flags & TF_EQ;
+    const bool dbuf = !(flags & TF_FIR);                     // two exchange buffers without FIR, one with (see tf_kernel)
+    const bool dual = (flags & TF_FIR) && !eq;               // packed dual transform: 16-byte elements
+    size_t b = dual ? (N + N / 8) * 2 * sizeof(float2) : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
+    b += 16 * sizeof(double);
+    if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
+    const bool wf = (flags & TF_WINDOW) && (flags & TF_FIR);
+    if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter
+    else if ((flags & TF_FIR) && !wf) b += 4 * (nt ? nt - 1 : kBnd) * sizeof(float2);  // 2 x [tail | next head]
+    if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
+    b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
+    b += 56 * sizeof(float2);                                      // twiddles of the stride-8 stage
+    if (flags & TF_CFR) b += 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red
+    if (wf) {
+        // behind the twiddle table: two stashes, the next symbol's samples, the windowed stream, the window
+        const size_t C = (size_t)std::max(ntaps - 1, 0), W = (size_t)std::max(overlap, 0);
+        b += (2 * (C + 2 * W) + (2 * W + C) + (2 * W + 2 * C)) * sizeof(float2) + 2 * W * sizeof(float) + 16;
+    } else if (flags & TF_WINDOW) {
+        b += 7 * kWinMax * sizeof(float2);                                     // seam buffers + window
+    }
+    return b;
+}
+
+// the frame-kernel variants that window the guard interval themselves: coded-bits chain with guard interval and
+// without FIR / CFR / s16 store, overlap up to kWinMax (and inside the cyclic prefix)
+bool tf_has_window(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_CFR | TF_OUT_S16;
+    if ((flags & want) != want || (flags & never) || a.overlap < 1 || a.overlap > kWinMax) return false;
+    // with FIR: the filter's look-ahead and the window must both fit into the cyclic prefix
+    if (flags & TF_FIR)
+        return a.ntaps >= 1 && a.ntaps <= kBnd && a.ntaps <= kMaxTaps &&
+               a.overlap + a.ntaps - 1 <= a.g.sym_size - a.g.N;
+    return a.overlap <= a.g.sym_size - a.g.N;
+}
+
+int tf_max_fused_taps() { return kBnd < kMaxTaps ? kBnd : kMaxTaps; }
+
+// the equalised-boundary variant: the chains of the pruned-dual-transform variant, given the inverse of the taps
+bool tf_has_eq(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
+    return a.t.eq_g != nullptr && a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & (TF_CFR | TF_WINDOW)) &&
+           (!(flags & TF_GAIN) || a.gain.mode != 1);
+}
+
+// the frame-kernel variants that store s16 themselves: Mode I coded-bits chain, guard + default-length filter,
+// gain none / fix / var, no CFR
+bool tf_has_s16(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
+    return a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & TF_CFR) &&
+           (!(flags & TF_GAIN) || a.gain.mode != 1);
+}
+
+hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
+{
+    if (flags & TF_FIR) {
+        // the fused (spectral) FIR needs its look-ahead to fit in a cyclic prefix
+        const int C = a.ntaps - 1;
+        if (a.ntaps < 1 || a.ntaps > kMaxTaps || a.ntaps > kBnd || C > a.g.sym_size - a.g.N)
+            return hipErrorInvalidValue;
+    }
+    switch (a.g.logN) {
+        // Mode I with the default filter length gets the compile-time tap count
+        case 8: return launch_tf_8_0(a, flags, s);
+        case 9: return launch_tf_9_0(a, flags, s);
+        case 10: return launch_tf_10_0(a, flags, s);
+        case 11:
+            return ((flags & TF_FIR) && a.ntaps == 45 && !(flags & (TF_CFR | TF_WINDOW))) ? launch_tf_11_45(a, flags, s)
+                                                       : launch_tf_11_0(a, flags, s);
+    }
+    return hipErrorInvalidValue;
+}
+
+}  // namespace dabgpu

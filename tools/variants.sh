@@ -1,16 +1,17 @@
 #!/bin/bash
-# Build tuning variants of libdabgpu.so into gpurun_out-independent tools/_variants/ (git-ignored).
-# usage: tools/variants.sh name "-DDABGPU_TF_WAVES=2 ..." [name flags]...
+# Build A/B variants of libdabgpu.so into tools/_variants/ (git-ignored): a copy of the csrc tree per variant, compiled with
+# extra flags (or after a patch applied by hand to the copy).  The timing tools pick a library through DABGPU_LIB.
+# usage: tools/variants.sh name "<extra hipcc flags>" [name flags]...
 set -e
-cd "$(dirname "$0")/../odr-dabmod_amd/csrc"
-mkdir -p ../../tools/_variants
+ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+mkdir -p "$ROOT/tools/_variants"
 while [ $# -ge 2 ]; do
   name=$1; flags=$2; shift 2
-  /opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -fvisibility=hidden ${NOLSO--Xclang -target-feature -Xclang -load-store-opt} ${NOSLP--fno-slp-vectorize} $flags \
-      -shared -o ../../tools/_variants/libdabgpu_$name.so dabgpu_kernels.hip dabgpu_api.hip \
-      -Rpass-analysis=kernel-resource-usage 2> ../../tools/_variants/$name.log &
-done
-wait
-for f in ../../tools/_variants/*.log; do
-  echo "== $f"; grep -A6 "tf_kernelILi11ELb1ELb1ELb1ELb1ELi48" $f | grep -E "VGPRs:|Scratch|Occupancy" | sed 's/.*remark: //; s/\[-R.*//'
+  d="$ROOT/tools/_variants/src_$name"
+  rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"
+  cp -r "$ROOT/odr-dabmod_amd/csrc" "$d/odr-dabmod_amd/csrc"; cp "$ROOT/include/"*.h "$d/include/"
+  rm -f "$d/odr-dabmod_amd/csrc/"*.o "$d/odr-dabmod_amd/csrc/libdabgpu.so"
+  make -s -C "$d/odr-dabmod_amd/csrc" -j8 NOSLP="-fno-slp-vectorize $flags" > "$ROOT/tools/_variants/$name.log" 2>&1
+  cp "$d/odr-dabmod_amd/csrc/libdabgpu.so" "$ROOT/tools/_variants/libdabgpu_$name.so"
+  echo "built tools/_variants/libdabgpu_$name.so"
 done
