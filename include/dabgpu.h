@@ -96,10 +96,11 @@ DABGPU_API int dabgpu_set_fir_default_taps(dabgpu_ctx *ctx);
 /* GuardIntervalInserter::update_window, src/GuardIntervalInserter.cpp:96-113 */
 DABGPU_API int dabgpu_set_window_overlap(dabgpu_ctx *ctx, size_t overlap);
 /* Resampler(inputRate, outputRate, resolution = spacing), src/Resampler.cpp:51-112;
- * resets the stream state (prev-input halo and overlap tail).  Built: up-sampling by L / M
- * (the rates reduced by their gcd) with M a power of two <= 128 in Mode I (2.4, 3.072, 4, 6.144,
- * 8, 10 ... Msps; x2 and x4 have their own faster kernel).  Other ratios -- down-sampling, M not
- * a power of two -- are refused by the next *_process call with DABGPU_E_INVALID. */
+ * resets the stream state (prev-input halo and overlap tail).  Built: every ratio L / M (the
+ * rates reduced by their gcd) with M a power of two up to the FFT size -- up- AND down-sampling
+ * (1.024, 1.536, 2.4, 3.072, 4.096, 6.144, 8.192 ... Msps in Mode I; x2 and x4 have their own
+ * faster kernel).  Any other ratio is refused HERE with DABGPU_E_INVALID (the reference's own
+ * hop loop cannot run those on whole transmission frames). */
 DABGPU_API int dabgpu_set_resampler(dabgpu_ctx *ctx, size_t in_rate, size_t out_rate);
 /* MemlessPoly::load_coefficients format 1, src/MemlessPoly.cpp:154-202 */
 DABGPU_API int dabgpu_set_poly(dabgpu_ctx *ctx, const float am[5], const float pm[5]);
@@ -264,13 +265,6 @@ DABGPU_API int dabgpu_chain_collect(dabgpu_ctx *ctx, const void **iq, size_t *ou
 
 /* wait for everything queued on the context's own stream */
 DABGPU_API int dabgpu_synchronize(dabgpu_ctx *ctx);
-
-/* timing aid for bench.py: average duration (ms) of the dominant kernel of the
- * most recent *_dev call repeated `iters` times on the context's stream,
- * bracketed by HIP events on that stream. */
-DABGPU_API int dabgpu_time_chain_dev(dabgpu_ctx *ctx, const void *d_bits, size_t n_frames,
-                                     unsigned stage_mask, void *d_iq, size_t out_cap, int iters,
-                                     float *avg_ms);
 
 #ifdef __cplusplus
 }

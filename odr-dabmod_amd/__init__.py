@@ -28,7 +28,7 @@ EXPORTS = [
     "dabgpu_ofdm_process", "dabgpu_gain_process", "dabgpu_guard_process", "dabgpu_fir_process",
     "dabgpu_resampler_process", "dabgpu_poly_process", "dabgpu_chain_out_bytes_per_frame",
     "dabgpu_chain_process", "dabgpu_chain_process_dev", "dabgpu_symbols_process_dev",
-    "dabgpu_synchronize", "dabgpu_time_chain_dev",
+    "dabgpu_synchronize",
     "dabgpu_chain_submit", "dabgpu_chain_collect", "dabgpu_set_cfr", "dabgpu_get_cfr_stats",
     "dabgpu_cic_equalizer_process", "dabgpu_set_tii", "dabgpu_tii_process",
     "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
@@ -136,7 +136,6 @@ def load_library():
     lib.dabgpu_format_size.restype = sz
     lib.dabgpu_format_process.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, szp]
     lib.dabgpu_format_process_dev.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, vp, vp]
-    lib.dabgpu_time_chain_dev.argtypes = [vp, vp, sz, u, vp, sz, C.c_int, C.POINTER(C.c_float)]
     lib.dabgpu_set_output_format.argtypes = [vp, C.c_int]
     lib.dabgpu_get_num_clipped.argtypes = [vp, szp]
     lib.dabgpu_fir_inverse_design.argtypes = [C.POINTER(C.c_float), sz, C.POINTER(C.c_float), C.POINTER(C.c_double)]
@@ -441,13 +440,6 @@ class Modulator:
         if not s:
             self.synchronize()
         return ob.value
-
-    def time_chain_dev(self, d_bits, n_frames, stages, d_out, iters):
-        ms = C.c_float()
-        self._chk(self._lib.dabgpu_time_chain_dev(
-            self._h, d_bits.data_ptr(), n_frames, stages, d_out.data_ptr(),
-            d_out.numel() * d_out.element_size(), iters, C.byref(ms)))
-        return ms.value
 
     def synchronize(self):
         self._chk(self._lib.dabgpu_synchronize(self._h))

@@ -1,7 +1,7 @@
 // dabgpu_api.hip -- the C-ABI of include/dabgpu.h: context, device tables,
 // host staging, and the mapping from reference plugins to kernel launches.
 
-#include "../../include/dabgpu.h"
+#include "dabgpu.h"
 #include "dabgpu_internal.h"
 
 #include <algorithm>
@@ -11,6 +11,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <tuple>
 #include <vector>
 
 using namespace dabgpu;
@@ -83,6 +84,26 @@ struct Settings {
     int tii_comb = 0, tii_pattern = 0;
     unsigned long long epoch = 1;  // bumped by every setter
     bool resampler_reset = true;
+
+    // What each group of device data is a function of.  apply_settings_groups compares these keys, never single fields: a
+    // setting that starts to feed a table is added to that table's key HERE, next to its declaration.
+    //   the fused FIR's tap table, its frequency response and the inverse filter of the equalised-boundary variant
+    auto fir_key() const { return std::tie(taps); }
+    //   the raised-cosine window of the guard interval
+    auto window_key() const { return std::tie(overlap); }
+    //   the predistorter's coefficient block (polynomial and LUT share it; the selector and the LUT scale are kernel arguments)
+    bool coef_equal(const Settings &o) const
+    {
+        return poly_is_lut == o.poly_is_lut && lut_scale == o.lut_scale && !std::memcmp(am, o.am, sizeof am) &&
+               !std::memcmp(pm, o.pm, sizeof pm) && !std::memcmp(lut, o.lut, sizeof lut);
+    }
+    //   the resampler's window, twiddles and geometry
+    auto resampler_key() const { return std::tie(rs_in, rs_out); }
+    //   the cached unit-gain TII segment (TII symbol -> IFFT -> [CFR] -> guard [window] -> [FIR]); gain scales it at use
+    auto tii_segment_key() const
+    {
+        return std::tie(taps, overlap, tii_comb, tii_pattern, tii_old_variant, cfr_enable, cfr_clip, cfr_errclip);
+    }
 };
 
 }  // namespace
@@ -141,6 +162,7 @@ struct dabgpu_ctx {
         DevBuf d_in, d_out;
         hipEvent_t computed = nullptr, copied = nullptr;
         bool busy = false;
+        int out_format = 0;                            // the output format this batch was submitted with
     } slot[2];
     // Pinned output buffers, THREE for two batches in flight: submit n copies into buffer n mod 3, so the
     // buffer handed out by collect() of batch n is next written by submit n + 3 -- after the collect at the
@@ -149,6 +171,7 @@ struct dabgpu_ctx {
     size_t h_out_cap[3] = {0, 0, 0};
     unsigned long long submit_seq = 0;
     bool clip_from_collect = false;        // dabgpu_get_num_clipped answers for the batch collect() returned last
+    bool clip_valid = false;               // the most recent chain call converted its output (d_clip holds ITS count)
     size_t collected_clipped = 0;
     hipStream_t copy_stream = nullptr;
     int slot_head = 0, slot_count = 0;                 // oldest batch in flight, number in flight
@@ -389,17 +412,11 @@ int apply_settings_groups(dabgpu_ctx *c)
         c->applied_epoch = c->set.epoch;
     }
     const bool first = !c->tables_valid;
-    const bool taps_changed = first || prev.taps != c->cur.taps;
-    const bool window_changed = c->cur.overlap && (first || prev.overlap != c->cur.overlap);
-    const bool coef_changed = first || std::memcmp(prev.am, c->cur.am, sizeof prev.am) ||
-                              std::memcmp(prev.pm, c->cur.pm, sizeof prev.pm) ||
-                              std::memcmp(prev.lut, c->cur.lut, sizeof prev.lut);
-    const bool rs_changed = first || prev.rs_in != c->cur.rs_in || prev.rs_out != c->cur.rs_out || c->cur.resampler_reset;
-    const bool tii_changed = prev.tii_comb != c->cur.tii_comb || prev.tii_pattern != c->cur.tii_pattern ||
-                             prev.tii_old_variant != c->cur.tii_old_variant || prev.cfr_enable != c->cur.cfr_enable ||
-                             prev.cfr_clip != c->cur.cfr_clip || prev.cfr_errclip != c->cur.cfr_errclip ||
-                             prev.overlap != c->cur.overlap;
-    if (taps_changed || tii_changed) c->tii_seg_epoch = 0;      // the cached TII segment went through the old filter / CFR
+    const bool taps_changed = first || prev.fir_key() != c->cur.fir_key();
+    const bool window_changed = c->cur.overlap && (first || prev.window_key() != c->cur.window_key());
+    const bool coef_changed = first || !prev.coef_equal(c->cur);
+    const bool rs_changed = first || prev.resampler_key() != c->cur.resampler_key() || c->cur.resampler_reset;
+    if (prev.tii_segment_key() != c->cur.tii_segment_key()) c->tii_seg_epoch = 0;   // the cached segment went through the old filter / CFR / window
     if (!(taps_changed || window_changed || coef_changed || rs_changed)) return DABGPU_OK;
     if (!first) HIPCHK(c, hipDeviceSynchronize());
     hipStream_t s = c->stream;
@@ -842,17 +859,28 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     // the polynomial predistorter inside, or none).  Every other combination, and u8 / s8, converts afterwards.
     unsigned long long *clip = nullptr;
     bool fuse_native = false, fuse_post = false;
+    if (apply_format) c->clip_valid = fmt != 0;       // (a complexf call leaves no count behind: never the previous call's)
     if (fmt) {
         HIPCHK(c, c->d_clip.reserve(16));
         HIPCHK(c, hipMemsetAsync(c->d_clip.p, 0, 16, s));
         clip = (unsigned long long *)c->d_clip.p;
         c->clip_stream = s;
         if (fmt == DABGPU_FMT_S16 && !tii && !windowed && from_bits) {
+            // ask the kernels' own predicates (the ones their launchers test), so that the separate convert kernel is taken
+            // whenever a variant does not exist in this build
             const bool poly_ok = !(mask & DABGPU_STAGE_POLY) || (!c->cur.poly_is_lut && (mask & DABGPU_STAGE_RESAMPLE));
-            fuse_native = !post && c->g.logN == 11 && c->cur.taps.size() == 45 && (mask & DABGPU_STAGE_FIR) &&
-                          !(mask & DABGPU_STAGE_NOGUARD) && !c->cur.cfr_enable &&
-                          !((mask & DABGPU_STAGE_GAIN) && c->cur.gain_mode == DABGPU_GAIN_MAX);
-            fuse_post = (mask & DABGPU_STAGE_RESAMPLE) && resampler_fast_ratio(c) && c->rs_nin == 4096 && poly_ok;
+            TfArgs ta{};
+            ta.g = c->g;
+            ta.gain = gain_of(c);
+            ta.ntaps = (int)c->cur.taps.size();
+            const unsigned tflags = TF_FROM_BITS | ((mask & DABGPU_STAGE_GAIN) ? TF_GAIN : 0) |
+                                    ((mask & DABGPU_STAGE_NOGUARD) ? 0 : TF_GUARD) | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0) |
+                                    (c->cur.cfr_enable ? TF_CFR : 0);
+            fuse_native = !post && tf_has_s16(ta, tflags);
+            ResamplerArgs ra{};
+            ra.nin = c->rs_nin;
+            ra.nout = c->rs_nout;
+            fuse_post = (mask & DABGPU_STAGE_RESAMPLE) && resampler_fast_ratio(c) && resampler_has_s16(ra) && poly_ok;
         }
     }
     float2 *d_out = (float2 *)d_out_v;
@@ -1181,7 +1209,7 @@ int dabgpu_get_num_clipped(dabgpu_ctx *c, size_t *num_clipped)
         *num_clipped = c->collected_clipped;
         return DABGPU_OK;
     }
-    if (!c->d_clip.p) return DABGPU_OK;
+    if (!c->d_clip.p || !c->clip_valid) return DABGPU_OK;
     HIPCHK(c, hipStreamSynchronize(c->clip_stream ? c->clip_stream : c->stream));
     unsigned long long v = 0;
     HIPCHK(c, hipMemcpy(&v, c->d_clip.p, sizeof v, hipMemcpyDeviceToHost));
@@ -1579,6 +1607,7 @@ int dabgpu_symbols_process_dev(dabgpu_ctx *c, const void *d_car, size_t n_frames
 {
     CTXCHK(c);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    c->clip_from_collect = false;
     return run_chain(c, d_car, false, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
 }
 
@@ -1647,7 +1676,8 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     size_t ob = 0;
     rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, c->stream);
     if (rc) return rc;
-    if (c->cur.out_format) {
+    sl.out_format = c->cur.out_format;
+    if (sl.out_format) {
         // the clip counter is one per context and the next submit zeroes it: this batch's count goes to the slot now
         if (!sl.h_clip) HIPCHK(c, hipHostMalloc((void **)&sl.h_clip, 16, hipHostMallocDefault));
         HIPCHK(c, hipMemcpyAsync(sl.h_clip, c->d_clip.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
@@ -1675,7 +1705,7 @@ int dabgpu_chain_collect(dabgpu_ctx *c, const void **iq, size_t *out_bytes)
     *iq = c->h_out[sl.h_out_index];
     if (out_bytes) *out_bytes = sl.out_bytes;
     c->clip_from_collect = true;
-    c->collected_clipped = (c->cur.out_format && sl.h_clip) ? (size_t)*sl.h_clip : 0;
+    c->collected_clipped = (sl.out_format && sl.h_clip) ? (size_t)*sl.h_clip : 0;     // (the format of ITS submit)
     sl.busy = false;
     c->slot_head ^= 1;
     --c->slot_count;
@@ -1686,27 +1716,6 @@ int dabgpu_synchronize(dabgpu_ctx *c)
 {
     CTXCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
-    return DABGPU_OK;
-}
-
-int dabgpu_time_chain_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames, unsigned mask,
-                          void *d_iq, size_t out_cap, int iters, float *avg_ms)
-{
-    CTXCHK(c);
-    if (iters < 1 || !avg_ms) return fail(c, DABGPU_E_INVALID, "iters < 1");
-    size_t ob = 0;
-    int rc = run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, &ob, c->stream);
-    if (rc) return rc;
-    HIPCHK(c, hipEventRecord(c->ev0, c->stream));
-    for (int i = 0; i < iters; ++i) {
-        rc = run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, &ob, c->stream);
-        if (rc) return rc;
-    }
-    HIPCHK(c, hipEventRecord(c->ev1, c->stream));
-    HIPCHK(c, hipEventSynchronize(c->ev1));
-    float ms = 0.f;
-    HIPCHK(c, hipEventElapsedTime(&ms, c->ev0, c->ev1));
-    *avg_ms = ms / (float)iters;
     return DABGPU_OK;
 }
 

@@ -400,7 +400,12 @@ int EtiReader::loadEtiData(const Buffer &dataIn)
                     size_t need = 4 /* EOH */ + myFicSource->getFramesize() + 4 /* EOF */ + 4 /* TIST */;
                     for (const auto &src : mySources) need += src->framesize();
                     if (need > m_remaining) {
-                        m_state = State::Sync;
+                        // The exception drops the rest of THIS input buffer; whatever part of the offending frame lies
+                        // beyond it (a caller feeding a byte stream in pieces) is skipped as padding, so that the
+                        // next frame start is a real one and its payload is never parsed as FC / STC.
+                        const size_t beyond = m_remaining > left ? m_remaining - left : 0;
+                        m_remaining = beyond;
+                        m_state = beyond ? State::Pad : State::Sync;
                         m_stc.clear();
                         mySources.clear();
                         throw std::runtime_error("EtiReader: stream characterisation exceeds the 6144-byte ETI frame");

@@ -3,7 +3,7 @@
 // and the reference's error conventions.
 #include "GpuStages.h"
 
-#include "../../include/dabgpu.h"
+#include "dabgpu.h"
 
 #include <algorithm>
 #include <cctype>

@@ -1,5 +1,5 @@
 // frontend_cabi.cpp -- include/dabfrontend.h over the classes of Frontend.h.
-#include "../../include/dabfrontend.h"
+#include "dabfrontend.h"
 
 #include "Frontend.h"
 

@@ -277,6 +277,37 @@ int run_cpu()
         for (int i = 0; i < 5; ++i) ok += fg.run() ? 1 : 0;
         CHECK(ok == 4 && sink->frames == 4 && sink->last == 8);
     }
+    // EtiReader fed a byte stream in pieces: a frame whose sub-channel list overruns the 6144-byte frame is refused,
+    // and the part of it that lies beyond the offending buffer is skipped -- the next frame start is a real one
+    {
+        auto frame = [](unsigned nst, unsigned stl) {
+            std::vector<uint8_t> f(6144, 0x55);
+            const uint8_t sync[4] = {0xFF, 0x07, 0x3A, 0xB6};
+            std::memcpy(f.data(), sync, 4);
+            f[4] = 0; f[5] = static_cast<uint8_t>(0x80 | nst); f[6] = static_cast<uint8_t>(1u << 3); f[7] = 0;   // FCT, FICF|NST, FP|MID=1, FL
+            for (unsigned i = 0; i < nst; ++i) {
+                uint8_t *st = &f[8 + 4 * i];
+                st[0] = static_cast<uint8_t>(i << 2); st[1] = static_cast<uint8_t>(96 * i);
+                st[2] = static_cast<uint8_t>((0x22u << 2) | (stl >> 8)); st[3] = static_cast<uint8_t>(stl & 0xff);
+            }
+            return f;
+        };
+        const std::vector<uint8_t> bad = frame(2, 1000), good = frame(1, 48);     // 2 x 8000 bytes of payload: overrun
+        double tist_offset = 0.0;
+        EtiReader rd(tist_offset);
+        bool refused = false;
+        try { rd.loadEtiData(Buffer(1000, bad.data())); } catch (const std::runtime_error &) { refused = true; }
+        CHECK(refused);
+        // the remaining 5144 bytes of the bad frame arrive next, together with a good frame: no exception, and the good
+        // frame's header is the one in force afterwards
+        std::vector<uint8_t> rest(bad.begin() + 1000, bad.end());
+        rest.insert(rest.end(), good.begin(), good.end());
+        bool threw2 = false;
+        int used = 0;
+        try { used = rd.loadEtiData(Buffer(rest.size(), rest.data())); } catch (const std::exception &) { threw2 = true; }
+        CHECK(!threw2 && used == static_cast<int>(rest.size()));
+        CHECK(rd.getSubchannels().size() == 1 && rd.getSubchannels()[0]->framesize() == 48 * 8);
+    }
     std::printf("host_selftest cpu: OK (%d checks)\n", g_checks);
     return 0;
 }

@@ -831,6 +831,74 @@ def test_chain_tii_setting_change_rebuilds_the_segment(pkg):
         md.close()
 
 
+# Every remote-control setter, toggled between two chain calls of ONE context, must leave the context in the state a
+# fresh context configured with the second value is in: the tables a setting feeds (tap table + frequency response +
+# inverse filter, guard window, predistorter block, resampler geometry, cached TII segment) are re-uploaded exactly
+# when their key changes (Settings::*_key in dabgpu_api.hip).  (value A, value B) per setter; stages = the full chain.
+_TOGGLES = {
+    "gain": (lambda md: md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0), lambda md: md.set_gain(0, 0.8, 1.0 / 400000.0, 3.0)),
+    "fir_taps": (lambda md: md.set_fir_taps(None),
+                 lambda md: md.set_fir_taps(np.hanning(45).astype(np.float32) / np.hanning(45).sum())),
+    "fir_taps_length": (lambda md: md.set_fir_taps(None), lambda md: md.set_fir_taps(np.ones(13, np.float32) / 13)),
+    "window_overlap": (lambda md: md.set_window_overlap(0), lambda md: md.set_window_overlap(24)),
+    "window_overlap_width": (lambda md: md.set_window_overlap(10), lambda md: md.set_window_overlap(24)),
+    "resampler": (lambda md: md.set_resampler(2048000, 4096000), lambda md: md.set_resampler(2048000, 8192000)),
+    "poly": (lambda md: md.set_poly([1, 0, 0, 0, 0], [0, 0, 0, 0, 0]),
+             lambda md: md.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0])),
+    "lut": (lambda md: md.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0]),
+            lambda md: md.set_lut(2.0 ** 31, np.linspace(1.0, 0.8, 32).astype(np.float32))),
+    "lut_scale": (lambda md: md.set_lut(2.0 ** 30, np.linspace(1.0, 0.8, 32).astype(np.float32)),
+                  lambda md: md.set_lut(2.0 ** 31, np.linspace(1.0, 0.8, 32).astype(np.float32))),
+    "cfr": (lambda md: md.set_cfr(False), lambda md: md.set_cfr(True, 45.0, 0.2)),
+    "cfr_clip": (lambda md: md.set_cfr(True, 60.0, 0.1), lambda md: md.set_cfr(True, 45.0, 0.2)),
+    "tii": (lambda md: md.set_tii(True, 1, 2), lambda md: md.set_tii(True, 7, 9, True)),
+    "tii_with_cfr": (lambda md: (md.set_tii(True, 3, 5), md.set_cfr(True, 60.0, 0.1)),
+                     lambda md: (md.set_tii(True, 3, 5), md.set_cfr(True, 45.0, 0.2))),
+    "tii_with_taps": (lambda md: (md.set_tii(True, 3, 5), md.set_fir_taps(None)),
+                      lambda md: (md.set_tii(True, 3, 5), md.set_fir_taps(np.ones(13, np.float32) / 13))),
+    "output_format": (lambda md: md.set_output_format(None), lambda md: md.set_output_format("s16")),
+}
+
+
+@pytest.mark.parametrize("name", sorted(_TOGGLES))
+def test_every_setter_toggled_between_two_chain_calls_equals_a_fresh_context(pkg, name):
+    first, second = _TOGGLES[name]
+    # (the polynomial wants |x| < 1, i.e. the SDR-style normalisation; the s16 toggle wants integers worth comparing)
+    fmt_case = name == "output_format"
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | (0 if fmt_case else pkg.STAGE_POLY)
+    bits = np.stack([synth_bits(28800, seed=4100 + i) for i in range(2)])
+
+    def base(md):
+        md.set_gain(2, 1.0, 0.6 if fmt_case else 1.0 / 50000.0, 4.0)
+        md.set_resampler(2048000, 8192000)
+        md.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0])
+
+    a = pkg.Modulator(mode=1, max_frames=2)
+    b = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        base(a)
+        base(b)
+        first(a)
+        a.chain(bits, stages)
+        second(a)
+        ya = a.chain(bits, stages)
+        second(b)
+        if name.startswith("resampler"):
+            # (set_resampler resets the stream state by contract: the toggled context starts a new stream too)
+            yb = b.chain(bits, stages)
+            assert np.array_equal(ya, yb), name
+        else:
+            # the same two batches through a context that only ever saw the second value: equal stream history (TII frame
+            # parity), and frame 1 of the batch lies beyond the reach of the resampler's two-hop halo of the call before
+            b.chain(bits, stages)
+            yb = b.chain(bits, stages)
+            assert ya.dtype == yb.dtype and ya.shape == yb.shape and np.isfinite(ya.view(np.float32 if ya.dtype == np.complex64 else ya.dtype)).all()
+            assert np.abs(ya[1]).max() > 0 and np.array_equal(ya[1], yb[1]), name
+    finally:
+        a.close()
+        b.close()
+
+
 # --------------------------------------------------------------------------- edge cases
 def test_size_checks_raise_like_the_reference(mods, pkg):
     md = mods[1]
@@ -1408,3 +1476,41 @@ def test_async_host_path_with_s16_output(pkg):
     finally:
         sync.close()
         asyn.close()
+
+
+def test_num_clipped_never_answers_for_an_earlier_call(pkg):
+    """dabgpu_get_num_clipped is the count of the MOST RECENT chain call: zero after a complexf call (not the previous
+    formatted call's count), the synchronous call's own count after a collect, and the count of the format a batch was
+    SUBMITTED with even when the format setting changes before its collect."""
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=2300 + i) for i in range(2)])
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR
+    md = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        md.set_gain(2, 1.0, 4.0, 4.0)              # (normalise 4: a good share of the components saturates s16)
+        md.set_output_format("s16")
+        md.chain(bits, stages)
+        n_s16 = md.num_clipped()
+        assert n_s16 > 1000
+        md.set_output_format(None)
+        md.chain(bits, stages)                       # complexf: no FormatConverter in this call
+        assert md.num_clipped() == 0
+        # asynchronous batch submitted as s16, the setting changed before its collect
+        md.set_output_format("s16")
+        md.submit(bits, stages)
+        md.set_output_format(None)
+        got = md.collect()
+        assert md.num_clipped() == n_s16 and got.nbytes == 2 * 196608 * 4
+        # a device-path call after a collect answers for itself, not for the collected batch
+        import torch
+        d_bits = torch.from_numpy(bits).cuda()
+        d_out = torch.empty((2, md.out_samples_per_frame(stages)), dtype=torch.complex64, device="cuda")
+        md.chain_dev(d_bits, 2, stages, d_out)
+        assert md.num_clipped() == 0
+        d_car = torch.zeros((2, 77 * 1536), dtype=torch.complex64, device="cuda")
+        md.submit(bits, stages)
+        md.collect()
+        md.symbols_dev(d_car, 2, stages, d_out)
+        assert md.num_clipped() == 0
+    finally:
+        md.close()
