@@ -796,6 +796,8 @@ DabGpuChain::DabGpuChain(const Settings &s)
     dabgpu_geometry g;
     m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
     m_in_bytes = g.tf_input_bytes;
+    if (s.emulatePipelineDrops > 3) throw std::runtime_error("DabGpuChain: emulatePipelineDrops is 0 ... 3");
+    m_drops = s.emulatePipelineDrops;
     if (s.enableGain) {
         m_mask |= DABGPU_STAGE_GAIN;
         m_ctx.check(dabgpu_set_gain(m_ctx.get(), static_cast<int>(s.gainMode), s.digitalGain, s.normalise,
@@ -866,6 +868,8 @@ size_t DabGpuChain::collect(const void **iq)
     return n;
 }
 
+size_t DabGpuChain::output_bytes_per_frame() const { return dabgpu_chain_out_bytes_per_frame(m_ctx.get(), m_mask); }
+
 size_t DabGpuChain::get_num_clipped_samples() const
 {
     size_t n = 0;
@@ -877,9 +881,22 @@ int DabGpuChain::process(Buffer *const dataIn, Buffer *dataOut)
 {
     if (dataIn->getLength() != m_in_bytes)
         throw std::runtime_error("DabGpuChain::process input size not valid!");
+    const Buffer *in = dataIn;
+    Buffer oldest;
+    if (m_drops) {
+        // the reference's pipelined stages: this call's frame goes in, the frame of m_drops calls ago comes out
+        m_delayed.emplace_back(dataIn->getLength(), dataIn->getData());
+        if (m_delayed.size() <= m_drops) {
+            dataOut->setLength(0);
+            return 0;
+        }
+        oldest = std::move(m_delayed.front());
+        m_delayed.pop_front();
+        in = &oldest;
+    }
     dataOut->setLength(dabgpu_chain_out_bytes_per_frame(m_ctx.get(), m_mask));
     size_t n = 0;
-    m_ctx.check(dabgpu_chain_process(m_ctx.get(), static_cast<const uint8_t *>(dataIn->getData()), 1, m_mask,
+    m_ctx.check(dabgpu_chain_process(m_ctx.get(), static_cast<const uint8_t *>(in->getData()), 1, m_mask,
                                      dataOut->getData(), dataOut->getLength(), &n));
     dataOut->setLength(n);
     return static_cast<int>(n);

@@ -313,6 +313,18 @@ public:
         std::string outputFormat = "complexf";
         // frames per call of the streaming interface below (process() always takes one)
         size_t maxBatchFrames = 1;
+        // Compatibility with the reference's start-up behaviour (0 = off, the default: every frame comes out, with
+        // no latency).  Each PipelinedModCodec of the reference -- GainControl, FIRFilter, MemlessPoly -- returns the
+        // PREVIOUS frame and nothing on its first call (src/ModPlugin.cpp:90-115), so a reference flowgraph with k of
+        // them emits frame i - k on call i and N - k frames for N calls.  With emulatePipelineDrops = k, process() does
+        // the same: the first k calls return 0 (Flowgraph::run stops the walk, src/Flowgraph.cpp:334-336), call i
+        // returns frame i - k, the last k frames never leave.  referencePipelineDepth() is the k of the equivalent
+        // reference graph.
+        unsigned emulatePipelineDrops = 0;
+        unsigned referencePipelineDepth() const
+        {
+            return (enableGain ? 1u : 0u) + (filterTapsFilename.empty() ? 0u : 1u) + (polyCoefFilename.empty() ? 0u : 1u);
+        }
     };
     explicit DabGpuChain(const Settings &s);
     // Streaming interface for a caller that can look ahead (a file, a buffered network input): submit() queues
@@ -322,6 +334,7 @@ public:
     void submit(const void *bits, size_t n_frames);
     size_t collect(const void **iq);
     size_t input_bytes_per_frame() const { return m_in_bytes; }
+    size_t output_bytes_per_frame() const;
     int process(Buffer *const dataIn, Buffer *dataOut) override;
     const char *name() override { return "DabGpuChain"; }
     // FormatConverter::get_num_clipped_samples of the most recent frame (src/FormatConverter.cpp:56-59)
@@ -331,4 +344,6 @@ private:
     dabgpu_host::Context m_ctx;
     unsigned m_mask = 0;
     size_t m_in_bytes = 0;
+    unsigned m_drops = 0;                 // Settings::emulatePipelineDrops
+    std::deque<Buffer> m_delayed;         // the frames "inside the reference's pipeline"
 };

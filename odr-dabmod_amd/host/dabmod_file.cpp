@@ -17,12 +17,15 @@
 //   --tii comb,pattern   --cfr clip,errorclip
 //   --loop N             read the file N times
 //   --bits-only          stop after the front-end: write the hot path's input blocks (no GPU needed)
+//   --reference-latency  emit exactly the frames the reference emits: one transmission frame fewer per pipelined stage
+//                        of the equivalent reference graph (GainControl, FIRFilter, MemlessPoly: src/ModPlugin.cpp:90-115)
 #include "Frontend.h"
 #include "GpuStages.h"
 
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <deque>
 #include <fstream>
 #include <memory>
 #include <string>
@@ -34,7 +37,8 @@ namespace {
     std::fprintf(stderr, "usage: dabmod_file <in.eti> <out> [--mode N] [--format complexf|s16|u8|s8] [--gainmode var|fix|max]\n"
                          "       [--digital G] [--normalise X] [--var V] [--fir none|default|file] [--rate R] [--poly file]\n"
                          "       [--ofdmwindowing W] [--tii comb,pattern] [--cfr clip,errorclip] [--loop N] [--bits-only]\n"
-                         "       [--batch N]   N transmission frames per GPU call, two calls in flight (default 1: frame by frame)\n");
+                         "       [--batch N]   N transmission frames per GPU call, two calls in flight (default 1: frame by frame)\n"
+                         "       [--reference-latency]   drop the frames the reference's pipelined stages never emit\n");
     std::exit(2);
 }
 }  // namespace
@@ -50,6 +54,7 @@ int main(int argc, char **argv)
     int loops = 1;
     bool bits_only = false;
     size_t batch = 1;
+    bool reference_latency = false;
     try {
         for (int i = 3; i < argc; ++i) {
             const std::string a = argv[i];
@@ -82,6 +87,7 @@ int main(int argc, char **argv)
             else if (a == "--loop") loops = std::atoi(val().c_str());
             else if (a == "--bits-only") bits_only = true;
             else if (a == "--batch") batch = std::max<size_t>(1, std::stoul(val()));
+            else if (a == "--reference-latency") reference_latency = true;
             else usage();
         }
 
@@ -104,10 +110,13 @@ int main(int argc, char **argv)
         uint8_t frame[6144];
         size_t n_eti = 0, n_tf = 0, clipped = 0;
         std::vector<uint8_t> pending;             // --batch: hot-path input of the batch being filled
+        std::deque<std::vector<uint8_t>> held;    // --batch with --reference-latency: the frames "inside the pipeline"
+        size_t n_out = 0;                         // transmission frames written
         int in_flight = 0;
         auto drain_one = [&]() {
             const void *p = nullptr;
             const size_t n = chain->collect(&p);
+            n_out += n / chain->output_bytes_per_frame();
             if (format != "complexf") clipped += chain->get_num_clipped_samples();
             out.write(static_cast<const char *>(p), static_cast<std::streamsize>(n));
             --in_flight;
@@ -140,6 +149,13 @@ int main(int argc, char **argv)
                         pending.reserve(batch * bits.getLength());
                     }
                     const uint8_t *b = static_cast<const uint8_t *>(bits.getData());
+                    if (reference_latency) {
+                        // frame i is modulated when frame i + k has arrived; the last k frames never are (see --reference-latency)
+                        held.emplace_back(b, b + bits.getLength());
+                        if (held.size() <= gs.referencePipelineDepth()) continue;
+                        pending.insert(pending.end(), held.front().begin(), held.front().end());
+                        held.pop_front();
+                    } else
                     pending.insert(pending.end(), b, b + bits.getLength());
                     if (pending.size() == batch * chain->input_bytes_per_frame()) {
                         if (in_flight == 2) { drain_one(); }
@@ -153,10 +169,12 @@ int main(int argc, char **argv)
                     // the output format is the chain's own last step (stored by its last kernel for s16); the
                     // stand-alone FormatConverter plugin stays available with --separate-converter
                     if (!separate_converter) gs.outputFormat = format;
+                    if (reference_latency) gs.emulatePipelineDrops = gs.referencePipelineDepth();
                     chain.reset(new DabGpuChain(gs));
                     if (separate_converter && format != "complexf") converter.reset(new FormatConverter(false, format));
                 }
-                chain->process(&bits, &iq);
+                if (chain->process(&bits, &iq) == 0) continue;       // (a frame inside the emulated pipeline: nothing yet)
+                ++n_out;
                 const Buffer *o = &iq;
                 if (converter) {
                     converter->process(&iq, &converted);
@@ -182,10 +200,11 @@ int main(int argc, char **argv)
             }
             while (in_flight) drain_one();
         }
-        std::fprintf(stderr, "dabmod_file: %zu ETI frames -> %zu transmission frames (mode %u)", n_eti, n_tf, gs.dabMode);
+        if (bits_only) n_out = n_tf;
+        std::fprintf(stderr, "dabmod_file: %zu ETI frames -> %zu transmission frames in, %zu out (mode %u)", n_eti, n_tf, n_out, gs.dabMode);
         if (format != "complexf") std::fprintf(stderr, ", %zu clipped components", clipped);
         std::fprintf(stderr, "\n");
-        std::printf("%zu %zu\n", n_eti, n_tf);
+        std::printf("%zu %zu %zu\n", n_eti, n_tf, n_out);
         return 0;
     } catch (const std::exception &e) {
         std::fprintf(stderr, "dabmod_file: %s\n", e.what());

@@ -169,7 +169,7 @@ def test_dabmod_file_front_end_only(tmp_path, fe_mod, layout):
     _write_eti(fin, eti, layout)
     r = subprocess.run([TOOL, fin, fout, "--bits-only"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
-    assert r.stdout.split() == [str(c["nframes"]), str(GOLD["eti_cfg1"]["blocks"])]
+    assert r.stdout.split() == [str(c["nframes"])] + [str(GOLD["eti_cfg1"]["blocks"])] * 2
     assert ("Input file format: " + layout.split("+")[-1]) in r.stderr
     import hashlib
     assert hashlib.sha256(open(fout, "rb").read()).hexdigest() == GOLD["eti_cfg1"]["sha256"]

@@ -162,7 +162,7 @@ def test_config1_eti_file_to_iq_file(tmp_path, fmt):
     tool = os.path.join(HOST, "dabmod_file")
     r = subprocess.run([tool, fin, fout, "--format", fmt], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0, r.stderr
-    assert r.stdout.split() == ["24", "6"]
+    assert r.stdout.split() == ["24", "6", "6"]
     bits = fe_mod.Frontend().eti_to_bits(eti, 1)
     ref = O.Chain(mode=1, stages=O.STAGE_GAIN, gain_mode=2, normalise=1.0).process(bits)
     if fmt == "complexf":
@@ -270,7 +270,7 @@ def test_dabmod_file_batched_pipeline_equals_frame_by_frame(tmp_path, fmt):
         r = subprocess.run([tool, fin, fout, "--format", fmt, "--fir", "default", "--digital", "2.5"] + extra,
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
-        assert r.stdout.split() == ["44", "11"]
+        assert r.stdout.split() == ["44", "11", "11"]
         outs.append(np.fromfile(fout, dtype=np.uint8))
         m = re.search(r"(\d+) clipped components", r.stderr)
         clips.append(int(m.group(1)) if m else None)
@@ -279,3 +279,34 @@ def test_dabmod_file_batched_pipeline_equals_frame_by_frame(tmp_path, fmt):
     assert clips[0] == clips[1] == clips[2]
     if fmt == "s16":
         assert clips[0] > 0                                  # digital gain 2.5 at normalise 1: the counter is exercised
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("batch", [1, 4])
+def test_dabmod_file_reference_latency_emits_the_reference_frame_count(tmp_path, batch):
+    """SURVEY section 0 fact 7 / 8(d) config 1 ("Expected: N/4 - 1 TFs"): every PipelinedModCodec of the reference drops one
+    transmission frame at start-up (src/ModPlugin.cpp:90-115) -- 40 ETI frames = 10 TFs in give 9 TFs out with GainControl
+    only, 8 with FIRFilter as well, 7 with MemlessPoly on top (measured on the reference build).  With
+    --reference-latency (DabGpuChain::Settings::emulatePipelineDrops) dabmod_file writes exactly those frames: the
+    FIRST N - k of the frames it writes without the switch."""
+    from tests.golden.synth import synth_eti
+    build_host()
+    eti = synth_eti(40)
+    fin = str(tmp_path / "in.eti")
+    eti.tofile(fin)
+    import oracle as O
+    coef = str(tmp_path / "poly.coef")
+    O.write_poly_file(coef, POLY_AM, POLY_PM)
+    tool = os.path.join(HOST, "dabmod_file")
+    cases = [([], 9), (["--fir", "default"], 8),
+             (["--fir", "default", "--rate", "8192000", "--poly", coef, "--normalise", str(1.0 / 50000.0)], 7)]
+    for opts, want in cases:
+        files = []
+        for lat in ([], ["--reference-latency"]):
+            fout = str(tmp_path / ("out_%d_%d.iq" % (want, len(lat))))
+            r = subprocess.run([tool, fin, fout, "--batch", str(batch)] + opts + lat, capture_output=True, text=True, timeout=300)
+            assert r.returncode == 0, r.stderr
+            assert r.stdout.split() == ["40", "10", str(want if lat else 10)], r.stdout
+            files.append(np.fromfile(fout, dtype=np.uint8))
+        per = files[0].size // 10
+        assert files[1].size == want * per and np.array_equal(files[1], files[0][:want * per])
