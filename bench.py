@@ -58,12 +58,15 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(workload, seconds_budget=14.0):
-    """The oracle's chain (kind "port": the -O3 -march=native build of oracle/dab_oracle.c with fp32 radix-4
-    transforms, liboracle_fast.so) timed on a bounded sample of the same workload, in the shape SURVEY 8(d) asks for:
-    (i) ONE stream in the reference's threading model -- modulator thread + one thread per PipelinedModCodec
-    (GainControl, FIRFilter, MemlessPoly), MemlessPoly split over further workers (src/ModPlugin.cpp:90-154);
-    (ii) S = cores / 4 such streams side by side (`value`); and the plain single-thread figure."""
+def cpu_baseline(workload, seconds_budget=16.0):
+    """The oracle's chain (kind "port": the -O3 -march=native build of oracle/dab_oracle.c, liboracle_fast.so, with fp32
+    transforms -- FFTW3f when the host has libfftw3f.so.3, else the file's own radix-4 Stockham; `fft` says which) timed on
+    a bounded sample of the same workload.  `value` is the host's best: C independent single-thread streams side by side
+    (C = the cores this process may use), or -- if that ever wins -- cores/4 streams in the reference's threading model.
+    Next to it, as SURVEY 8(d) asks: ONE stream in the reference's threading model (modulator thread + one thread per
+    PipelinedModCodec -- GainControl, FIRFilter, MemlessPoly --, MemlessPoly split over further workers,
+    src/ModPlugin.cpp:90-154), cores/4 such streams, and one plain thread.  Only frames that REACH the output are counted
+    (a pipelined stage holds one frame back at the start of every call)."""
     import threading
     import numpy as np
     import oracle as O
@@ -76,7 +79,7 @@ def cpu_baseline(workload, seconds_budget=14.0):
     else:
         kw.update(stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000,
                   am=(1.0, 0.05, -0.01, 0.002, 0.0), pm=(0.0, 0.02, 0.003, 0.0, 0.0))
-    nb = 8
+    nb = 32                    # frames per call: the pipelined model's start-up (threads, held-back frames) amortised
     bits = np.stack([synth_bits(28800, seed=500 + i) for i in range(nb)])
     cores = max(1, len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1))
     try:                                   # a container's CPU quota, when there is one (cgroup v2)
@@ -89,7 +92,7 @@ def cpu_baseline(workload, seconds_budget=14.0):
     poly_threads = 0 if workload != "cfg4" else max(1, min(8, cores // nstreams - 3))
 
     def timed_run(nthreads, seconds, pipelined):
-        """nthreads independent streams, each looping 8-frame calls until the deadline; frames in / elapsed."""
+        """nthreads independent streams, each looping nb-frame calls until the deadline; frames OUT / elapsed."""
         chains = [O.Chain(**kw) for _ in range(nthreads)]
         outs = [np.empty((nb, c.out_samples_per_tf), np.complex64) for c in chains]
         for c, o in zip(chains, outs):
@@ -102,10 +105,10 @@ def cpu_baseline(workload, seconds_budget=14.0):
             start.wait()
             while time.perf_counter() < deadline[0]:
                 if pipelined:
-                    chains[i].process_pipelined(bits, poly_threads, outs[i])
+                    done[i] += len(chains[i].process_pipelined(bits, poly_threads, outs[i]))
                 else:
                     chains[i].process(bits, outs[i])
-                done[i] += nb
+                    done[i] += nb
 
         threads = [threading.Thread(target=worker, args=(i,)) for i in range(nthreads)]
         for t in threads:
@@ -118,18 +121,26 @@ def cpu_baseline(workload, seconds_budget=14.0):
         dt = time.perf_counter() - t0
         return sum(done), dt
 
-    n1, dt1 = timed_run(1, 0.2 * seconds_budget, False)
-    np1, dtp1 = timed_run(1, 0.3 * seconds_budget, True)
-    nn, dtn = timed_run(nstreams, 0.5 * seconds_budget, True)
-    return {"value": round(nn / dtn, 3), "unit": "frames/s", "cores": cores, "kind": "port",
-            "streams": nstreams, "one_stream_reference_threading": round(np1 / dtp1, 3),
+    n1, dt1 = timed_run(1, 0.15 * seconds_budget, False)
+    nc, dtc = timed_run(cores, 0.35 * seconds_budget, False)
+    np1, dtp1 = timed_run(1, 0.2 * seconds_budget, True)
+    nn, dtn = timed_run(nstreams, 0.3 * seconds_budget, True)
+    all_cores, ref_model = nc / dtc, nn / dtn
+    return {"value": round(max(all_cores, ref_model), 3), "unit": "frames/s", "cores": cores, "kind": "port",
+            "fft": O.fft_engine(),
+            "value_is": "independent single-thread streams on every core" if all_cores >= ref_model
+                        else "cores/4 streams in the reference threading model",
+            "independent_streams_all_cores": round(all_cores, 3),
+            "reference_threading_streams": nstreams, "reference_threading_value": round(ref_model, 3),
+            "one_stream_reference_threading": round(np1 / dtp1, 3),
             "single_thread_value": round(n1 / dt1, 3), "cpu_model": cpu_model(),
-            "sample": "%d streams of the %s chain side by side, each in the reference's threading model (modulator "
-                      "thread + one thread per pipelined stage%s): %d Mode-I frames in %.1f s; one such stream: %d "
-                      "frames in %.1f s; one plain thread: %d frames in %.1f s (oracle/dab_oracle.c, "
-                      "-O3 -march=native, fp32 radix-4 transforms)"
-                      % (nstreams, workload, ", %d MemlessPoly workers" % poly_threads if poly_threads else "",
-                         nn, dtn, np1, dtp1, n1, dt1)}
+            "sample": "%s chain, Mode I, %d frames per call: %d single-thread streams side by side %d frames in %.1f s; "
+                      "%d streams in the reference's threading model (modulator thread + one thread per pipelined "
+                      "stage%s) %d frames out in %.1f s; one such stream %d frames out in %.1f s; one plain thread %d "
+                      "frames in %.1f s (oracle/dab_oracle.c, -O3 -march=native, fp32 transforms: %s)"
+                      % (workload, nb, cores, nc, dtc, nstreams,
+                         ", %d MemlessPoly workers" % poly_threads if poly_threads else "", nn, dtn, np1, dtp1, n1, dt1,
+                         O.fft_engine())}
 
 
 def free_port():
@@ -351,8 +362,8 @@ def main():
     achieved = algo * B / (kern_ms * 1e-3) / 1e9  # GB/s per GPU, per-launch HIP-event time
 
     # Profiler counters are not collected by this run: they are REPLAYED from profiles/traffic.json (rocprofv3 PMC passes
-    # of the same workload and batch, tools/profile_all.sh) -- and only while the device sources are the ones those
-    # counters were collected on (source hash); after any kernel change they are dropped until re-profiled.
+    # of the same workload and batch, tools/profile_all.sh + tools/make_traffic.py) -- and only while the device sources
+    # are the ones those counters were collected on (source hash); after any kernel change they are dropped until re-profiled.
     traffic, busy, replay = None, {}, None
     tp = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tp):
@@ -363,7 +374,9 @@ def main():
                 replay = "dropped: profiles/traffic.json was collected on other device sources (%s)" % tj.get("source_hash")
             elif t and t.get("frames") == B:
                 traffic = t.get("hbm_bytes_per_launch")
-                busy = {k: t[k] for k in ("valu_busy", "lds_busy") if k in t}
+                busy = {k: t[k] for k in ("valu_busy", "lds_busy", "hbm_frac", "packed_fraction_of_valu", "wave_active_frac",
+                                          "wave_issue_stall_frac", "wave_issue_stall_lds_frac", "wave_parked_frac",
+                                          "lds_bank_conflict_share") if k in t}
                 if t.get("gpu_cycles_per_launch_profiled"):
                     # the part is power-limited under this kernel: GRBM_GUI_ACTIVE / 8 XCDs over the launch time is
                     # the clock it actually ran at (2.4 GHz nominal)
@@ -373,6 +386,42 @@ def main():
                 replay = "dropped: no counters for %d frames per launch" % B
         except Exception:
             traffic, busy, replay = None, {}, "dropped: unreadable profiles/traffic.json"
+
+    # What limits the kernel, from those numbers (never a fixed string): a unit at >= 80 % is the limiter; otherwise no
+    # unit is saturated and the limiter is instruction ISSUE -- a SIMD retires one instruction at a time, VALU or LDS, so
+    # their times add (the sum of the per-instruction issue costs of the hot loop, profiles/isa_mix.json,
+    # reproduces the measured time per symbol) -- reported with the share of their life the waves spend stalled at issue.
+    def limiter_of(b):
+        if not b:
+            return "not profiled for this build"
+        units = {"valu": b.get("valu_busy", 0.0), "lds": b.get("lds_busy", 0.0), "hbm": b.get("hbm_frac", 0.0)}
+        top_unit = max(units, key=units.get)
+        if units[top_unit] >= 0.8:
+            return "%s (%.0f %% busy)" % (top_unit, 100 * units[top_unit])
+        return ("instruction issue: no unit saturated (valu %.0f %%, lds %.0f %%, hbm %.0f %% -- valu + lds = %.0f %% of the "
+                "SIMD time, they do not overlap); waves stalled at issue %.0f %% of their life (%.0f %% on the LDS path), parked "
+                "at s_waitcnt / s_barrier %.0f %%"
+                % (100 * units["valu"], 100 * units["lds"], 100 * units["hbm"], 100 * (units["valu"] + units["lds"]),
+                   100 * b.get("wave_issue_stall_frac", 0.0), 100 * b.get("wave_issue_stall_lds_frac", 0.0),
+                   100 * b.get("wave_parked_frac", 0.0)))
+
+    # the static issue-time model of the hot loop next to the measured time per loop iteration (profiles/isa_mix.json)
+    issue = None
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+        m = mj.get(args.workload)
+        if m and mj.get("source_hash") == P.source_hash() and busy.get("effective_clock_GHz"):
+            # iterations per launch per SIMD: cfg 2/3 -- 77 symbols x 4 waves per frame, cfg 4 -- 96 hops x 8 waves
+            per_frame = 96 * 8 if args.workload == "cfg4" else 77 * 4
+            measured = busy["effective_clock_GHz"] * 1e9 * kern_ms * 1e-3 * 1024 / (B * per_frame)
+            if args.workload == "cfg4":
+                measured *= 0.885          # (the resampler's share of the two-kernel launch, profiles/)
+            issue = {"model_simd_ticks_per_wave_iteration": m["issue_model_simd_ticks"],
+                     "measured_simd_cycles_per_wave_iteration": round(measured, 1),
+                     "model_over_measured": round(m["issue_model_simd_ticks"]["total"] / measured, 3),
+                     "iteration": m["loop_iteration"]}
+    except Exception:
+        issue = None
 
     # this box's own ceilings next to the nominal 8 TB/s: a fill (write only) and a copy (read + write) over 4 GiB
     def measured_peaks():
@@ -419,12 +468,12 @@ def main():
                    "residency": "input and output device-resident (no PCIe in the timed region); the host entry points "
                                 "are PCIe-bound, see DESIGN.md section 6"},
         # "bound": the roofline the fraction is priced against (HBM).  "limiter": what the counters say
-        # actually limits the kernel -- VALU issue and LDS traffic, both about half busy, not HBM.
+        # actually limits the kernel (limiter_of above).
         "roofline": {"bound": "hbm", "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS,
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "kernel": "tf_kernel" if args.workload != "cfg4" else "tf_kernel+resampler_kernel",
                      "algorithmic_bytes_per_frame": algo, "kernel_ms_per_launch": round(kern_ms, 4), **busy,
-                     "limiter": "valu+lds (latency-bound mix; see valu_busy / lds_busy)" if busy else "not profiled for this build",
+                     "limiter": limiter_of(busy), "issue_model": issue,
                      "counters_source": replay},
     }
     if rank == 0 and world == 1 and not args.no_extra:

@@ -128,6 +128,7 @@ struct dabgpu_ctx {
     float rs_factor = 1.f;
     // scratch
     DevBuf d_a, d_b, d_c, d_in, d_out, d_count, d_fmt, d_clip;
+    DevBuf d_phase;                        // tool builds only (-DDABGPU_PHASE_TIMING): the frame kernel's per-phase cycle counters
     hipStream_t clip_stream = nullptr;     // stream of the most recent chain call that converted its output
     // TII (f-4): carrier set, the one-frame carrier image and its native-rate response, gain of symbol 1
     DevBuf d_acp, d_tii_car, d_tii_frame, d_gain1, d_cic;
@@ -150,7 +151,6 @@ struct dabgpu_ctx {
     Settings cur;                    // snapshot used by the processing thread
     unsigned long long applied_epoch = 0;
 
-    hipEvent_t ev0 = nullptr, ev1 = nullptr;
 
     // asynchronous host path (dabgpu_chain_submit / dabgpu_chain_collect): two batches in flight,
     // pinned staging on both sides, device->host copies on their own stream
@@ -671,6 +671,9 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
 {
     TfArgs a{};
     a.clipped = s16_clipped;
+#ifdef DABGPU_PHASE_TIMING
+    a.phase_cycles = (unsigned long long *)c->d_phase.p;
+#endif
     a.g = c->g;
     a.t = tables_of(c);
     a.gain = gain_of(c);
@@ -1022,8 +1025,11 @@ int dabgpu_create(const dabgpu_config *cfg, dabgpu_ctx **out)
     };
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) return bail(hip_fail(c, e, "hipStreamCreate"));
-    (void)hipEventCreate(&c->ev0);
-    (void)hipEventCreate(&c->ev1);
+#ifdef DABGPU_PHASE_TIMING
+    if (c->d_phase.reserve(16 * sizeof(unsigned long long)) != hipSuccess ||
+        hipMemset(c->d_phase.p, 0, 16 * sizeof(unsigned long long)) != hipSuccess)
+        return bail(fail(c, DABGPU_E_DEVICE, "phase counters"));
+#endif
     // the fused kernel uses up to ~40 KiB of dynamic LDS; nothing to opt in on gfx950 (<= 64 KiB)
     int rc = build_tables(c);
     if (rc) return bail(rc);
@@ -1041,7 +1047,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (c->stream) (void)hipStreamSynchronize(c->stream);
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh, &c->d_eqg,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
-                      &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count, &c->d_fmt, &c->d_clip,
+                      &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count, &c->d_fmt, &c->d_clip, &c->d_phase,
                       &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1, &c->d_cic,
                       &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();
@@ -1056,8 +1062,6 @@ void dabgpu_destroy(dabgpu_ctx *c)
     for (void *h : c->h_out)
         if (h) (void)hipHostFree(h);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
-    if (c->ev0) (void)hipEventDestroy(c->ev0);
-    if (c->ev1) (void)hipEventDestroy(c->ev1);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
 }
@@ -1718,5 +1722,18 @@ int dabgpu_synchronize(dabgpu_ctx *c)
     HIPCHK(c, hipStreamSynchronize(c->stream));
     return DABGPU_OK;
 }
+
+#ifdef DABGPU_PHASE_TIMING
+// tool builds only (tools/phase_timing.py): the frame kernel's per-phase shader-cycle sums since the last call, 16 words
+// (Phase order of device_common.h; word 15 = wave-iterations behind the sums); zeroes them
+DABGPU_API int dabgpu_debug_phase_cycles(dabgpu_ctx *c, unsigned long long *out16)
+{
+    CTXCHK(c);
+    HIPCHK(c, hipDeviceSynchronize());
+    HIPCHK(c, hipMemcpy(out16, c->d_phase.p, 16 * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    HIPCHK(c, hipMemset(c->d_phase.p, 0, 16 * sizeof(unsigned long long)));
+    return DABGPU_OK;
+}
+#endif
 
 }  // extern "C"

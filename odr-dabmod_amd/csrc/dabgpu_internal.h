@@ -66,6 +66,9 @@ struct TfArgs {
     unsigned long long *clipped;
     // TF_WINDOW: raised-cosine overlap of the guard interval (t.window holds the 2 * overlap factors)
     int overlap;
+    // tool builds only (-DDABGPU_PHASE_TIMING, tools/phase_timing.py): 16 counters the symbol loop adds its per-phase
+    // shader cycles to; nullptr (and ignored) in the product
+    unsigned long long *phase_cycles;
 };
 
 enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */,

@@ -28,6 +28,48 @@ DEV void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "m
 DEV void lds_barrier_vm() { asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 DEV void xbarrier() { lds_barrier(); }       // the barriers of the FFT exchanges
 
+// Per-phase cycle stamps of the frame kernel's symbol loop -- a TOOL build only (tools/phase_timing.py compiles a copy of
+// the library with -DDABGPU_PHASE_TIMING); in the product build PhaseTimer is an empty type and every stamp() compiles to
+// nothing.  A stamp drains the wave's outstanding LDS operations (their latency belongs to the phase that issued them),
+// reads s_memtime (shader cycles) and adds the time since the previous stamp to the phase's counter; sched_barrier keeps
+// the compiler from moving work across it.  The counters are wave-uniform (SGPRs); flush() adds them to a global array.
+// The samples a timing build produces are the product's (timing only, no arithmetic changes); it runs ~10 % slower.
+enum Phase { PH_INPUT = 0, PH_BUTTERFLY, PH_EXCHANGE, PH_GAIN_WINDOWS, PH_STORES, PH_BOUNDARY, PH_LOOP, PH_COUNT };
+#ifdef DABGPU_PHASE_TIMING
+struct PhaseTimer {
+    unsigned long long last, acc[PH_COUNT];
+    DEV void begin()
+    {
+#pragma unroll
+        for (int i = 0; i < PH_COUNT; ++i) acc[i] = 0;
+        last = __builtin_amdgcn_s_memtime();
+    }
+    DEV void stamp(int phase)
+    {
+        __builtin_amdgcn_sched_barrier(0);
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        const unsigned long long now = __builtin_amdgcn_s_memtime();
+        acc[phase] += now - last;
+        last = now;
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    DEV void flush(unsigned long long *out, unsigned iterations)
+    {
+        if (out && (threadIdx.x & 63) == 0) {
+#pragma unroll
+            for (int i = 0; i < PH_COUNT; ++i) atomicAdd(out + i, acc[i]);
+            atomicAdd(out + 15, (unsigned long long)iterations);      // wave-iterations behind the sums
+        }
+    }
+};
+#else
+struct PhaseTimer {
+    DEV void begin() {}
+    DEV void stamp(int) {}
+    DEV void flush(unsigned long long *, unsigned) {}
+};
+#endif
+
 DEV cf mk(float x, float y) { return make_float2(x, y); }
 // One-instruction square root / reciprocal (v_sqrt_f32, v_rcp_f32: 1 ulp).  The per-symbol gain is a wave-uniform
 // scalar that every lane computes for itself; the correctly rounded sqrtf and division expand to ~17 and ~10
@@ -340,8 +382,9 @@ template <int LOGN> struct Fft {
     // template argument, not a test of the pointer: a pointer into the dynamic LDS block is never provably non-null,
     // and the run-time test costs a scalar branch per twiddle.
     template <int S, bool DBUF, typename V, bool U8>
-    static DEV void run(V *v, V *lds2, int &par, const cf *tw, int t, const cf *tw8 = nullptr)
+    static DEV void run(V *v, V *lds2, int &par, const cf *tw, int t, const cf *tw8 = nullptr, PhaseTimer *pt = nullptr)
     {
+#define DABGPU_STAMP(PH) do { if (pt) pt->stamp(PH); } while (0)
 #define DABGPU_NEXT_BUF (lds2 + ((DBUF && (par ^= 1)) ? LDS_ELEMS : 0))
         int n = 0;
         cf w[7];
@@ -353,21 +396,29 @@ template <int LOGN> struct Fft {
             for (int r = 0; r < 7; ++r) w[r] = twid<S>(tw8[r * 8 + (t & 7)]);
         }
         dft8<S>(v);
+        DABGPU_STAMP(PH_BUTTERFLY);
         exchange<1, DBUF, V>(v, DABGPU_NEXT_BUF, t);
+        DABGPU_STAMP(PH_EXCHANGE);
         if (NR8 >= 2) {
             if (EARLY8) n += 7; else stage_twiddles<S>(tw, n, w);
             twiddle_dft8<S>(v, w);
+            DABGPU_STAMP(PH_BUTTERFLY);
             if (NR8 > 2 || RF > 1) exchange<8, DBUF, V>(v, DABGPU_NEXT_BUF, t);
+            DABGPU_STAMP(PH_EXCHANGE);
         }
         if (NR8 >= 3) {
             stage_twiddles<S>(tw, n, w);
             twiddle_dft8<S>(v, w);
+            DABGPU_STAMP(PH_BUTTERFLY);
             if (NR8 > 3 || RF > 1) exchange<64, DBUF, V>(v, DABGPU_NEXT_BUF, t);
+            DABGPU_STAMP(PH_EXCHANGE);
         }
         if (NR8 >= 4) {
             stage_twiddles<S>(tw, n, w);
             twiddle_dft8<S>(v, w);
+            DABGPU_STAMP(PH_BUTTERFLY);
             if (RF > 1) exchange<512, DBUF, V>(v, DABGPU_NEXT_BUF, t);
+            DABGPU_STAMP(PH_EXCHANGE);
         }
         if (RF == 4) {
 #pragma unroll
@@ -386,6 +437,8 @@ template <int LOGN> struct Fft {
                 v[b + 4] = csub(x0, x1);
             }
         }
+        DABGPU_STAMP(PH_BUTTERFLY);
+#undef DABGPU_STAMP
 #undef DABGPU_NEXT_BUF
     }
 

@@ -700,8 +700,14 @@ void tf_kernel(const TfArgs a)
         s_loop = 1;
     }
 
+    // (per-phase cycle stamps: an empty type unless the library is a -DDABGPU_PHASE_TIMING tool build, see device_common.h)
+    PhaseTimer pt;
+    unsigned pt_iterations = 0;
+    pt.begin();
     for (int s = s_loop; s < s_stop; ++s) {
         if (FROM_BITS) __builtin_assume(s >= 1);    // (the blank null symbol was peeled off above)
+        pt.stamp(PH_LOOP);
+        ++pt_iterations;
         const bool lookahead = s >= s_end;      // FIR / WIN only: no output for this symbol
         cf val[6], v[8];
         uint32_t pf = 0u;
@@ -782,7 +788,8 @@ void tf_kernel(const TfArgs a)
                 for (int c = 0; c < 6; ++c) val[c] = cmul(val[c], hk[c]);
             }
             place(val, v);
-            F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
+            pt.stamp(PH_INPUT);
+            F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l, &pt);
             if (CFR) {
                 cf refv[8];
                 place(val, refv);
@@ -866,6 +873,7 @@ void tf_kernel(const TfArgs a)
             if (t >= T - kEqQL) zp_new[t - (T - kEqQL)] = v[7];
             if (t <= kEqQH) zp_new[kEqQL + t] = v[0];
             lds_barrier();
+            pt.stamp(PH_GAIN_WINDOWS);
             // (the boundary outputs follow the symbol's own stores, below: its samples are dead registers by then)
         } else if constexpr (WIN && FIR) {
             // ---- windowed seam AND look-ahead filter: the C + 2W outputs whose 45 samples touch the seam ----
@@ -983,9 +991,11 @@ void tf_kernel(const TfArgs a)
                 if ((m > m_cp || (m == m_cp && n >= N - cpl)) && (!WIN || n - (N - cpl) >= W)) put(pos, n - (N - cpl), y);
             }
         }
+        pt.stamp(PH_STORES);
         if constexpr (EQ) {
             if (have_prev) eq_boundary(eq_zp + cur * kEqW);
             cur ^= 1;
+            pt.stamp(PH_BOUNDARY);
             if (lookahead) break;
         }
         have_prev = true;
@@ -1015,6 +1025,7 @@ void tf_kernel(const TfArgs a)
         boundary(bnd + cur * 2 * KB);
     }
     if (OFMT == 1) s16_flush_count(nclip, a.clipped);
+    pt.flush(a.phase_cycles, pt_iterations);
 }
 
 template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)

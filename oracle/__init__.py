@@ -121,6 +121,8 @@ def _load(name):
     lib.dabo_chain_cfr_stats.restype = C.POINTER(_CfrStats)
     lib.dabo_dft_f64.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_double), C.c_size_t, C.c_int]
     lib.dabo_dft_f64.restype = None
+    if hasattr(lib, "dabo_fft_engine"):                    # the baseline build only (-DDABO_FAST)
+        lib.dabo_fft_engine.restype = C.c_char_p
     if hasattr(lib, "dabo_chain_process_pipelined"):      # the baseline build only (-DDABO_FAST)
         lib.dabo_chain_process_pipelined.argtypes = [C.c_void_p, _U8P, C.c_size_t, C.c_int, _FP,
                                                      C.POINTER(C.c_size_t)]
@@ -138,10 +140,28 @@ def lib():
     return _lib
 
 
+def fft_engine():
+    """Transform engine of the CPU-baseline build: "fftw3f" (libfftw3f.so.3 found at run time) or "port"."""
+    return fast_lib().dabo_fft_engine().decode()
+
+
 def fast_lib():
     """-O3 -march=native build of the same source, for the timed CPU baseline."""
     global _fast
     if _fast is None:
+        # -march=native: the library is only good on the CPU model it was compiled on.  A copy that travelled from another
+        # host (the build container -> the GPU box) is rebuilt here before it is loaded.
+        stamp = os.path.join(_DIR, "liboracle_fast.host")
+        try:
+            here = next(l for l in open("/proc/cpuinfo") if l.startswith("model name"))
+        except (OSError, StopIteration):
+            here = "unknown\n"
+        built_on = open(stamp).read() if os.path.exists(stamp) else None
+        if built_on != here:
+            try:
+                subprocess.check_call(["make", "-s", "-B", "-C", _DIR, "liboracle_fast.so"])
+            except (OSError, subprocess.CalledProcessError):
+                pass                      # (no compiler here: load what there is)
         _fast = _load("liboracle_fast.so")
     return _fast
 

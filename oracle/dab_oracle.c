@@ -316,8 +316,82 @@ static const float *fast_twiddles(size_t n)
     return g_ftw[lg];
 }
 
+/* FFTW3f engine of the baseline build, when the host has it: the reference's own transform library
+ * (src/OfdmGenerator.cpp:106-117, src/Resampler.cpp:94-108: fftwf_plan_dft_1d(..., FFTW_MEASURE), fftwf_execute).  Not a
+ * link-time dependency -- libfftw3f.so.3 is looked for at run time (DABO_FFTW=0 in the environment skips the search), and
+ * the few prototypes used are declared here.  dabo_fft_engine() says which engine the baseline ran on. */
+#include <dlfcn.h>
+#include <pthread.h>
+typedef float fftwf_cpx_[2];
+typedef void *(*fftwf_plan_fn_)(int, fftwf_cpx_ *, fftwf_cpx_ *, int, unsigned);
+typedef void (*fftwf_exec_fn_)(void *, fftwf_cpx_ *, fftwf_cpx_ *);
+static struct {
+    int tried;
+    void *lib;
+    fftwf_plan_fn_ plan;
+    fftwf_exec_fn_ exec;
+    void *plans[32][2];
+    pthread_mutex_t mu;
+} g_fftw = {0, NULL, NULL, NULL, {{NULL}}, PTHREAD_MUTEX_INITIALIZER};
+
+static void fftw_try_load(void)
+{
+    pthread_mutex_lock(&g_fftw.mu);
+    if (!g_fftw.tried) {
+        const char *e = getenv("DABO_FFTW");
+        if (!e || strcmp(e, "0") != 0) {
+            void *h = dlopen("libfftw3f.so.3", RTLD_NOW | RTLD_LOCAL);
+            if (!h) h = dlopen("libfftw3f.so", RTLD_NOW | RTLD_LOCAL);
+            if (h) {
+                g_fftw.plan = (fftwf_plan_fn_)dlsym(h, "fftwf_plan_dft_1d");
+                g_fftw.exec = (fftwf_exec_fn_)dlsym(h, "fftwf_execute_dft");
+                if (g_fftw.plan && g_fftw.exec) g_fftw.lib = h;
+            }
+        }
+        g_fftw.tried = 1;
+    }
+    pthread_mutex_unlock(&g_fftw.mu);
+}
+
+const char *dabo_fft_engine(void)
+{
+    fftw_try_load();
+    return g_fftw.lib ? "fftw3f" : "port";
+}
+
+/* plan for (n = 2^lg, sign), created once (planning is not thread-safe, executing a plan on new arrays is):
+ * FFTW_MEASURE as the reference plans, FFTW_UNALIGNED because the plan runs on the callers' arrays */
+static void *fftw_plan_for(int lg, int sign)
+{
+    const int si = sign > 0 ? 1 : 0;
+    void *p = __atomic_load_n(&g_fftw.plans[lg][si], __ATOMIC_ACQUIRE);
+    if (p) return p;
+    pthread_mutex_lock(&g_fftw.mu);
+    p = g_fftw.plans[lg][si];
+    if (!p) {
+        const size_t n = (size_t)1 << lg;
+        fftwf_cpx_ *a = (fftwf_cpx_ *)calloc(n, sizeof(fftwf_cpx_)), *b = (fftwf_cpx_ *)calloc(n, sizeof(fftwf_cpx_));
+        if (a && b) p = g_fftw.plan((int)n, a, b, sign > 0 ? +1 : -1, /* FFTW_MEASURE */ 0u | /* FFTW_UNALIGNED */ (1u << 1));
+        free(a);
+        free(b);
+        __atomic_store_n(&g_fftw.plans[lg][si], p, __ATOMIC_RELEASE);
+    }
+    pthread_mutex_unlock(&g_fftw.mu);
+    return p;
+}
+
 static void dft_f32_fast(const float *in, float *out, size_t n, int sign, float *work)
 {
+    fftw_try_load();
+    if (g_fftw.lib && in != out) {
+        int lgn = 0;
+        while (((size_t)1 << lgn) < n) ++lgn;
+        void *p = fftw_plan_for(lgn, sign);
+        if (p) {
+            g_fftw.exec(p, (fftwf_cpx_ *)(uintptr_t)in, (fftwf_cpx_ *)out);     /* (out of place: the input is left alone) */
+            return;
+        }
+    }
     const float *tw = fast_twiddles(n);
     const float sg = sign > 0 ? 1.0f : -1.0f;
     int lg = 0;

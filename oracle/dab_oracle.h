@@ -195,6 +195,12 @@ int dabo_chain_process(dabo_chain *c, const uint8_t *bits, size_t nframes, float
  * papr (may be NULL) receives (nb_symbols+1) x 4 doubles */
 const dabo_cfr_stats *dabo_chain_cfr_stats(const dabo_chain *c, size_t f, double *papr);
 
+#ifdef DABO_FAST
+/* CPU-baseline build only: "fftw3f" when libfftw3f.so.3 was found at run time and carries the power-of-two transforms
+ * (the reference's own engine, src/OfdmGenerator.cpp:106-117), else "port" (the fp32 radix-4 Stockham of this file) */
+const char *dabo_fft_engine(void);
+#endif
+
 /* float64 unnormalised DFT used by a6/a10, exposed for tests: sign=+1 backward. */
 void dabo_dft_f64(const double *in_ri, double *out_ri, size_t n, int sign);
 

@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 import oracle as O
+from tests.conftest import ROOT
 from tests.receiver import dab_demodulate_mode1
 from tests.golden.synth import (LUT_SCALE, POLY_AM, POLY_PM, format_edges, format_input, lut_table, synth_bits,
                                 synth_signal)
@@ -351,3 +352,74 @@ def test_oracle_chain_decodes_through_an_independent_receiver():
                 fast=True).process(bits[:2])
     stream = y.reshape(-1)[4 * 2048::4]
     assert np.array_equal(dab_demodulate_mode1(stream[:196608], 44), bits[0])
+
+
+FAKE_FFTW = r"""
+/* test double of libfftw3f.so.3: the three entry points the baseline build looks up, over a plain float64 DFT */
+#include <math.h>
+#include <stdlib.h>
+typedef float cpx[2];
+typedef struct { int n, sign; } plan;
+void *fftwf_plan_dft_1d(int n, cpx *in, cpx *out, int sign, unsigned flags)
+{
+    (void)in; (void)out; (void)flags;
+    plan *p = malloc(sizeof *p);
+    p->n = n; p->sign = sign;
+    return p;
+}
+void fftwf_execute_dft(void *pp, cpx *in, cpx *out)
+{
+    const plan *p = pp;
+    const int n = p->n;
+    /* radix-2 decimation in time, float64, recursion-free: bit-reversed copy, then butterflies */
+    double *re = malloc(sizeof(double) * n), *im = malloc(sizeof(double) * n);
+    int lg = 0;
+    while ((1 << lg) < n) ++lg;
+    for (int i = 0; i < n; ++i) {
+        int r = 0;
+        for (int b = 0; b < lg; ++b) r |= ((i >> b) & 1) << (lg - 1 - b);
+        re[r] = in[i][0]; im[r] = in[i][1];
+    }
+    for (int len = 2; len <= n; len <<= 1) {
+        const double ang = (p->sign > 0 ? 2.0 : -2.0) * M_PI / len;
+        for (int i = 0; i < n; i += len)
+            for (int k = 0; k < len / 2; ++k) {
+                const double wr = cos(ang * k), wi = sin(ang * k);
+                const int a = i + k, b = i + k + len / 2;
+                const double tr = re[b] * wr - im[b] * wi, ti = re[b] * wi + im[b] * wr;
+                re[b] = re[a] - tr; im[b] = im[a] - ti;
+                re[a] += tr; im[a] += ti;
+            }
+    }
+    for (int i = 0; i < n; ++i) { out[i][0] = (float)re[i]; out[i][1] = (float)im[i]; }
+    free(re); free(im);
+}
+"""
+
+
+def test_cpu_baseline_build_picks_up_fftw3f_when_the_host_has_it(tmp_path):
+    """bench.py's CPU baseline runs on FFTW3f -- the reference's own transform library (src/OfdmGenerator.cpp:106-117)
+    -- when libfftw3f.so.3 is present, and says which engine it used.  The image has no FFTW, so the run-time lookup is
+    exercised against a test double on LD_LIBRARY_PATH: same frames within the float tolerance, engine reported."""
+    import json
+    import subprocess
+    import sys
+    src = tmp_path / "fake_fftw.c"
+    src.write_text(FAKE_FFTW)
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-o", str(tmp_path / "libfftw3f.so.3"), str(src), "-lm"])
+    code = ("import sys, json, numpy as np; sys.path.insert(0, %r); import oracle as O\n"
+            "from tests.golden.synth import synth_bits\n"
+            "bits = synth_bits(28800, seed=77).reshape(1, -1)\n"
+            "y = O.Chain(mode=1, stages=15, gain_mode=2, normalise=1 / 50000., out_rate=8192000, fast=True).process(bits)\n"
+            "np.save(sys.argv[1], y); print(json.dumps({'engine': O.fft_engine()}))\n" % ROOT)
+    res = {}
+    for name, env in (("fftw", {"LD_LIBRARY_PATH": str(tmp_path)}), ("port", {"DABO_FFTW": "0", "LD_LIBRARY_PATH": str(tmp_path)}),
+                      ("absent", {})):
+        out = str(tmp_path / (name + ".npy"))
+        r = subprocess.run([sys.executable, "-c", code, out], env=dict(os.environ, **env), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        res[name] = (json.loads(r.stdout.strip().splitlines()[-1])["engine"], np.load(out))
+    assert res["fftw"][0] == "fftw3f" and res["port"][0] == "port" and res["absent"][0] == "port"
+    a, b = res["fftw"][1], res["port"][1]
+    assert np.linalg.norm(a - b) / np.linalg.norm(b) < 1e-6
+    assert np.array_equal(res["port"][1], res["absent"][1])
