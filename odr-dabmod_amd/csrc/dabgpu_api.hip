@@ -555,18 +555,15 @@ GainParams gain_of(const dabgpu_ctx *c)
 int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
 {
     if (c->chunks_cfg > 0) return c->chunks_cfg;
-    // One workgroup per frame once the batch alone fills the chip; below that frames are split into runs of
-    // symbols.  Every run pays a prologue (the differential state up to its first symbol, gathered from LDS-staged
-    // blocks) and, with FIR, one look-ahead transform, so the split stops at about three workgroups per CU -- the
-    // measured optimum (tools/sweep_chunks.py, Mode I): 768 / B runs for B >= 48, 13 ... 39 runs for a handful of
-    // frames, single symbols for one or two (latency, not efficiency, counts there: 18 us per Mode-I frame).
+    // One workgroup per frame once the batch alone fills the chip (1024 workgroups: four per CU); below that frames are
+    // split into runs of symbols so that the launch still has about 1024 of them.  Every run pays a prologue (the
+    // differential state up to its first symbol: a bit-sliced sum over the blocks before it, a few microseconds whatever
+    // the depth) and, with FIR, one look-ahead transform.  Measured optimum, Mode I (tools/sweep_chunks.py, round 3):
+    // 1024 / B runs down to B = 32, two symbols per run for 12 ... 31 frames, single symbols below (latency, not
+    // efficiency, counts there: 10 us per Mode-I frame).
     const int nsym = c->g.nb_symbols + 1;
     const size_t n = n_frames;
-    int want;
-    if (n >= 1024) want = 1;
-    else if (n >= 48) want = (int)((768 + n - 1) / n);
-    else if (n >= 3) want = std::min(39, std::max(13, (int)((256 + n - 1) / n)));
-    else want = nsym;
+    const int want = n >= 1024 ? 1 : (int)((1024 + n - 1) / n);
     return std::max(1, std::min(want, nsym));
 }
 

@@ -323,24 +323,59 @@ void tf_kernel(const TfArgs a)
     if (FROM_BITS) {
         // the loop below applies block s-2 on entering symbol s; bring the state to
         // "blocks 0 .. s_begin-3 applied"
-        // A chunk that starts deep inside the frame replays up to 74 blocks here.  Gathering their bits straight from
-        // global memory costs 12 scattered byte loads per lane and block -- 3500 load instructions per workgroup whose
-        // 64 lanes each touch their own byte: 27 of the 35 us of a one-frame launch went into the texture addresser.
-        // So the blocks are copied to LDS first (coalesced dwords into the exchange buffer, which is idle until the
-        // first transform) and the bytes are gathered from there, in slabs of as many blocks as the buffer holds.
+        // A chunk that starts deep inside the frame needs the sum (mod 4 quarter turns) of up to 74 blocks' increments for
+        // each of its carriers.  The sum is formed BIT-SLICED, 32 carriers per register: dword j of a block's I half and dword
+        // j of its Q half hold the bits of carriers 32 j .. 32 j + 31, the increment of a carrier is the 2-bit number
+        // (I ^ Q) + 2 Q, and a 2-bit counter per carrier kept as two bit planes (s0, s1) takes it with five bitwise operations
+        // for all 32 at once:  c = s0 & l;  s0 ^= l;  s1 ^= h ^ c.  K / 32 lanes cover a block, the workgroup's lanes form
+        // as many groups of them as fit, group g walks blocks g, g + NG, ... straight from global memory (coalesced dwords,
+        // all loads independent), the groups' counters are added through LDS, and every lane then picks its six carriers'
+        // two bits out of the planes.  (Round 2 replayed the blocks one by one through the symbol loop's gather -- 12 LDS byte
+        // reads and ~50 instructions per lane and block, up to 74 times: most of a small batch's time.)
         {
             const int nblk = s_begin - 2;                        // blocks 0 .. s_begin - 3
-            uint32_t *stage = reinterpret_cast<uint32_t *>(fbuf);
-            constexpr int kBlkWords = K / 16;                    // K / 4 bytes per block
-            constexpr int kSlab = (kXElems * (int)sizeof(cf)) / (kBlkWords * 4);
-            static_assert(kSlab >= 1, "the exchange buffer holds at least one block");
-            for (int d0 = 0; d0 < nblk; d0 += kSlab) {
-                const int nb = min(kSlab, nblk - d0);
-                const uint32_t *src = reinterpret_cast<const uint32_t *>(fbits + (size_t)d0 * (size_t)(K / 4));
-                for (int i = t; i < nb * kBlkWords; i += (int)blockDim.x) stage[i] = src[i];
+            constexpr int W = K / 32;                            // dwords per half block
+            constexpr int kThreadsTf = T < 64 ? 64 : T;          // == blockDim.x
+            constexpr int NG = kThreadsTf / W;                   // block-parallel groups of W lanes
+            static_assert(K % 32 == 0 && NG >= 1 && (2 * NG + 2) * W * 4 <= kXElems * (int)sizeof(cf), "bit-sliced prefix");
+            if (nblk > 0) {                                      // (workgroup-uniform)
+                uint32_t *planes = reinterpret_cast<uint32_t *>(fbuf);      // [NG][2][W], then the total [2][W]
+                const int j = t % W, g = t / W;
+                uint32_t s0 = 0u, s1 = 0u;
+                if (g < NG) {
+                    const uint32_t *col = reinterpret_cast<const uint32_t *>(fbits) + j;
+                    for (int b = g; b < nblk; b += NG) {
+                        const uint32_t iw = col[(size_t)b * (K / 16)], qw = col[(size_t)b * (K / 16) + W];
+                        const uint32_t l = iw ^ qw, c = s0 & l;
+                        s0 ^= l;
+                        s1 ^= qw ^ c;
+                    }
+                    planes[(2 * g) * W + j] = s0;
+                    planes[(2 * g + 1) * W + j] = s1;
+                }
                 lds_barrier_vm();
-                for (int j = 0; j < nb; ++j) advance(reinterpret_cast<const uint8_t *>(stage + j * kBlkWords));
-                lds_barrier();                                   // the slab is consumed (next slab / first exchange)
+                if (t < W) {
+                    uint32_t a0 = planes[t], a1 = planes[W + t];
+#pragma unroll
+                    for (int gg = 1; gg < NG; ++gg) {
+                        const uint32_t b0 = planes[(2 * gg) * W + t], b1 = planes[(2 * gg + 1) * W + t], c = a0 & b0;
+                        a0 ^= b0;
+                        a1 ^= b1 ^ c;
+                    }
+                    planes[2 * NG * W + t] = a0;
+                    planes[(2 * NG + 1) * W + t] = a1;
+                }
+                lds_barrier();
+                unsigned inc = 0u;
+#pragma unroll
+                for (int c = 0; c < 6; ++c) {
+                    // carrier n: bit 7 - (n & 7) of byte n >> 3 of the half block, i.e. of byte (n >> 3) & 3 of dword n >> 5
+                    const unsigned n = (unsigned)bitpos[c], bit = 8u * ((n >> 3) & 3u) + 7u - (n & 7u);
+                    const uint32_t lo = planes[2 * NG * W + (n >> 5)], hi = planes[(2 * NG + 1) * W + (n >> 5)];
+                    inc |= (__builtin_amdgcn_ubfe(lo, bit, 1u) | (__builtin_amdgcn_ubfe(hi, bit, 1u) << 1)) << fpos[c];
+                }
+                P = (P + inc) & 0x333333u;
+                lds_barrier();                                   // the planes are consumed (first exchange)
             }
         }
         // stage the block of the first symbol (block s_begin-2) into bitbuf[0]
