@@ -270,6 +270,249 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
     if (S16) s16_flush_count(nclip, a.clipped);
 }
 
+// ===========================================================================
+// a10 + a11 at the BASELINE config 4 shape (nin = 4096, x4): resampler16_kernel.
+//
+// Two things differ from resampler_kernel above.
+// (1) HOPS ARE INDEPENDENT WORK ITEMS.  out_h = second_half(Y_{h-1}) + first_half(Y_h) and the interpolation
+//     u -> IDFT_nout(stuff(DFT_nin(u))) is linear and commutes with circular shifts (a shift by nin/2 in goes to a shift
+//     by nout/2 out), so the overlap-add moves IN FRONT of the forward transform:
+//         out_h = first_half( IDFT_nout( stuff( DFT_nin( g_h ) ) ) ),
+//         g_h = [ (w1 + w2) c_{h-1} | w2 c_h + w1 c_{h-2} ]        (w1, w2 = the halves of the window, c = input hops).
+//     One forward transform per hop, nothing carried from hop to hop (the kernel above carries the previous spectrum and
+//     forms G_h = F_h + (-1)^k F_{h-1}): no run prologue, no hop state in registers.
+// (2) 4096 = 16 . 16 . 16 ON 256 LANES: sixteen points per lane, three radix-16 stages, TWO exchanges through LDS per
+//     transform where 8 . 8 . 8 . 8 on 512 lanes has three.  A SIMD issues one instruction at a time, VALU or LDS (DESIGN.md
+//     section 6), so a transform costs the SUM of its butterfly and its exchange instructions: a third fewer of the latter.
+//     Plain single transforms on 256-lane workgroups, TWO independent workgroups per CU (213 VGPRs, 76 KB of LDS with two
+//     exchange buffers) that fill each other's barrier waits, where the packed kernel is one 512-lane workgroup per CU in
+//     lockstep.  Every input sample is read once (two of a hop's three input hops stay in registers from the hops before,
+//     the new one is requested a hop ahead).
+//     Measured (same box, cfg 4, 4096 frames): 335 k TF/s against 303 k for resampler_kernel<12, 4>; with three workgroups
+//     per CU at <= 168 VGPRs (no room to keep the inputs or to request them ahead) 322 k.
+// The numpy model of every index mapping below: tools/design/resampler16_model.py.
+//
+// Lane t holds point t + 256 m in slot m, before and after every transform (natural order both sides).
+//   stage 1: DFT16 over the slots; exchange 1 keeps element (t, r) at r (256 + 2) + t (one row per output: scatter
+//            contiguous across lanes, gather (t & 15) 258 + (t >> 4) + 16 m conflict-free: 2 (t & 15) + (t >> 4) takes every
+//            value mod 32 once per 32 lanes)
+//   stage 2: twiddle W_256^{m (t mod 16)} (a 16 x 16 LDS table), DFT16; exchange 2 keeps element (t, r) at
+//            (t >> 4) 256 + (t & 15) + 16 r, gather t + 256 m (both contiguous across lanes)
+//   stage 3: twiddle W_4096^{m t} -- products of the resident W^t, W^2t, W^4t, W^8t (eight registers instead of thirty, no
+//            table: at most three roundings on a twiddle; the model puts the transform's error at 1.8e-7 rel-RMS), DFT16.
+// 16-point DFT as 4 x 4: DFT4 over slots {i, i+4, i+8, i+12}, the nine twiddles W16^{i k} (one of them +-i, two of them
+// 45-degree rotations), DFT4 over i.
+template <int S> DEV cf cmulc(cf a, float c, float s) { return mk(fmaf(a.x, c, -(float)S * (a.y * s)), fmaf(a.y, c, (float)S * (a.x * s))); }   // a (c + S i s)
+template <int S, bool HALF = false> DEV void dft16(cf *v)
+{
+    constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;     // cos, sin (pi / 8)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) dft4<S>(v[i], v[i + 4], v[i + 8], v[i + 12]);          // a[i][k] at v[i + 4 k]
+    v[1 + 4] = cmulc<S>(v[1 + 4], c1, s1);                                             // W16^1
+    v[1 + 8] = rot1<S>(v[1 + 8]);                                                      // W16^2
+    v[1 + 12] = cmulc<S>(v[1 + 12], s1, c1);                                           // W16^3
+    v[2 + 4] = rot1<S>(v[2 + 4]);                                                      // W16^2
+    v[2 + 8] = mul_i<S>(v[2 + 8]);                                                     // W16^4
+    v[2 + 12] = rot3<S>(v[2 + 12]);                                                    // W16^6
+    v[3 + 4] = cmulc<S>(v[3 + 4], s1, c1);                                             // W16^3
+    v[3 + 8] = rot3<S>(v[3 + 8]);                                                      // W16^6
+    v[3 + 12] = cmulc<S>(v[3 + 12], -c1, -s1);                                         // W16^9
+    cf y[16];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        cf b0 = v[4 * k], b1 = v[4 * k + 1], b2 = v[4 * k + 2], b3 = v[4 * k + 3];
+        if (HALF) {
+            // outputs 0 ... 7 only (the first half of a branch transform's samples): rows 0 and 1 of the second DFT4
+            const cf s0 = cadd(b0, b2), s1_ = csub(b0, b2), s2 = cadd(b1, b3), d3 = csub(b1, b3);
+            y[k] = cadd(s0, s2);
+            y[4 + k] = caddi<S>(s1_, d3);
+        } else {
+            dft4<S>(b0, b1, b2, b3);
+            y[k] = b0; y[4 + k] = b1; y[8 + k] = b2; y[12 + k] = b3;
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < (HALF ? 8 : 16); ++r) v[r] = y[r];
+}
+
+struct Fft16 {
+    static constexpr int N = 4096, T = 256, P1 = T + 2;
+    static constexpr int LDS_ELEMS = 16 * P1;                 // the row image of exchange 1 (exchange 2 needs N of them)
+    template <int S> static DEV cf tw(cf w) { return S > 0 ? w : mk(w.x, -w.y); }
+    // pw: W^t, W^2t, W^4t, W^8t (table holds exp(+2 pi i k / N)); tw2: [16][16] W_256^{m a}
+    // Two exchange buffers, used in turn: ONE barrier per exchange (a wave that runs ahead scatters into the buffer its
+    // slower siblings are not gathering from; it cannot reach that one again before they have passed the next barrier).
+    template <int S, bool HALF> static DEV void run(cf *v, cf *lds0, const cf *tw2, const cf *pw, int t)
+    {
+        dft16<S>(v);
+        {
+            cf *lds = lds0;
+            cf *wp = lds + t;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[r * P1] = v[r];
+            xbarrier();
+            const cf *rp = lds + ((t & 15) * P1 + (t >> 4));
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = rp[16 * m];
+        }
+        {
+            const cf *tp = tw2 + (t & 15);
+#pragma unroll
+            for (int m = 1; m < 16; ++m) v[m] = cmul(v[m], tw<S>(tp[16 * m]));
+        }
+        dft16<S>(v);
+        {
+            cf *lds = lds0 + LDS_ELEMS;
+            cf *wp = lds + ((t >> 4) * 256 + (t & 15));
+#pragma unroll
+            for (int r = 0; r < 16; ++r) wp[16 * r] = v[r];
+            xbarrier();
+            const cf *rp = lds + t;
+#pragma unroll
+            for (int m = 0; m < 16; ++m) v[m] = rp[256 * m];
+        }
+        {
+            // (the products below are loop-invariant across hops and the compiler would hoist all fifteen of them -- thirty
+            // registers it then parks in scratch; the empty asm makes the four resident powers opaque at this point, so
+            // the eleven products are formed here, 44 instructions per transform)
+            cf q0 = pw[0], q1 = pw[1], q2 = pw[2], q3 = pw[3];
+            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y), "+v"(q2.x), "+v"(q2.y), "+v"(q3.x), "+v"(q3.y));
+            const cf w1 = tw<S>(q0), w2 = tw<S>(q1), w4 = tw<S>(q2), w8 = tw<S>(q3);
+            const cf w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w6, w1);
+            v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
+            v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
+            v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
+            v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
+            v[15] = cmul(v[15], cmul(w8, w7));
+        }
+        dft16<S, HALF>(v);
+    }
+};
+
+template <bool POLY, bool S16> __global__ __launch_bounds__(256, 2)
+void resampler16_kernel(const ResamplerArgs a, int hops_per_run)
+{
+    typedef Fft16 F;
+    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, Q = 4, HOUT = HIN * Q, NOUT = NIN * Q;
+    unsigned nclip = 0;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    cf *xbuf = reinterpret_cast<cf *>(smem);                       // two exchange buffers
+    cf *tw2 = xbuf + 2 * F::LDS_ELEMS;                             // [16][16]: W_256^{m a}
+    cf *nyq = tw2 + 256;                                           // [2]: Nyquist bin per hop parity (+ pad)
+    float *win = reinterpret_cast<float *>(nyq + 8);               // first half of the (symmetric) Hann window
+    const int t = threadIdx.x;
+    const long h0 = (long)blockIdx.x * hops_per_run;
+    const long h1 = min((long)a.nhops, h0 + hops_per_run);
+    if (h0 >= (long)a.nhops) return;
+
+    tw2[t] = a.tw_in[(16 * (t >> 4) * (t & 15)) & (NIN - 1)];
+#pragma unroll
+    for (int m = 0; m < 8; ++m) win[t + T * m] = a.window[t + T * m];
+    cf pw[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) pw[k] = a.tw_in[((1 << k) * t) & (NIN - 1)];
+    const cf wp1 = a.tw_out[t & (NOUT - 1)];                      // W_nout^t; the branches' W_nout^{t p} are its powers
+    PolyCoef pc{};
+    if (POLY) {
+        // wave-uniform: as scalars (read through the pointer they arrive in vector registers, ten loop-invariant ones that
+        // the allocator then parks in scratch and reloads every hop)
+        auto sc = [&](int i) __attribute__((always_inline)) -> float {
+            return __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, a.poly[i])));
+        };
+        pc.a0 = sc(0); pc.a1 = sc(1); pc.a2 = sc(2); pc.a3 = sc(3); pc.a4 = sc(4);
+        pc.p0 = sc(8); pc.p1 = sc(9); pc.p2 = sc(10); pc.p3 = sc(11); pc.p4 = sc(12);
+    }
+    lds_barrier_vm();
+
+    // S = [halo (2 hops) | in]; sample q of input hop h + k - 2 (k = 0, 1, 2: c_{h-2}, c_{h-1}, c_h)
+    auto sample = [&](long h, int k, int q) __attribute__((always_inline)) -> cf {
+        const long i = (h + k) * HIN + q;
+        return i < NIN ? a.halo[i] : a.in[i - NIN];
+    };
+    // branch twiddle of bin t + 256 m for branch p:  W_nout^{kappa p} = W_nout^{t p} * e^{2 pi i m p / 64}
+    // (* (-i)^p for the negative-frequency half, kappa = k - nin): one table value per branch and lane, the rest are
+    // compile-time rotations; the Nyquist bin (lane 0, slot 8), which the reference places at +nin/2 AND -nin/2
+    // (src/Resampler.cpp:153-164), gets the sum of both twiddles
+    auto branch_rot = [](int p, int m) __attribute__((always_inline)) -> cf {
+        const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % 64) / 64.0
+                           - (m >= 8 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
+        return mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
+    };
+    const float sgn = (t & 1) ? -1.0f : 1.0f;
+    const float fN = (float)NIN;
+
+    // Every input sample is read ONCE: a hop needs the input hops c_{h-2}, c_{h-1}, c_h, and the workgroup walks consecutive
+    // hops, so two of the three are the previous hop's -- they stay in registers (2 x 16), and the new one (a miss all the way
+    // to HBM) is requested a hop AHEAD, before the previous hop's last transform, so that its latency passes behind that
+    // transform, the predistorter and the stores.  (With all three loaded at the top of the hop the four waves of the
+    // workgroup sat out the HBM latency together: a fifth of the kernel's time.)
+    cf in0[8], in1[8], in2[8], nxt[8];                             // c_h, c_{h-1}, c_{h-2}, c_{h+1}: samples t + 256 m
+#pragma unroll
+    for (int m = 0; m < 8; ++m) {
+        const int q = t + T * m;
+        in0[m] = sample(h0, 2, q); in1[m] = sample(h0, 1, q); in2[m] = sample(h0, 0, q);
+        nxt[m] = mk(0.f, 0.f);
+    }
+    for (long h = h0; h < h1; ++h) {
+        cf v[16], b0[8];
+        // ---- g_h: the overlap-add in front of the forward transform (window halves w1[q] = win[q], w2[q] = win[HIN-1-q]) ----
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            const int q = t + T * m;
+            const float w1 = win[q], w2 = win[HIN - 1 - q];
+            const cf c1 = in1[m], c0 = in0[m], c2 = in2[m];
+            b0[m] = cscale(c1, (w1 + w2) * a.factor);
+            v[m] = b0[m];
+            v[m + 8] = mk((w2 * c0.x + w1 * c2.x) * a.factor, (w2 * c0.y + w1 * c2.y) * a.factor);
+        }
+        F::template run<-1, false>(v, xbuf, tw2, pw, t);           // v = G_h, bin t + 256 m in slot m
+        const int slot = (int)(h & 1);
+        if (t == 0) nyq[slot] = v[8];                              // (read after the next transform's barriers)
+        cf G[16];
+#pragma unroll
+        for (int m = 0; m < 16; ++m) G[m] = v[m];
+        cf o[8 * (Q - 1)];
+        cf wpp = wp1;
+#pragma unroll
+        for (int p = 1; p < Q; ++p) {
+            if (p > 1) wpp = cmul(wpp, wp1);
+#pragma unroll
+            for (int m = 0; m < 16; ++m) {
+                v[m] = cmul(cmul(G[m], wpp), branch_rot(p, m));
+                if (m == 8 && t == 0) v[m] = cscale(G[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
+            }
+            if (p == Q - 1 && h + 1 < h1) {
+#pragma unroll
+                for (int m = 0; m < 8; ++m) nxt[m] = sample(h + 1, 2, t + T * m);
+            }
+            F::template run<+1, true>(v, xbuf, tw2, pw, t);
+#pragma unroll
+            for (int m = 0; m < 8; ++m) o[(p - 1) * 8 + m] = v[m];
+        }
+        // ---- branch 0 is the input under the summed window halves (IDFT(DFT(g)) = nin g) plus the second Nyquist copy;
+        //      the Q branches of an output sample leave together, 32 contiguous bytes per lane and slot ----
+        const cf ny = nyq[slot];
+        cf *dst = a.out + (size_t)h * HOUT;
+        uint32_t *dst16 = reinterpret_cast<uint32_t *>(a.out) + (size_t)h * HOUT;
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            cf a0 = mk(fmaf(fN, b0[m].x, sgn * ny.x), fmaf(fN, b0[m].y, sgn * ny.y)), a1 = o[m], a2 = o[8 + m], a3 = o[16 + m];
+            if (POLY) { poly_apply2(a0, a1, pc); poly_apply2(a2, a3, pc); }
+            const size_t at = (size_t)Q * (t + T * m);
+            if (S16) {
+                *reinterpret_cast<uint4 *>(dst16 + at) = make_uint4(s16_pack(a0, nclip), s16_pack(a1, nclip), s16_pack(a2, nclip), s16_pack(a3, nclip));
+            } else {
+                float4 *d4 = reinterpret_cast<float4 *>(dst + at);
+                d4[0] = make_float4(a0.x, a0.y, a1.x, a1.y);
+                d4[1] = make_float4(a2.x, a2.y, a3.x, a3.y);
+            }
+        }
+#pragma unroll
+        for (int m = 0; m < 8; ++m) { in2[m] = in1[m]; in1[m] = in0[m]; in0[m] = nxt[m]; }
+    }
+    if (S16) s16_flush_count(nclip, a.clipped);
+}
+
 template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipStream_t s)
 {
     constexpr int NIN = 1 << LOGNIN;
@@ -295,16 +538,28 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
             else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
             break;
         case 4:
-            if (a.clipped) {
-                if constexpr (LOGNIN == 12) {
-                    if (poly) hipLaunchKernelGGL((resampler_kernel<12, 4, true, true>), grid, block, lds, s, a, hpr);
-                    else hipLaunchKernelGGL((resampler_kernel<12, 4, false, true>), grid, block, lds, s, a, hpr);
-                    break;
-                }
-                return hipErrorInvalidValue;
+            if constexpr (LOGNIN == 12) {
+                // the BASELINE config 4 shape: hop-independent radix-16 kernel, three 256-lane workgroups per CU.  No run
+                // prologue, so short streams are cut into single hops; long ones into runs of 24 (four runs per frame)
+                const int hpr16 = (int)std::max<size_t>(1, std::min<size_t>(24, a.nhops / 1536));
+                const dim3 grid16((unsigned)((a.nhops + hpr16 - 1) / hpr16)), block16(256);
+                const size_t lds16 = (size_t)(2 * Fft16::LDS_ELEMS + 256 + 8) * sizeof(float2) + (size_t)(NIN / 2) * sizeof(float);
+                // (more than 64 KiB of dynamic LDS has to be asked for)
+#define RS16_LAUNCH(P, F)                                                                                              \
+                do {                                                                                                   \
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resampler16_kernel<P, F>),       \
+                                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);        \
+                    if (e != hipSuccess) return e;                                                                     \
+                    hipLaunchKernelGGL((resampler16_kernel<P, F>), grid16, block16, lds16, s, a, hpr16);               \
+                } while (0)
+                if (a.clipped) { if (poly) RS16_LAUNCH(true, true); else RS16_LAUNCH(false, true); }
+                else           { if (poly) RS16_LAUNCH(true, false); else RS16_LAUNCH(false, false); }
+#undef RS16_LAUNCH
+            } else {
+                if (a.clipped) return hipErrorInvalidValue;
+                if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
+                else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
             }
-            if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
-            else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
             break;
         default: return hipErrorInvalidValue;
     }
