@@ -233,6 +233,9 @@ def main():
                     help="transmission frames per step per GPU (32768 = 51.5 GB of IQ per step: sized for 288 GB of HBM)")
     ap.add_argument("--chunks", type=int, default=0, help="workgroups per frame (0 = auto)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--counters", choices=["live", "replay", "off"], default="live",
+                    help="profiler counters of the headline workload: collected by this run through rocprofv3 --pmc (N = 1; falls "
+                         "back to replay), replayed from profiles/traffic.json, or none")
     ap.add_argument("--no-extra", action="store_true", help="skip the secondary workloads")
     ap.add_argument("--gather", type=int, default=0, metavar="FRAMES",
                     help="after the timed region, gather FRAMES frames of IQ from every rank on rank 0 (the optional "
@@ -361,31 +364,82 @@ def main():
     algo = ALGO_BYTES[args.workload]
     achieved = algo * B / (kern_ms * 1e-3) / 1e9  # GB/s per GPU, per-launch HIP-event time
 
-    # Profiler counters are not collected by this run: they are REPLAYED from profiles/traffic.json (rocprofv3 PMC passes
-    # of the same workload and batch, tools/profile_all.sh + tools/make_traffic.py) -- and only while the device sources
-    # are the ones those counters were collected on (source hash); after any kernel change they are dropped until re-profiled.
+    # Profiler counters.  At N = 1 the bench collects them ITSELF for the headline workload (--counters live, the default):
+    # three rocprofv3 --pmc passes of the same launch (tools/prof_run.py: same workload, same batch) right after the timed
+    # region -- SQ + GRBM counters, FETCH_SIZE, WRITE_SIZE in separate passes, no tracing beside --pmc -- each under a
+    # timeout.  If that is not possible (no rocprofv3, a pass fails or times out, N > 1) the figures are REPLAYED from
+    # profiles/traffic.json -- the same passes collected by tools/profile_all.sh -- and only while the device sources are
+    # the ones those were collected on (source hash); `counters_source` says which.  Formulas: tools/counter_math.py.
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import counter_math
     traffic, busy, replay = None, {}, None
-    tp = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tp):
+    packed_fraction = 0.0
+    try:
+        mj = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+        if mj.get("source_hash") == P.source_hash():
+            packed_fraction = mj.get(args.workload, {}).get("packed_fraction_of_valu", 0.0)
+    except Exception:
+        mj = {}
+    KEEP = ("valu_busy", "lds_busy", "hbm_frac", "packed_fraction_of_valu", "wave_active_frac", "wave_issue_stall_frac",
+            "wave_issue_stall_lds_frac", "wave_parked_frac", "lds_bank_conflict_share", "traffic_over_algorithmic")
+
+    def live_counters():
+        import glob
+        import shutil
+        import subprocess
+        import tempfile
+        if shutil.which("rocprofv3") is None:
+            return None, "rocprofv3 not found"
+        top = tempfile.mkdtemp(prefix="dabgpu_pmc_")
+        passes = ["SQ_INSTS_VALU SQ_INSTS_LDS SQ_WAVE_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_INST_LDS SQ_WAIT_ANY "
+                  "SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE", "SQ_LDS_BANK_CONFLICT FETCH_SIZE", "WRITE_SIZE"]
+        try:
+            dbs = []
+            for i, pmc in enumerate(passes):
+                out = os.path.join(top, "p%d" % i)
+                cmd = ["rocprofv3", "--pmc"] + pmc.split() + ["-d", out, "-o", "pmc", "--", sys.executable,
+                       os.path.join(ROOT, "tools", "prof_run.py"), args.workload, str(B), "3"]
+                r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
+                found = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
+                if r.returncode != 0 or not found:
+                    return None, "rocprofv3 pass %d failed (rc %d)" % (i, r.returncode)
+                dbs += found
+            blocks = counter_math.read_rocpd(dbs)
+            if not blocks:
+                return None, "no kernel of the workload in the rocprofv3 output"
+            return counter_math.figures(blocks, algo * B, packed_fraction, "resampler" if "resampler" in blocks else "tf_kernel"), None
+        except Exception as ex:                               # (timeout, unreadable output, ...)
+            return None, "%s: %s" % (type(ex).__name__, str(ex)[:120])
+        finally:
+            shutil.rmtree(top, ignore_errors=True)
+
+    t = None
+    if args.counters == "live" and rank == 0 and world == 1:
+        torch.cuda.empty_cache()
+        t, why = live_counters()
+        replay = ("collected in this run: rocprofv3 --pmc, 3 passes of tools/prof_run.py %s %d" % (args.workload, B)) if t \
+            else "live collection failed (%s); " % why
+    if t is None and args.counters != "off":
+        tp = os.path.join(ROOT, "profiles", "traffic.json")
         try:
             tj = json.load(open(tp))
-            t = tj.get(args.workload)
+            tt = tj.get(args.workload)
             if tj.get("source_hash") != P.source_hash():
-                replay = "dropped: profiles/traffic.json was collected on other device sources (%s)" % tj.get("source_hash")
-            elif t and t.get("frames") == B:
-                traffic = t.get("hbm_bytes_per_launch")
-                busy = {k: t[k] for k in ("valu_busy", "lds_busy", "hbm_frac", "packed_fraction_of_valu", "wave_active_frac",
-                                          "wave_issue_stall_frac", "wave_issue_stall_lds_frac", "wave_parked_frac",
-                                          "lds_bank_conflict_share") if k in t}
-                if t.get("gpu_cycles_per_launch_profiled"):
-                    # the part is power-limited under this kernel: GRBM_GUI_ACTIVE / 8 XCDs over the launch time is
-                    # the clock it actually ran at (2.4 GHz nominal)
-                    busy["effective_clock_GHz"] = round(t["gpu_cycles_per_launch_profiled"] / (kern_ms * 1e6), 2)
-                replay = "profiles/traffic.json (%s, source hash %s)" % (tj.get("profile_dir"), tj.get("source_hash"))
+                replay = (replay or "") + "replay dropped: profiles/traffic.json was collected on other device sources (%s)" % tj.get("source_hash")
+            elif tt and tt.get("frames") == B:
+                t = tt
+                replay = (replay or "") + "replayed from profiles/traffic.json (%s, source hash %s)" % (tj.get("profile_dir"), tj.get("source_hash"))
             else:
-                replay = "dropped: no counters for %d frames per launch" % B
+                replay = (replay or "") + "replay dropped: no counters for %d frames per launch" % B
         except Exception:
-            traffic, busy, replay = None, {}, "dropped: unreadable profiles/traffic.json"
+            replay = (replay or "") + "replay dropped: unreadable profiles/traffic.json"
+    if t:
+        traffic = t.get("hbm_bytes_per_launch")
+        busy = {k: t[k] for k in KEEP if k in t}
+        if t.get("gpu_cycles_per_launch_profiled"):
+            # the part is power-limited under this kernel: GRBM_GUI_ACTIVE / 8 XCDs over the launch time is the clock it
+            # actually ran at (2.4 GHz nominal)
+            busy["effective_clock_GHz"] = round(t["gpu_cycles_per_launch_profiled"] / (kern_ms * 1e6), 2)
 
     # What limits the kernel, from those numbers (never a fixed string): a unit at >= 80 % is the limiter; otherwise no
     # unit is saturated and the limiter is instruction ISSUE -- a SIMD retires one instruction at a time, VALU or LDS, so
@@ -408,14 +462,13 @@ def main():
     # the static issue-time model of the hot loop next to the measured time per loop iteration (profiles/isa_mix.json)
     issue = None
     try:
-        mj = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
         m = mj.get(args.workload)
         if m and mj.get("source_hash") == P.source_hash() and busy.get("effective_clock_GHz"):
-            # iterations per launch per SIMD: cfg 2/3 -- 77 symbols x 4 waves per frame, cfg 4 -- 96 hops x 8 waves
-            per_frame = 96 * 8 if args.workload == "cfg4" else 77 * 4
-            measured = busy["effective_clock_GHz"] * 1e9 * kern_ms * 1e-3 * 1024 / (B * per_frame)
-            if args.workload == "cfg4":
-                measured *= 0.885          # (the resampler's share of the two-kernel launch, profiles/)
+            # wave-iterations per frame and waves per SIMD: cfg 2 / 3 -- 77 symbols x 4 waves, four workgroups per CU;
+            # cfg 4 -- 96 hops x 4 waves, two workgroups per CU (the resampler's share of the two-kernel launch)
+            per_frame = 96 * 4 if args.workload == "cfg4" else 77 * 4
+            share = 0.88 if args.workload == "cfg4" else 1.0
+            measured = share * busy["effective_clock_GHz"] * 1e9 * kern_ms * 1e-3 * 1024 / (B * per_frame)
             issue = {"model_simd_ticks_per_wave_iteration": m["issue_model_simd_ticks"],
                      "measured_simd_cycles_per_wave_iteration": round(measured, 1),
                      "model_over_measured": round(m["issue_model_simd_ticks"]["total"] / measured, 3),

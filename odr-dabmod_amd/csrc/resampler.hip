@@ -298,16 +298,34 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 //            value mod 32 once per 32 lanes)
 //   stage 2: twiddle W_256^{m (t mod 16)} (a 16 x 16 LDS table), DFT16; exchange 2 keeps element (t, r) at
 //            (t >> 4) 256 + (t & 15) + 16 r, gather t + 256 m (both contiguous across lanes)
-//   stage 3: twiddle W_4096^{m t} -- products of the resident W^t, W^2t, W^4t, W^8t (eight registers instead of thirty, no
-//            table: at most three roundings on a twiddle; the model puts the transform's error at 1.8e-7 rel-RMS), DFT16.
+//   stage 3: twiddle W_4096^{m t} -- fifteen values per lane, resident in registers (two workgroups per CU leave room for
+//            them; formed as products of four resident powers they cost 44 instructions per transform), DFT16.
 // 16-point DFT as 4 x 4: DFT4 over slots {i, i+4, i+8, i+12}, the nine twiddles W16^{i k} (one of them +-i, two of them
 // 45-degree rotations), DFT4 over i.
 template <int S> DEV cf cmulc(cf a, float c, float s) { return mk(fmaf(a.x, c, -(float)S * (a.y * s)), fmaf(a.y, c, (float)S * (a.x * s))); }   // a (c + S i s)
-template <int S, bool HALF = false> DEV void dft16(cf *v)
+// t + x * w (four FMAs: the same count as the product alone)
+DEV cf cfma(cf t, cf x, cf w) { return mk(fmaf(-x.y, w.y, fmaf(x.x, w.x, t.x)), fmaf(x.y, w.x, fmaf(x.x, w.y, t.y))); }
+// TW: the inputs 1 ... 15 are first multiplied by w[0 ... 14].  The products of the upper two inputs of every first-layer
+// DFT4 are folded into its sums -- s = u + v w is four FMAs, d = 2 u - s two -- instead of product, sum and difference:
+// four instructions fewer per DFT4, sixteen per twiddled 16-point DFT.
+template <int S, bool HALF = false, bool TW = false> DEV void dft16(cf *v, const cf *w = nullptr)
 {
     constexpr float c1 = 0.92387953251128675613f, s1 = 0.38268343236508977173f;     // cos, sin (pi / 8)
+    if (TW) {
 #pragma unroll
-    for (int i = 0; i < 4; ++i) dft4<S>(v[i], v[i + 4], v[i + 8], v[i + 12]);          // a[i][k] at v[i + 4 k]
+        for (int i = 0; i < 4; ++i) {
+            const cf x0 = i == 0 ? v[0] : cmul(v[i], w[i - 1]), x1 = cmul(v[i + 4], w[i + 3]);
+            const cf s0 = cfma(x0, v[i + 8], w[i + 7]), s2 = cfma(x1, v[i + 12], w[i + 11]);
+            const cf s1_ = mk(fmaf(2.0f, x0.x, -s0.x), fmaf(2.0f, x0.y, -s0.y)), d3 = mk(fmaf(2.0f, x1.x, -s2.x), fmaf(2.0f, x1.y, -s2.y));
+            v[i] = cadd(s0, s2);
+            v[i + 8] = csub(s0, s2);
+            v[i + 4] = caddi<S>(s1_, d3);
+            v[i + 12] = csubi<S>(s1_, d3);
+        }
+    } else {
+#pragma unroll
+        for (int i = 0; i < 4; ++i) dft4<S>(v[i], v[i + 4], v[i + 8], v[i + 12]);      // a[i][k] at v[i + 4 k]
+    }
     v[1 + 4] = cmulc<S>(v[1 + 4], c1, s1);                                             // W16^1
     v[1 + 8] = rot1<S>(v[1 + 8]);                                                      // W16^2
     v[1 + 12] = cmulc<S>(v[1 + 12], s1, c1);                                           // W16^3
@@ -339,7 +357,7 @@ struct Fft16 {
     static constexpr int N = 4096, T = 256, P1 = T + 2;
     static constexpr int LDS_ELEMS = 16 * P1;                 // the row image of exchange 1 (exchange 2 needs N of them)
     template <int S> static DEV cf tw(cf w) { return S > 0 ? w : mk(w.x, -w.y); }
-    // pw: W^t, W^2t, W^4t, W^8t (table holds exp(+2 pi i k / N)); tw2: [16][16] W_256^{m a}
+    // pw: W^{m t}, m = 1 ... 15, resident (table holds exp(+2 pi i k / N)); tw2: [16][16] W_256^{m a}
     // Two exchange buffers, used in turn: ONE barrier per exchange (a wave that runs ahead scatters into the buffer its
     // slower siblings are not gathering from; it cannot reach that one again before they have passed the next barrier).
     template <int S, bool HALF> static DEV void run(cf *v, cf *lds0, const cf *tw2, const cf *pw, int t)
@@ -357,10 +375,11 @@ struct Fft16 {
         }
         {
             const cf *tp = tw2 + (t & 15);
+            cf w[15];
 #pragma unroll
-            for (int m = 1; m < 16; ++m) v[m] = cmul(v[m], tw<S>(tp[16 * m]));
+            for (int m = 1; m < 16; ++m) w[m - 1] = tw<S>(tp[16 * m]);
+            dft16<S, false, true>(v, w);
         }
-        dft16<S>(v);
         {
             cf *lds = lds0 + LDS_ELEMS;
             cf *wp = lds + ((t >> 4) * 256 + (t & 15));
@@ -372,20 +391,11 @@ struct Fft16 {
             for (int m = 0; m < 16; ++m) v[m] = rp[256 * m];
         }
         {
-            // (the products below are loop-invariant across hops and the compiler would hoist all fifteen of them -- thirty
-            // registers it then parks in scratch; the empty asm makes the four resident powers opaque at this point, so
-            // the eleven products are formed here, 44 instructions per transform)
-            cf q0 = pw[0], q1 = pw[1], q2 = pw[2], q3 = pw[3];
-            asm volatile("" : "+v"(q0.x), "+v"(q0.y), "+v"(q1.x), "+v"(q1.y), "+v"(q2.x), "+v"(q2.y), "+v"(q3.x), "+v"(q3.y));
-            const cf w1 = tw<S>(q0), w2 = tw<S>(q1), w4 = tw<S>(q2), w8 = tw<S>(q3);
-            const cf w3 = cmul(w2, w1), w5 = cmul(w4, w1), w6 = cmul(w4, w2), w7 = cmul(w6, w1);
-            v[1] = cmul(v[1], w1); v[2] = cmul(v[2], w2); v[3] = cmul(v[3], w3); v[4] = cmul(v[4], w4);
-            v[5] = cmul(v[5], w5); v[6] = cmul(v[6], w6); v[7] = cmul(v[7], w7); v[8] = cmul(v[8], w8);
-            v[9] = cmul(v[9], cmul(w8, w1)); v[10] = cmul(v[10], cmul(w8, w2)); v[11] = cmul(v[11], cmul(w8, w3));
-            v[12] = cmul(v[12], cmul(w8, w4)); v[13] = cmul(v[13], cmul(w8, w5)); v[14] = cmul(v[14], cmul(w8, w6));
-            v[15] = cmul(v[15], cmul(w8, w7));
+            cf w[15];
+#pragma unroll
+            for (int m = 1; m < 16; ++m) w[m - 1] = tw<S>(pw[m - 1]);
+            dft16<S, HALF, true>(v, w);
         }
-        dft16<S, HALF>(v);
     }
 };
 
@@ -408,9 +418,9 @@ void resampler16_kernel(const ResamplerArgs a, int hops_per_run)
     tw2[t] = a.tw_in[(16 * (t >> 4) * (t & 15)) & (NIN - 1)];
 #pragma unroll
     for (int m = 0; m < 8; ++m) win[t + T * m] = a.window[t + T * m];
-    cf pw[4];
+    cf pw[15];                                                     // the last stage's twiddles W_nin^{m t}: thirty resident registers
 #pragma unroll
-    for (int k = 0; k < 4; ++k) pw[k] = a.tw_in[((1 << k) * t) & (NIN - 1)];
+    for (int m = 1; m < 16; ++m) pw[m - 1] = a.tw_in[(m * t) & (NIN - 1)];
     const cf wp1 = a.tw_out[t & (NOUT - 1)];                      // W_nout^t; the branches' W_nout^{t p} are its powers
     PolyCoef pc{};
     if (POLY) {
