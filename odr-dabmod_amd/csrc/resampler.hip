@@ -302,7 +302,6 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 //            them; formed as products of four resident powers they cost 44 instructions per transform), DFT16.
 // 16-point DFT as 4 x 4: DFT4 over slots {i, i+4, i+8, i+12}, the nine twiddles W16^{i k} (one of them +-i, two of them
 // 45-degree rotations), DFT4 over i.
-template <int S> DEV cf cmulc(cf a, float c, float s) { return mk(fmaf(a.x, c, -(float)S * (a.y * s)), fmaf(a.y, c, (float)S * (a.x * s))); }   // a (c + S i s)
 // t + x * w (four FMAs: the same count as the product alone)
 DEV cf cfma(cf t, cf x, cf w) { return mk(fmaf(-x.y, w.y, fmaf(x.x, w.x, t.x)), fmaf(x.y, w.x, fmaf(x.x, w.y, t.y))); }
 // TW: the inputs 1 ... 15 are first multiplied by w[0 ... 14].  The products of the upper two inputs of every first-layer
@@ -326,27 +325,31 @@ template <int S, bool HALF = false, bool TW = false> DEV void dft16(cf *v, const
 #pragma unroll
         for (int i = 0; i < 4; ++i) dft4<S>(v[i], v[i + 4], v[i + 8], v[i + 12]);      // a[i][k] at v[i + 4 k]
     }
-    v[1 + 4] = cmulc<S>(v[1 + 4], c1, s1);                                             // W16^1
-    v[1 + 8] = rot1<S>(v[1 + 8]);                                                      // W16^2
-    v[1 + 12] = cmulc<S>(v[1 + 12], s1, c1);                                           // W16^3
-    v[2 + 4] = rot1<S>(v[2 + 4]);                                                      // W16^2
-    v[2 + 8] = mul_i<S>(v[2 + 8]);                                                     // W16^4
-    v[2 + 12] = rot3<S>(v[2 + 12]);                                                    // W16^6
-    v[3 + 4] = cmulc<S>(v[3 + 4], s1, c1);                                             // W16^3
-    v[3 + 8] = rot3<S>(v[3 + 8]);                                                      // W16^6
-    v[3 + 12] = cmulc<S>(v[3 + 12], -c1, -s1);                                         // W16^9
+    // second layer: DFT4 over i for every k, input i under the twiddle W16^{i k}.  The products are folded into the sums
+    // as above (s = u + v w, d = 2 u - s), ten instructions fewer per 16-point DFT; W16^4 = +-i costs nothing.
+    constexpr float kh = kSqrtHalf, fS = (float)S;
+    const cf W1 = mk(c1, fS * s1), W2 = mk(kh, fS * kh), W3 = mk(s1, fS * c1), W6 = mk(-kh, fS * kh), W9 = mk(-c1, -fS * s1);
+    auto twice_minus = [](cf u, cf s) __attribute__((always_inline)) { return mk(fmaf(2.0f, u.x, -s.x), fmaf(2.0f, u.y, -s.y)); };
     cf y[16];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
-        cf b0 = v[4 * k], b1 = v[4 * k + 1], b2 = v[4 * k + 2], b3 = v[4 * k + 3];
-        if (HALF) {
-            // outputs 0 ... 7 only (the first half of a branch transform's samples): rows 0 and 1 of the second DFT4
-            const cf s0 = cadd(b0, b2), s1_ = csub(b0, b2), s2 = cadd(b1, b3), d3 = csub(b1, b3);
-            y[k] = cadd(s0, s2);
-            y[4 + k] = caddi<S>(s1_, d3);
+        const cf b0 = v[4 * k], b1 = v[4 * k + 1], b2 = v[4 * k + 2], b3 = v[4 * k + 3];
+        cf s0, s1_, s2, d3;
+        if (k == 0) {
+            s0 = cadd(b0, b2); s1_ = csub(b0, b2); s2 = cadd(b1, b3); d3 = csub(b1, b3);
         } else {
-            dft4<S>(b0, b1, b2, b3);
-            y[k] = b0; y[4 + k] = b1; y[8 + k] = b2; y[12 + k] = b3;
+            const cf wa = k == 1 ? W1 : (k == 2 ? W2 : W3), wb = k == 1 ? W2 : W6, wc = k == 1 ? W3 : (k == 2 ? W6 : W9);
+            if (k == 2) { s0 = caddi<S>(b0, b2); s1_ = csubi<S>(b0, b2); }
+            else { s0 = cfma(b0, b2, wb); s1_ = twice_minus(b0, s0); }
+            const cf x1 = cmul(b1, wa);
+            s2 = cfma(x1, b3, wc);
+            d3 = twice_minus(x1, s2);
+        }
+        y[k] = cadd(s0, s2);
+        y[4 + k] = caddi<S>(s1_, d3);
+        if (!HALF) {                  // (HALF: outputs 0 ... 7 only -- the first half of a branch transform's samples)
+            y[8 + k] = csub(s0, s2);
+            y[12 + k] = csubi<S>(s1_, d3);
         }
     }
 #pragma unroll
@@ -360,9 +363,11 @@ struct Fft16 {
     // pw: W^{m t}, m = 1 ... 15, resident (table holds exp(+2 pi i k / N)); tw2: [16][16] W_256^{m a}
     // Two exchange buffers, used in turn: ONE barrier per exchange (a wave that runs ahead scatters into the buffer its
     // slower siblings are not gathering from; it cannot reach that one again before they have passed the next barrier).
-    template <int S, bool HALF> static DEV void run(cf *v, cf *lds0, const cf *tw2, const cf *pw, int t)
+    // w1: optional twiddles on the inputs 1 ... 15 of the FIRST stage (the branch transforms' per-slot rotations: folded
+    // into that stage's first butterfly layer like the stage twiddles)
+    template <int S, bool HALF, bool TW1 = false> static DEV void run(cf *v, cf *lds0, const cf *tw2, const cf *pw, int t, const cf *w1 = nullptr)
     {
-        dft16<S>(v);
+        dft16<S, false, TW1>(v, w1);
         {
             cf *lds = lds0;
             cf *wp = lds + t;
@@ -486,16 +491,24 @@ void resampler16_kernel(const ResamplerArgs a, int hops_per_run)
 #pragma unroll
         for (int p = 1; p < Q; ++p) {
             if (p > 1) wpp = cmul(wpp, wp1);
+            // v = G W_nout^{t p}; the per-slot rotation goes into the transform's first stage as input twiddles.  The Nyquist
+            // bin (lane 0, slot 8) carries 2 cos(pi p / Q) instead: pre-divided by its rotation.
+            cf rot[15];
+#pragma unroll
+            for (int m = 1; m < 16; ++m) rot[m - 1] = branch_rot(p, m);
 #pragma unroll
             for (int m = 0; m < 16; ++m) {
-                v[m] = cmul(cmul(G[m], wpp), branch_rot(p, m));
-                if (m == 8 && t == 0) v[m] = cscale(G[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q));
+                v[m] = cmul(G[m], wpp);
+                if (m == 8 && t == 0) {
+                    const cf r8 = branch_rot(p, 8);                // (unit modulus: 1 / r8 = conj r8)
+                    v[m] = cmul(cscale(G[m], 2.0f * (float)__builtin_cos(3.14159265358979323846 * (double)p / (double)Q)), mk(r8.x, -r8.y));
+                }
             }
             if (p == Q - 1 && h + 1 < h1) {
 #pragma unroll
                 for (int m = 0; m < 8; ++m) nxt[m] = sample(h + 1, 2, t + T * m);
             }
-            F::template run<+1, true>(v, xbuf, tw2, pw, t);
+            F::template run<+1, true, true>(v, xbuf, tw2, pw, t, rot);
 #pragma unroll
             for (int m = 0; m < 8; ++m) o[(p - 1) * 8 + m] = v[m];
         }
