@@ -219,11 +219,26 @@ DEV c2 cfma(c2 t, c2 x, cf w)          // t + x * w
         : "=v"(im), "=&v"(i0) : "v"(xre), "v"(xim), "v"(ww), "v"(tim));
     return c2{make_float2(re.x, re.y), make_float2(im.x, im.y)};
 }
+DEV cf cfma(cf t, cf x, cf w)          // t + x * w: four FMAs, what the product alone costs
+{
+    return mk(fmaf(-x.y, w.y, fmaf(x.x, w.x, t.x)), fmaf(x.y, w.x, fmaf(x.x, w.y, t.y)));
+}
+DEV cf twice_minus(cf u, cf s) { return mk(fmaf(2.0f, u.x, -s.x), fmaf(2.0f, u.y, -s.y)); }       // 2 u - s
 template <int S> DEV void twiddle_dft8(cf *v, const cf *w)
 {
+    // (the same folding as for packed pairs below: a_i = u_i + v_{i+4} w, b_i = 2 u_i - a_i -- two instructions fewer per
+    // pair than product, sum and difference)
+    cf a[4], b[4];
 #pragma unroll
-    for (int r = 1; r < 8; ++r) v[r] = cmul(v[r], w[r - 1]);
-    dft8<S>(v);
+    for (int i = 0; i < 4; ++i) {
+        const cf u = i == 0 ? v[0] : cmul(v[i], w[i - 1]);
+        a[i] = cfma(u, v[i + 4], w[i + 3]);
+        b[i] = twice_minus(u, a[i]);
+    }
+    dft4<S>(a[0], a[1], a[2], a[3]);
+    dft8_odd<S>(b[0], b[1], b[2], b[3]);
+    v[0] = a[0]; v[2] = a[1]; v[4] = a[2]; v[6] = a[3];
+    v[1] = b[0]; v[3] = b[1]; v[5] = b[2]; v[7] = b[3];
 }
 template <int S> DEV void twiddle_dft8(c2 *v, const cf *w)
 {
@@ -425,9 +440,18 @@ template <int LOGN> struct Fft {
             for (int b = 0; b < 2; ++b) {
                 const cf w1 = twid<S>(tw[n]), w2 = twid<S>(tw[n + 1]), w3 = twid<S>(tw[n + 2]);
                 n += 3;
-                V x0 = v[b], x1 = cmul(v[b + 2], w1), x2 = cmul(v[b + 4], w2), x3 = cmul(v[b + 6], w3);
-                dft4<S>(x0, x1, x2, x3);
-                v[b] = x0; v[b + 2] = x1; v[b + 4] = x2; v[b + 6] = x3;
+                if constexpr (std::is_same<V, cf>::value) {
+                    // (products folded into the first layer's sums, as in twiddle_dft8)
+                    const cf x0 = v[b], x1 = cmul(v[b + 2], w1);
+                    const cf s0 = cfma(x0, v[b + 4], w2), s2 = cfma(x1, v[b + 6], w3);
+                    const cf s1 = twice_minus(x0, s0), d3 = twice_minus(x1, s2);
+                    v[b] = cadd(s0, s2); v[b + 4] = csub(s0, s2);
+                    v[b + 2] = caddi<S>(s1, d3); v[b + 6] = csubi<S>(s1, d3);
+                } else {
+                    V x0 = v[b], x1 = cmul(v[b + 2], w1), x2 = cmul(v[b + 4], w2), x3 = cmul(v[b + 6], w3);
+                    dft4<S>(x0, x1, x2, x3);
+                    v[b] = x0; v[b + 2] = x1; v[b + 4] = x2; v[b + 6] = x3;
+                }
             }
         } else if (RF == 2) {
 #pragma unroll

@@ -302,8 +302,6 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 //            them; formed as products of four resident powers they cost 44 instructions per transform), DFT16.
 // 16-point DFT as 4 x 4: DFT4 over slots {i, i+4, i+8, i+12}, the nine twiddles W16^{i k} (one of them +-i, two of them
 // 45-degree rotations), DFT4 over i.
-// t + x * w (four FMAs: the same count as the product alone)
-DEV cf cfma(cf t, cf x, cf w) { return mk(fmaf(-x.y, w.y, fmaf(x.x, w.x, t.x)), fmaf(x.y, w.x, fmaf(x.x, w.y, t.y))); }
 // TW: the inputs 1 ... 15 are first multiplied by w[0 ... 14].  The products of the upper two inputs of every first-layer
 // DFT4 are folded into its sums -- s = u + v w is four FMAs, d = 2 u - s two -- instead of product, sum and difference:
 // four instructions fewer per DFT4, sixteen per twiddled 16-point DFT.
@@ -315,7 +313,7 @@ template <int S, bool HALF = false, bool TW = false> DEV void dft16(cf *v, const
         for (int i = 0; i < 4; ++i) {
             const cf x0 = i == 0 ? v[0] : cmul(v[i], w[i - 1]), x1 = cmul(v[i + 4], w[i + 3]);
             const cf s0 = cfma(x0, v[i + 8], w[i + 7]), s2 = cfma(x1, v[i + 12], w[i + 11]);
-            const cf s1_ = mk(fmaf(2.0f, x0.x, -s0.x), fmaf(2.0f, x0.y, -s0.y)), d3 = mk(fmaf(2.0f, x1.x, -s2.x), fmaf(2.0f, x1.y, -s2.y));
+            const cf s1_ = twice_minus(x0, s0), d3 = twice_minus(x1, s2);
             v[i] = cadd(s0, s2);
             v[i + 8] = csub(s0, s2);
             v[i + 4] = caddi<S>(s1_, d3);
@@ -329,7 +327,6 @@ template <int S, bool HALF = false, bool TW = false> DEV void dft16(cf *v, const
     // as above (s = u + v w, d = 2 u - s), ten instructions fewer per 16-point DFT; W16^4 = +-i costs nothing.
     constexpr float kh = kSqrtHalf, fS = (float)S;
     const cf W1 = mk(c1, fS * s1), W2 = mk(kh, fS * kh), W3 = mk(s1, fS * c1), W6 = mk(-kh, fS * kh), W9 = mk(-c1, -fS * s1);
-    auto twice_minus = [](cf u, cf s) __attribute__((always_inline)) { return mk(fmaf(2.0f, u.x, -s.x), fmaf(2.0f, u.y, -s.y)); };
     cf y[16];
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
