@@ -439,7 +439,7 @@ def main():
         if t.get("gpu_cycles_per_launch_profiled"):
             # the part is power-limited under this kernel: GRBM_GUI_ACTIVE / 8 XCDs over the launch time is the clock it
             # actually ran at (2.4 GHz nominal)
-            busy["effective_clock_GHz"] = round(t["gpu_cycles_per_launch_profiled"] / (kern_ms * 1e6), 2)
+            busy["effective_clock_GHz"] = t.get("effective_clock_GHz_profiled") or round(t["gpu_cycles_per_launch_profiled"] / (kern_ms * 1e6), 2)
 
     # What limits the kernel, from those numbers (never a fixed string): a unit at >= 80 % is the limiter; otherwise no
     # unit is saturated and the limiter is instruction ISSUE -- a SIMD retires one instruction at a time, VALU or LDS, so
@@ -459,17 +459,16 @@ def main():
                    100 * b.get("wave_issue_stall_frac", 0.0), 100 * b.get("wave_issue_stall_lds_frac", 0.0),
                    100 * b.get("wave_parked_frac", 0.0)))
 
-    # the static issue-time model of the hot loop next to the measured time per loop iteration (profiles/isa_mix.json)
+    # the static issue-time model of the hot loop next to the measured SIMD cycles per loop iteration: the dominant kernel's
+    # GRBM_GUI_ACTIVE / 8 cycles per launch x 1024 SIMDs / wave-iterations per launch (a cycle COUNT: no clock estimate in it)
     issue = None
     try:
         m = mj.get(args.workload)
-        if m and mj.get("source_hash") == P.source_hash() and busy.get("effective_clock_GHz"):
-            # wave-iterations per frame and waves per SIMD: cfg 2 / 3 -- 77 symbols x 4 waves, four workgroups per CU;
-            # cfg 4 -- 96 hops x 4 waves, two workgroups per CU (the resampler's share of the two-kernel launch)
+        if m and mj.get("source_hash") == P.source_hash() and t and t.get("dominant_kernel_cycles_profiled"):
+            # wave-iterations per frame: cfg 2 / 3 -- 77 symbols x 4 waves; cfg 4 -- 96 hops x 4 waves
             per_frame = 96 * 4 if args.workload == "cfg4" else 77 * 4
-            share = 0.88 if args.workload == "cfg4" else 1.0
-            measured = share * busy["effective_clock_GHz"] * 1e9 * kern_ms * 1e-3 * 1024 / (B * per_frame)
-            issue = {"model_simd_ticks_per_wave_iteration": m["issue_model_simd_ticks"],
+            measured = t["dominant_kernel_cycles_profiled"] * 1024 / (B * per_frame)
+            issue = {"model_simd_cycles_per_wave_iteration": m["issue_model_simd_ticks"],
                      "measured_simd_cycles_per_wave_iteration": round(measured, 1),
                      "model_over_measured": round(m["issue_model_simd_ticks"]["total"] / measured, 3),
                      "iteration": m["loop_iteration"]}

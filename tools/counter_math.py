@@ -36,7 +36,8 @@ def figures(blocks, algo_bytes_per_launch, packed_fraction, dominant=None):
                   "lds_busy": round(b.get("SQ_LDS_IDX_ACTIVE", 0.0) / (256 * cyc), 3),
                   "lds_bank_conflict_share": round(b.get("SQ_LDS_BANK_CONFLICT", 0.0) / max(b.get("SQ_LDS_IDX_ACTIVE", 0.0), 1.0), 3),
                   "valu_insts_per_launch": b["SQ_INSTS_VALU"], "lds_insts_per_launch": b.get("SQ_INSTS_LDS", 0.0),
-                  "gpu_cycles_per_launch_profiled": sum(bb.get("GRBM_GUI_ACTIVE", 0.0) for bb in blocks.values()) / 8})
+                  "gpu_cycles_per_launch_profiled": sum(bb.get("GRBM_GUI_ACTIVE", 0.0) for bb in blocks.values()) / 8,
+                  "dominant_kernel_cycles_profiled": cyc})
         if dur_s:
             e["hbm_frac"] = round(e["hbm_bytes_per_launch"] / (sum(bb.get("_duration_ns", 0.0) for bb in blocks.values()) * 1e-9) / HBM_PEAK, 3)
             e["effective_clock_GHz_profiled"] = round(cyc / dur_s / 1e9, 3)
