@@ -90,3 +90,35 @@ def test_fir_inverse_design_is_host_logic_and_inverts_the_filter_on_the_occupied
     notch = np.convolve(taps[:43].astype(np.float64), [1, -2 * np.cos(2 * np.pi * 300 / N), 1]).astype(np.float32)
     assert notch.size == 45 and not pkg.fir_inverse_design(notch)[0]
     assert not pkg.fir_inverse_design(taps[:44])[0]
+
+
+def test_counter_math_and_the_static_mix_belong_to_the_committed_sources():
+    """The utilisation figures of the bench line: (i) the formulas (tools/counter_math.py) on a synthetic set of counters --
+    VALU priced at 2 cycles per plain and 4 per packed wave64 instruction, FETCH_SIZE doubled, shares of a wave's life;
+    (ii) profiles/isa_mix.json (the packed share and the issue-time model, tools/isa_mix.py) carries the hash of the device
+    sources in the tree, i.e. it was regenerated after the last kernel change."""
+    import importlib
+    import json
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import counter_math as cm
+    cyc = 1.0e6
+    blocks = {"tf_kernel": {"GRBM_GUI_ACTIVE": 8 * cyc, "SQ_INSTS_VALU": 1024 * cyc * 0.1, "SQ_LDS_IDX_ACTIVE": 256 * cyc * 0.5,
+                            "SQ_LDS_BANK_CONFLICT": 256 * cyc * 0.05, "SQ_WAVE_CYCLES": 1000.0, "SQ_ACTIVE_INST_ANY": 400.0,
+                            "SQ_WAIT_INST_ANY": 350.0, "SQ_WAIT_INST_LDS": 100.0, "SQ_WAIT_ANY": 250.0,
+                            "WRITE_SIZE": 1000.0, "FETCH_SIZE": 100.0, "_duration_ns": 1.0e6}}
+    e = cm.figures(blocks, 1200 * 1024, 0.5)
+    assert e["hbm_bytes_per_launch"] == (1000 + 2 * 100) * 1024 and e["traffic_over_algorithmic"] == 1.0
+    assert abs(e["valu_busy"] - 0.1 * (2 + 2 * 0.5)) < 1e-9           # half of the instructions packed: 3 cycles on average
+    assert abs(cm.figures(blocks, 0, 0.0)["valu_busy"] - 0.2) < 1e-9   # all plain: 2 cycles
+    assert e["lds_busy"] == 0.5 and e["lds_bank_conflict_share"] == 0.1
+    assert (e["wave_active_frac"], e["wave_issue_stall_frac"], e["wave_issue_stall_lds_frac"], e["wave_parked_frac"]) == (0.4, 0.35, 0.1, 0.25)
+    assert e["effective_clock_GHz_profiled"] == 1.0 and e["dominant_kernel"] == "tf_kernel"
+    mix = json.load(open(os.path.join(ROOT, "profiles", "isa_mix.json")))
+    pkg = importlib.import_module("odr-dabmod_amd")
+    assert mix["source_hash"] == pkg.source_hash(), "run tools/isa_mix.py --json profiles/isa_mix.json after changing a kernel"
+    for wl in ("cfg2", "cfg3", "cfg4", "ifft_fir_stage"):
+        m = mix[wl]
+        assert m["valu_instructions"] > 100 and 0.0 <= m["packed_fraction_of_valu"] <= 1.0
+        t = m["issue_model_simd_ticks"]
+        assert abs(t["valu"] + t["lds"] + t["vmem"] - t["total"]) < 0.5
