@@ -284,12 +284,12 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 // (2) 4096 = 16 . 16 . 16 ON 256 LANES: sixteen points per lane, three radix-16 stages, TWO exchanges through LDS per
 //     transform where 8 . 8 . 8 . 8 on 512 lanes has three.  A SIMD issues one instruction at a time, VALU or LDS (DESIGN.md
 //     section 6), so a transform costs the SUM of its butterfly and its exchange instructions: a third fewer of the latter.
-//     Plain single transforms on 256-lane workgroups, TWO independent workgroups per CU (213 VGPRs, 76 KB of LDS with two
+//     Plain single transforms on 256-lane workgroups, TWO independent workgroups per CU (250 VGPRs, 76 KB of LDS with two
 //     exchange buffers) that fill each other's barrier waits, where the packed kernel is one 512-lane workgroup per CU in
 //     lockstep.  Every input sample is read once (two of a hop's three input hops stay in registers from the hops before,
 //     the new one is requested a hop ahead).
-//     Measured (same box, cfg 4, 4096 frames): 335 k TF/s against 303 k for resampler_kernel<12, 4>; with three workgroups
-//     per CU at <= 168 VGPRs (no room to keep the inputs or to request them ahead) 322 k.
+//     Measured (same box, cfg 4, 4096 frames): 364 k TF/s against 320 k for resampler_kernel<12, 4>; with three workgroups
+//     per CU at <= 168 VGPRs (no room to keep the inputs or to request them ahead) 322 k.  DESIGN.md section 4.3 has the steps.
 // The numpy model of every index mapping below: tools/design/resampler16_model.py.
 //
 // Lane t holds point t + 256 m in slot m, before and after every transform (natural order both sides).
