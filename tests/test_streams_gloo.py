@@ -145,3 +145,18 @@ def test_bench_one_rank_dry_run_needs_no_process_group():
                        capture_output=True, text=True, timeout=60)
     assert r.returncode == 0, r.stderr[-2000:]
     assert json.loads(r.stdout.strip())["n_gpus"] == 1
+
+
+def test_bench_under_torch_distributed_run_as_the_driver_launches_it():
+    """The driver's N > 1 command: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1
+    --master-port P bench.py --gpus N ... -- every process is one rank (no second launcher inside), rank 0 prints the one line."""
+    import json
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(free_port()), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run",
+                        "--steps", "2", "--warmup", "1", "--frames", "50"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["config"]["frames_per_step_per_gpu"] == 50
