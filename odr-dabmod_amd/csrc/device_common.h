@@ -77,6 +77,7 @@ DEV cf mk(float x, float y) { return make_float2(x, y); }
 // zero or far above FLT_MIN, so the denormal pre-scaling of sqrtf is not needed either.
 DEV float fast_sqrt(float x) { return __builtin_amdgcn_sqrtf(x); }
 DEV float fast_rcp(float x) { return __builtin_amdgcn_rcpf(x); }
+DEV float fast_rsq(float x) { return __builtin_amdgcn_rsqf(x); }
 DEV cf cadd(cf a, cf b) { return mk(a.x + b.x, a.y + b.y); }
 DEV cf csub(cf a, cf b) { return mk(a.x - b.x, a.y - b.y); }
 DEV cf cmul(cf a, cf b) { return mk(fmaf(a.x, b.x, -(a.y * b.y)), fmaf(a.x, b.y, a.y * b.x)); }
@@ -671,22 +672,87 @@ DEV float lane_bcast(float x, int lane)
 {
     return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, x), lane));
 }
+// The steps are v_add_f32 / v_max_f32 with the DPP operand in place, written by hand (through update_dpp the compiler spends
+// a v_mov_b32_dpp, a zeroing v_mov_b32 and the addition per step): quad_perm [1,0,3,2], [2,3,0,1], row_ror 4, 8 leave every
+// lane with its row's result; row_bcast:15 into rows 1 and 3 and row_bcast:31 into rows 2 and 3 leave the wave's in lane 63.
+// A DPP read needs two wait states after the VALU write of its source: values reduced together fill them for each other.
+#define DABGPU_RED_STEPS(OP, R)                                                                  \
+    OP " " R ", " R ", " R " quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
+    OP " " R ", " R ", " R " quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"      \
+    OP " " R ", " R ", " R " row_ror:4 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+    OP " " R ", " R ", " R " row_ror:8 row_mask:0xf bank_mask:0xf\n\ts_nop 1\n\t"                \
+    OP " " R ", " R ", " R " row_bcast:15 row_mask:0xa bank_mask:0xf\n\ts_nop 1\n\t"             \
+    OP " " R ", " R ", " R " row_bcast:31 row_mask:0xc bank_mask:0xf"
 DEV float wave_sum_dpp(float x)
 {
-    x += dpp_mov<0xB1>(x);    // quad_perm [1,0,3,2]
-    x += dpp_mov<0x4E>(x);    // quad_perm [2,3,0,1]
-    x += dpp_mov<0x124>(x);   // row_ror:4
-    x += dpp_mov<0x128>(x);   // row_ror:8  -> every lane holds the sum of its row of 16
-    return (lane_bcast(x, 0) + lane_bcast(x, 16)) + (lane_bcast(x, 32) + lane_bcast(x, 48));
+    asm volatile("s_nop 1\n\t" DABGPU_RED_STEPS("v_add_f32_dpp", "%0") : "+v"(x));
+    return lane_bcast(x, 63);
 }
 DEV float wave_max_dpp(float x)
 {
-    x = fmaxf(x, dpp_mov<0xB1>(x));
-    x = fmaxf(x, dpp_mov<0x4E>(x));
-    x = fmaxf(x, dpp_mov<0x124>(x));
-    x = fmaxf(x, dpp_mov<0x128>(x));
-    return fmaxf(fmaxf(lane_bcast(x, 0), lane_bcast(x, 16)), fmaxf(lane_bcast(x, 32), lane_bcast(x, 48)));
+    asm volatile("s_nop 1\n\t" DABGPU_RED_STEPS("v_max_f32_dpp", "%0") : "+v"(x));
+    return lane_bcast(x, 63);
 }
+#undef DABGPU_RED_STEPS
+// four values at once (each step's four instructions are independent: no wait states to pad); OP0 is the first value's
+// operation, the other three are sums
+#define DABGPU_RED4_STEP(OP0, CTRL)                                                              \
+    OP0 " %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"                          \
+    "v_add_f32_dpp %2, %2, %2 " CTRL "\n\tv_add_f32_dpp %3, %3, %3 " CTRL "\n\t"
+#define DABGPU_RED4(OP0)                                                                         \
+    "s_nop 1\n\t"                                                                               \
+    DABGPU_RED4_STEP(OP0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")                      \
+    DABGPU_RED4_STEP(OP0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")                      \
+    DABGPU_RED4_STEP(OP0, "row_ror:4 row_mask:0xf bank_mask:0xf")                                \
+    DABGPU_RED4_STEP(OP0, "row_ror:8 row_mask:0xf bank_mask:0xf")                                \
+    DABGPU_RED4_STEP(OP0, "row_bcast:15 row_mask:0xa bank_mask:0xf")                             \
+    DABGPU_RED4_STEP(OP0, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+DEV void wave_sum4_dpp(float &a, float &b, float &c, float &d)
+{
+    asm volatile(DABGPU_RED4("v_add_f32_dpp") "s_nop 0" : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+    a = lane_bcast(a, 63); b = lane_bcast(b, 63); c = lane_bcast(c, 63); d = lane_bcast(d, 63);
+}
+DEV void wave_max_sum3_dpp(float &mx, float &b, float &c, float &d)
+{
+    asm volatile(DABGPU_RED4("v_max_f32_dpp") "s_nop 0" : "+v"(mx), "+v"(b), "+v"(c), "+v"(d));
+    mx = lane_bcast(mx, 63); b = lane_bcast(b, 63); c = lane_bcast(c, 63); d = lane_bcast(d, 63);
+}
+#undef DABGPU_RED4
+#undef DABGPU_RED4_STEP
+// x, y summed over the four lanes of every DPP quad
+DEV void quad_sum2_dpp(float &x, float &y)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
+                 : "+v"(x), "+v"(y));
+}
+// two values (one wait state between the steps left to pad)
+#define DABGPU_RED2_STEP(OP0, CTRL)                                                              \
+    "s_nop 0\n\t" OP0 " %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"
+#define DABGPU_RED2(OP0)                                                                         \
+    "s_nop 0\n\t"                                                                               \
+    DABGPU_RED2_STEP(OP0, "quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf")                      \
+    DABGPU_RED2_STEP(OP0, "quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf")                      \
+    DABGPU_RED2_STEP(OP0, "row_ror:4 row_mask:0xf bank_mask:0xf")                                \
+    DABGPU_RED2_STEP(OP0, "row_ror:8 row_mask:0xf bank_mask:0xf")                                \
+    DABGPU_RED2_STEP(OP0, "row_bcast:15 row_mask:0xa bank_mask:0xf")                             \
+    DABGPU_RED2_STEP(OP0, "row_bcast:31 row_mask:0xc bank_mask:0xf")
+DEV void wave_sum2_dpp(float &a, float &b)
+{
+    asm volatile(DABGPU_RED2("v_add_f32_dpp") "s_nop 1" : "+v"(a), "+v"(b));
+    a = lane_bcast(a, 63); b = lane_bcast(b, 63);
+}
+DEV void wave_max_sum_dpp(float &mx, float &b)
+{
+    asm volatile(DABGPU_RED2("v_max_f32_dpp") "s_nop 1" : "+v"(mx), "+v"(b));
+    mx = lane_bcast(mx, 63); b = lane_bcast(b, 63);
+}
+#undef DABGPU_RED2
+#undef DABGPU_RED2_STEP
 
 // Gain of one OFDM symbol inside the fused kernel.  One pass: the DC bin of every
 // symbol is zero by construction (reference src/OfdmGenerator.cpp:209-210), so the
@@ -724,7 +790,7 @@ template <int T> DEV float symbol_gain_fused(const cf *v, const GainParams &gp, 
         qr = fmaf(v[i].x, v[i].x, qr); qi = fmaf(v[i].y, v[i].y, qi);
     }
     float f0 = on ? sr : 0.f, f1 = on ? si : 0.f, f2 = on ? qr : 0.f, f3 = on ? qi : 0.f;
-    f0 = wave_sum_dpp(f0); f1 = wave_sum_dpp(f1); f2 = wave_sum_dpp(f2); f3 = wave_sum_dpp(f3);
+    wave_sum4_dpp(f0, f1, f2, f3);
     if (NW > 1) {
         if ((t & 63) == 0) {
             red[4 * (t >> 6)] = f0; red[4 * (t >> 6) + 1] = f1;

@@ -91,7 +91,7 @@ template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, boo
 // FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
 // 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             EQ ? 4 : CFR ? 2 : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+                             EQ ? 4 : CFR ? (FROM_BITS && FIR ? 3 : 2) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
@@ -289,6 +289,10 @@ void tf_kernel(const TfArgs a)
     const int bit_slot = t < kBitWords ? t : kBitWords;   // kBitWords = dummy slot
 
     // the lane's 6 active carriers of symbol s
+    // MAG_IN_GAIN (the equalised-boundary variant with GainControl: every sample of the symbol is scaled by g after the
+    // transform anyway): the symbol's common carrier magnitude |y_s| is not applied to the twelve carrier components here but
+    // to the gain, g |y_s| -- one scalar product instead of twelve (everything between the carriers and the scaling is linear)
+    constexpr bool MAG_IN_GAIN = EQ && GAIN;
     auto load_active = [&](int s, cf *val) __attribute__((always_inline)) {
         if (FROM_BITS) {
             const float mg = s >= 1 ? mag_l[s - 1] : 0.f;
@@ -297,7 +301,8 @@ void tf_kernel(const TfArgs a)
                 const unsigned rot64 = ((unsigned)(s - 1) & 7u) << 6;        // (byte offset of the rotated copy)
                 const cf u = *reinterpret_cast<const cf *>(reinterpret_cast<const char *>(unit8) +
                                                           ((__builtin_amdgcn_ubfe(P, fpos[c], 2u) << 4) | rot64));
-                val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
+                if (MAG_IN_GAIN) val[c] = u;                                 // (the loop never sees the null symbol here)
+                else val[c] = s >= 1 ? mk(u.x * mg, u.y * mg) : mk(0.f, 0.f);   // blank NULL symbol: +0
             }
         } else {
             // position of bin tt + T r: r <= 3 -> bin - 1 (positive carriers first), r >= 5 -> bin - N + K.
@@ -399,17 +404,18 @@ void tf_kernel(const TfArgs a)
             pk = fmaxf(pk, mag2);
             sm += mag2;
             before[m] = v[m];
-            if (mag2 > clip2) {                                   // :320-330
-                const float f = sqrtf(clip2 / mag2);
-                v[m] = cscale(v[m], f);
-                ++nclip;
-            }
+            // :320-330, x * sqrt(clip^2 / |x|^2) as x * clip * rsq(|x|^2): one v_rsq_f32 and a select, no branch, no
+            // correctly rounded division and square root (twenty-odd instructions each; the factor is good to 1 ulp and
+            // the transforms that follow round more than that)
+            const bool over = mag2 > clip2;
+            v[m] = cscale(v[m], over ? fabsf(a.cfr_clip) * fast_rsq(mag2) : 1.0f);
+            nclip += over ? 1u : 0u;
         }
         if (stats) {
             // PAPRStats::process_block before CFR (src/PAPRStats.cpp:41-60): per-wave partials now,
             // combined by lane 0 behind the forward transform's barriers
-            pk = wave_max_dpp(lane_on ? pk : 0.f);
-            sm = wave_sum_dpp(lane_on ? sm : 0.f);
+            pk = lane_on ? pk : 0.f; sm = lane_on ? sm : 0.f;
+            wave_max_sum_dpp(pk, sm);
             if ((t & 63) == 0) { cfr_red[2 * (t >> 6)] = pk; cfr_red[2 * (t >> 6) + 1] = sm; }
         }
         F::template run<-1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
@@ -427,11 +433,10 @@ void tf_kernel(const TfArgs a)
             const cf c = cscale(v[m], 1.0f / (float)N);         // :349-350 (a power of two: exact)
             cf e = csub(refv[m], c);
             const float mag2 = e.x * e.x + e.y * e.y;
-            if (mag2 > eclip2) {                                  // :357-360
-                e = cscale(e, sqrtf(eclip2 / mag2));
-                ++neclip;
-            }
-            v[m] = cadd(c, e);
+            const bool over = mag2 > eclip2;                      // :357-360
+            const float f = over ? fabsf(a.cfr_errclip) * fast_rsq(mag2) : 1.0f;
+            neclip += over ? 1u : 0u;
+            v[m] = mk(fmaf(e.x, f, c.x), fmaf(e.y, f, c.y));
         }
         if (FIR) {
             // the corrected spectrum and its filtered copy go back to the time domain as one packed transform;
@@ -452,9 +457,10 @@ void tf_kernel(const TfArgs a)
             F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
         }
         if (stats) {
-            unsigned n1 = lane_on ? nclip : 0u, n2 = lane_on ? neclip : 0u;
-#pragma unroll
-            for (int o = 32; o > 0; o >>= 1) { n1 += __shfl_xor(n1, o, 64); n2 += __shfl_xor(n2, o, 64); }
+            // (a lane counts at most 8: the wave's sums are exact as floats, and the DPP adds cost no LDS round trips)
+            float c1 = lane_on ? (float)nclip : 0.f, c2_ = lane_on ? (float)neclip : 0.f;
+            wave_sum2_dpp(c1, c2_);
+            const unsigned n1 = (unsigned)c1, n2 = (unsigned)c2_;
             if ((t & 63) == 0) {
                 if (n1) atomicAdd(a.cfr_counts + 2 * (size_t)frame, n1);
                 if (n2) atomicAdd(a.cfr_counts + 2 * (size_t)frame + 1, n2);
@@ -470,10 +476,8 @@ void tf_kernel(const TfArgs a)
                     siq += before[m].x * before[m].x + before[m].y * before[m].y;
                     sdl += d.x * d.x + d.y * d.y;
                 }
-                pk2 = wave_max_dpp(lane_on ? pk2 : 0.f);
-                sm2 = wave_sum_dpp(lane_on ? sm2 : 0.f);
-                siq = wave_sum_dpp(lane_on ? siq : 0.f);
-                sdl = wave_sum_dpp(lane_on ? sdl : 0.f);
+                pk2 = lane_on ? pk2 : 0.f; sm2 = lane_on ? sm2 : 0.f; siq = lane_on ? siq : 0.f; sdl = lane_on ? sdl : 0.f;
+                wave_max_sum3_dpp(pk2, sm2, siq, sdl);
                 float *r2 = cfr_red + 2 * NW;
                 if ((t & 63) == 0) {
                     r2[4 * (t >> 6)] = pk2; r2[4 * (t >> 6) + 1] = sm2;
@@ -522,8 +526,8 @@ void tf_kernel(const TfArgs a)
         float pwr = 0.f;
 #pragma unroll
         for (int c = 0; c < 6; ++c) pwr += val[c].x * val[c].x + val[c].y * val[c].y;
-        q = wave_sum_dpp(lane_on ? 2.0f * q : 0.f);
-        pwr = wave_sum_dpp(lane_on ? pwr : 0.f);
+        q = lane_on ? 2.0f * q : 0.f; pwr = lane_on ? pwr : 0.f;
+        wave_sum2_dpp(q, pwr);
         if ((t & 63) == 0) { redf[2 * (t >> 6)] = pwr; redf[2 * (t >> 6) + 1] = q; }
     };
     auto spectral_gain = [&](const float *redf) __attribute__((always_inline)) -> float {
@@ -604,8 +608,7 @@ void tf_kernel(const TfArgs a)
                     acc.y = fmaf(x.y, tp, acc.y);
                 }
             }
-            acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);   // the 4 lanes of an output
-            acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);   // are one DPP quad
+            quad_sum2_dpp(acc.x, acc.y);                                    // the 4 lanes of an output are one DPP quad
             if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, t >> 2, acc);
         }
     };
@@ -622,8 +625,7 @@ void tf_kernel(const TfArgs a)
                 acc.x = fmaf(x.x, tp, acc.x);
                 acc.y = fmaf(x.y, tp, acc.y);
             }
-            acc.x += dpp_mov<0xB1>(acc.x); acc.y += dpp_mov<0xB1>(acc.y);
-            acc.x += dpp_mov<0x4E>(acc.x); acc.y += dpp_mov<0x4E>(acc.y);
+            quad_sum2_dpp(acc.x, acc.y);
             if (i < n_out && q == 0) put(out_pos + i0, t >> 2, acc);
         }
     };
@@ -689,13 +691,7 @@ void tf_kernel(const TfArgs a)
             cf y = mk(0.f, 0.f);
 #pragma unroll
             for (int k = 0; k < 11; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
-            asm volatile("s_nop 1\n\t"
-                         "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
-                         "s_nop 0\n\t"
-                         "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
-                         "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
-                         : "+v"(y.x), "+v"(y.y));
+            quad_sum2_dpp(y.x, y.y);
             if (t < 4 * C && q == 0) put(prev_pos + prev_seg - C, t >> 2, cadd(y, zp[kEqQL - C + i]));
         }
     };
@@ -867,6 +863,7 @@ void tf_kernel(const TfArgs a)
             // TII (f-4): the null symbol of the coded-bits path is added afterwards, scaled by the
             // multiplier of symbol 1 (src/GainControl.cpp:139-144)
             if (FROM_BITS && a.gain1 != nullptr && s == 1 && t == 0) a.gain1[frame] = g;
+            if (MAG_IN_GAIN) g *= mag_l[s - 1];
         }
 
         // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the
