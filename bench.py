@@ -275,8 +275,13 @@ def main():
     local_rank = device_index
     dev = torch.device("cuda", device_index)
 
-    def run_workload(workload, B, steps, warmup, fmt=None):
+    def run_workload(workload, B, steps, warmup, fmt=None, option=None):
         md = P.Modulator(mode=1, device=local_rank, max_frames=B, chunks_per_frame=args.chunks)
+        # rows f-3 / f-4 on the cfg 3 chain, with the values doc/example.ini of the reference suggests
+        if option == "cfr":
+            md.set_cfr(True, 50.0, 0.1)
+        elif option == "window":
+            md.set_window_overlap(10)
         # (s16: file-style normalisation for the native-rate chain, 30000/50000 where the polynomial needs |x| < 1)
         md.set_gain(P.GAIN_VAR, 1.0, (1.0 if workload != "cfg4" else 0.6) if fmt else 1.0 / 50000.0, 4.0)
         md.set_output_format(fmt)
@@ -543,13 +548,15 @@ def main():
             # (batch B in {1, 16, 256} next to the best; "_s16": FormatConverter fused into the last store)
             for wl, b2 in (("cfg2", bs), ("ifft_fir_stage", bs), ("cfg4", max(64, bs // 4)),
                            (args.workload + "_B1", 1), (args.workload + "_B16", 16), (args.workload + "_B256", 256),
-                           ("cfg3_s16", B), ("cfg4_s16", max(64, bs // 4))):
+                           ("cfg3_s16", B), ("cfg4_s16", max(64, bs // 4)),
+                           ("cfg3_cfr", max(64, bs // 2)), ("cfg3_window", max(64, bs // 2))):
                 if wl == args.workload:
                     continue
                 try:
-                    base = wl.split("_B")[0].replace("_s16", "")
+                    base = wl.split("_B")[0].replace("_s16", "").replace("_cfr", "").replace("_window", "")
+                    option = "cfr" if wl.endswith("_cfr") else ("window" if wl.endswith("_window") else None)
                     k = max(3, args.steps // 4) if b2 > 256 else (200 if b2 == 1 else 50)
-                    w2, k2 = run_workload(base, b2, k, 1, fmt="s16" if wl.endswith("_s16") else None)
+                    w2, k2 = run_workload(base, b2, k, 1, fmt="s16" if wl.endswith("_s16") else None, option=option)
                     algo2 = ALGO_BYTES[base] if not wl.endswith("_s16") else \
                         28800 + (ALGO_BYTES[base] - 28800) // 2                 # 4 bytes per sample written
                     gbps = algo2 * b2 / (k2 * 1e-3) / 1e9

@@ -841,11 +841,12 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     const bool post = mask & (DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY);
     const bool fir_fits = (int)c->cur.taps.size() - 1 <= c->g.sym_size - c->g.N &&
                           (int)c->cur.taps.size() <= tf_max_fused_taps();
-    // one fused kernel, unless the guard interval is windowed, the filter does not fit it, or CFR is on
+    // one fused kernel, unless the guard interval is windowed or the filter does not fit it
     // (then: IFFT[+CFR][+gain] -> guard kernel -> FIR kernel)
-    // (CFR has fused variants with the whole epilogue -- guard + FIR -- or with none of it)
+    // (CFR has fused variants with the whole epilogue -- guard + FIR --, with none of it, and, from coded bits, with the
+    // guard interval alone)
     const bool windowed = (c->cur.overlap > 0 || ((mask & DABGPU_STAGE_FIR) && !fir_fits) ||
-                           (c->cur.cfr_enable && !(mask & DABGPU_STAGE_FIR))) &&
+                           (c->cur.cfr_enable && !(mask & DABGPU_STAGE_FIR) && !from_bits)) &&
                           !(mask & DABGPU_STAGE_NOGUARD);
     if (windowed && c->cur.overlap > 0) {
         const size_t W = c->cur.overlap;

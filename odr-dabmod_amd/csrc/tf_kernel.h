@@ -91,11 +91,12 @@ template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, boo
 // FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
 // 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             EQ ? 4 : CFR ? (FROM_BITS && FIR ? 3 : 2) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+                             EQ ? 4 : CFR ? (FROM_BITS && GUARD ? 3 : 2) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
-    static_assert(!CFR || (GUARD == FIR), "CFR variants: the full fused epilogue, or none of it");
+    static_assert(!CFR || GUARD == FIR || (FROM_BITS && GUARD),
+                  "CFR variants: the full fused epilogue or none of it; the coded-bits chain also with the guard interval alone");
     static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR),
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
@@ -570,6 +571,32 @@ void tf_kernel(const TfArgs a)
     int prev_seg = 0;
     bool have_prev = false;
 
+    // Run-time tap count: lane q of an output's quad takes the taps q, q + 4, ... -- FOUR of them per trip, their eight LDS
+    // reads issued together and waited for once (one tap per trip is one LDS round trip per tap: twelve in a row for the
+    // default filter).  Taps past the filter count as zero and read the lane's first sample again.  Same order of
+    // accumulation as one tap per trip.  (Fully unrolled, the NT > 0 way, it pushes these variants into spilling.)
+    auto fir_quad_lane = [&](const cf *sp, int q) __attribute__((always_inline)) -> cf {
+        cf acc = mk(0.f, 0.f);
+#pragma unroll 1
+        for (int j = q; j < ntaps; j += 16) {
+            cf x[4];
+            float tp[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int jj = j + 4 * k;
+                const bool in = jj < ntaps;
+                x[k] = sp[in ? jj : q];
+                tp[k] = in ? taps_l[jj] : 0.f;
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                acc.x = fmaf(x[k].x, tp[k], acc.x);
+                acc.y = fmaf(x[k].y, tp[k], acc.y);
+            }
+        }
+        return acc;
+    };
+
     // boundary outputs of the previous segment: 4 lanes per output, shuffle-reduced
     constexpr int kThreads = T < 64 ? 64 : T;      // == blockDim.x (a compile-time constant keeps it out of the loop)
     auto boundary = [&](const cf *src) __attribute__((always_inline)) {
@@ -599,14 +626,7 @@ void tf_kernel(const TfArgs a)
                     acc.y = fmaf(x[k].y, tp[k], acc.y);
                 }
             } else {
-                // (rolled or lightly unrolled: fully unrolling its iterations pushes the kernel into spilling)
-#pragma unroll 1
-                for (int j = q; j < ntaps; j += 4) {
-                    const cf x = src[ii + j];
-                    const float tp = taps_l[j];
-                    acc.x = fmaf(x.x, tp, acc.x);
-                    acc.y = fmaf(x.y, tp, acc.y);
-                }
+                acc = fir_quad_lane(src + ii, q);
             }
             quad_sum2_dpp(acc.x, acc.y);                                    // the 4 lanes of an output are one DPP quad
             if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, t >> 2, acc);
@@ -618,13 +638,7 @@ void tf_kernel(const TfArgs a)
         for (int i0 = 0; i0 < n_out; i0 += kThreads / 4) {
             const int i = i0 + (t >> 2), q = t & 3;
             const int ii = i < n_out ? i : 0;
-            cf acc = mk(0.f, 0.f);
-            for (int j = q; j < ntaps; j += 4) {
-                const cf x = src[ii + j];
-                const float tp = taps_l[j];
-                acc.x = fmaf(x.x, tp, acc.x);
-                acc.y = fmaf(x.y, tp, acc.y);
-            }
+            cf acc = fir_quad_lane(src + ii, q);
             quad_sum2_dpp(acc.x, acc.y);
             if (i < n_out && q == 0) put(out_pos + i0, t >> 2, acc);
         }
@@ -1075,6 +1089,8 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
 #define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, EPI, EPI, 0, true>), grid, block, lds, s, a)
+#define TF_LAUNCH_CFR_GUARD(GN)                                                                \
+    hipLaunchKernelGGL((tf_kernel<LOGN, true, GN, true, false, 0, true>), grid, block, lds, s, a)
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
@@ -1082,9 +1098,12 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     if ((flags & TF_WINDOW) && !tf_has_window(a, flags)) return hipErrorInvalidValue;
     if ((flags & TF_EQ) && !tf_has_eq(a, flags)) return hipErrorInvalidValue;
     if (flags & TF_CFR) {
-        // with the whole fused epilogue (guard + FIR) or with none of it
-        if (gd != fr || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
-        if (fr) {
+        // with the whole fused epilogue (guard + FIR) or with none of it; from coded bits also with the guard interval alone
+        // (firfilter is off by default in the reference's configuration: src/ConfigParser.cpp:198)
+        if ((gd != fr && !(fb && gd)) || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
+        if (gd && !fr) {
+            if (gn) TF_LAUNCH_CFR_GUARD(true); else TF_LAUNCH_CFR_GUARD(false);
+        } else if (fr) {
             if (fb) { if (gn) TF_LAUNCH_CFR(true, true, true); else TF_LAUNCH_CFR(true, false, true); }
             else    { if (gn) TF_LAUNCH_CFR(false, true, true); else TF_LAUNCH_CFR(false, false, true); }
         } else {
@@ -1151,6 +1170,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     }
 #undef TF_LAUNCH
 #undef TF_LAUNCH_CFR
+#undef TF_LAUNCH_CFR_GUARD
     return hipGetLastError();
 }
 

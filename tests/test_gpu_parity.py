@@ -666,9 +666,11 @@ def test_ofdm_generator_with_cfr(pkg, mode):
         md.close()
 
 
-@pytest.mark.parametrize("mode,chunks", [(1, 1), (1, 5), (3, 1)])
-def test_chain_cfg3_with_cfr(pkg, mode, chunks):
-    """Full chain from coded bits with CFR: 3 frames in calls of 2 + 1, statistics per frame."""
+@pytest.mark.parametrize("mode,chunks,stages", [(1, 1, 3), (1, 5, 3), (3, 1, 3), (1, 1, 1), (1, 7, 1), (2, 1, 1), (1, 1, 0)])
+def test_chain_cfg3_with_cfr(pkg, mode, chunks, stages):
+    """Full chain from coded bits with CFR: 3 frames in calls of 2 + 1, statistics per frame.  stages 3: gain + FIRFilter
+    (CFR inside the fused epilogue); 1: gain, no FIRFilter -- the reference's default, firfilter.enabled = 0
+    (src/ConfigParser.cpp:198) -- with the guard interval fused; 0: neither."""
     md = pkg.Modulator(mode=mode, max_frames=2, chunks_per_frame=chunks)
     try:
         K, N = md.geometry["carriers"], md.geometry["spacing"]
@@ -677,12 +679,12 @@ def test_chain_cfg3_with_cfr(pkg, mode, chunks):
         md.set_cfr(True, clip, eclip)
         per = md.geometry["tf_input_bytes"]
         bits = np.stack([synth_bits(per, seed=1300 + i) for i in range(3)])
-        ch = O.Chain(mode=mode, stages=3, gain_mode=2, normalise=1.0 / 50000.0, cfr=(clip, eclip))
+        ch = O.Chain(mode=mode, stages=stages, gain_mode=2, normalise=1.0 / 50000.0, cfr=(clip, eclip))
         ref = ch.process(bits)
         want = [ch.cfr_stats(f) for f in range(3)]
-        y01 = md.chain(bits[:2], 3)
+        y01 = md.chain(bits[:2], stages)
         got = [md.cfr_stats(0), md.cfr_stats(1)]
-        y2 = md.chain(bits[2:], 3)
+        y2 = md.chain(bits[2:], stages)
         got.append(md.cfr_stats(0))
         y = np.concatenate([y01, y2])
         for f in range(3):
