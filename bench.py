@@ -290,7 +290,8 @@ def main():
         elif workload == "ifft_fir_stage":
             stages, from_bits = P.STAGE_GAIN | P.STAGE_FIR, False
         elif workload == "cfg3":
-            stages, from_bits = P.STAGE_GAIN | P.STAGE_FIR, True
+            # (option "nofir": the reference's default configuration, firfilter.enabled = 0, src/ConfigParser.cpp:198)
+            stages, from_bits = P.STAGE_GAIN | (0 if option == "nofir" else P.STAGE_FIR), True
         else:
             stages, from_bits = P.STAGE_GAIN | P.STAGE_FIR | P.STAGE_RESAMPLE | P.STAGE_POLY, True
             md.set_resampler(2048000, 8192000)
@@ -549,12 +550,12 @@ def main():
             for wl, b2 in (("cfg2", bs), ("ifft_fir_stage", bs), ("cfg4", max(64, bs // 4)),
                            (args.workload + "_B1", 1), (args.workload + "_B16", 16), (args.workload + "_B256", 256),
                            ("cfg3_s16", B), ("cfg4_s16", max(64, bs // 4)),
-                           ("cfg3_cfr", max(64, bs // 2)), ("cfg3_window", max(64, bs // 2))):
+                           ("cfg3_cfr", max(64, bs // 2)), ("cfg3_window", max(64, bs // 2)), ("cfg3_nofir", B)):
                 if wl == args.workload:
                     continue
                 try:
-                    base = wl.split("_B")[0].replace("_s16", "").replace("_cfr", "").replace("_window", "")
-                    option = "cfr" if wl.endswith("_cfr") else ("window" if wl.endswith("_window") else None)
+                    base = wl.split("_B")[0].replace("_s16", "").replace("_cfr", "").replace("_window", "").replace("_nofir", "")
+                    option = wl.rsplit("_", 1)[1] if wl.endswith(("_cfr", "_window", "_nofir")) else None
                     k = max(3, args.steps // 4) if b2 > 256 else (200 if b2 == 1 else 50)
                     w2, k2 = run_workload(base, b2, k, 1, fmt="s16" if wl.endswith("_s16") else None, option=option)
                     algo2 = ALGO_BYTES[base] if not wl.endswith("_s16") else \
