@@ -18,7 +18,7 @@ template <int CH> __global__ __launch_bounds__(256) void kseg(float2 *out, float
 // The frame kernel's stores exactly: lane t holds samples n = t + 256 m; the cyclic prefix (n >= 1544) goes to seg + (n - 1544),
 // the body to seg + 504 + n.  A symbol is 20416 bytes = 159.5 cache lines, so every other symbol's wave stores (512 bytes) start
 // in the middle of a 128-byte line.  ROT: those symbols use lane (t + 8) mod 256 for sample index t -- every wave store aligned.
-template <bool ROT> __global__ __launch_bounds__(256) void kframe(float2 *out, float v)
+template <bool ROT> __global__ __launch_bounds__(256) void kframe(float2 *out, float v, int work)
 {
     float2 *f = out + (size_t)blockIdx.x * kFrame;
     const int t = threadIdx.x;
@@ -26,6 +26,9 @@ template <bool ROT> __global__ __launch_bounds__(256) void kframe(float2 *out, f
     size_t seg = kNull;
     for (int s = 1; s < 77; ++s) {
         const int tn = (ROT && (s & 1)) ? ((t + 8) & 255) : t;
+        // `work` dependent FMAs per symbol and wave between the store bursts (the frame kernel computes ~1500 cycles' worth)
+        for (int i = 0; i < work; ++i) v = __builtin_fmaf(v, 1.0000001f, 1e-9f);
+        if (work > 0) __syncthreads();
 #pragma unroll
         for (int m = 0; m < 8; ++m) f[seg + 504 + tn + 256 * m] = make_float2(v + s, v);
         if (tn >= 8) f[seg + tn - 8] = make_float2(v + s, v);
@@ -92,8 +95,9 @@ int main(int argc, char **argv)
         CK(hipEventElapsedTime(&ms, e0, e1));
         printf("%s: %.0f GB/s (%.0f frames/s)\n", w == 1 ? " 8 bytes per lane and store" : w == 2 ? "16 bytes per lane and store" : w == 3 ? " 8 bytes, rotated start symbol" : w == 4 ? " 2 x 4 bytes non-temporal" : w == 5 ? " 8 bytes non-temporal" : "16 bytes non-temporal", 5.0 * B * kFrame * 8 / (ms * 1e-3) / 1e9, 5.0 * B / (ms * 1e-3));
     }
-    for (int rot = 0; rot < 2; ++rot) {
-        auto go = [&]() { if (rot) hipLaunchKernelGGL(kframe<true>, dim3(B), dim3(256), 0, 0, d, 1.0f); else hipLaunchKernelGGL(kframe<false>, dim3(B), dim3(256), 0, 0, d, 1.0f); };
+    for (int rot = 0; rot < 6; ++rot) {
+        const int work = rot < 2 ? 0 : (rot - 1) * 100;      // 0, 0, 100 ... 400 dependent FMAs (~4-5 cycles each per wave)
+        auto go = [&]() { if (rot == 1) hipLaunchKernelGGL(kframe<true>, dim3(B), dim3(256), 0, 0, d, 1.0f, 0); else hipLaunchKernelGGL(kframe<false>, dim3(B), dim3(256), 0, 0, d, 1.0f, work); };
         go(); go();
         CK(hipDeviceSynchronize());
         CK(hipEventRecord(e0));
@@ -102,7 +106,11 @@ int main(int argc, char **argv)
         CK(hipEventSynchronize(e1));
         float ms2;
         CK(hipEventElapsedTime(&ms2, e0, e1));
-        printf("frame kernel's stores (prefix + body)%s: %.0f GB/s (%.0f frames/s)\n", rot ? ", odd symbols on rotated lanes (all wave stores line-aligned)" : "",
+        char what[96];
+        if (rot == 1) snprintf(what, sizeof what, ", odd symbols on rotated lanes (all wave stores line-aligned)");
+        else if (rot) snprintf(what, sizeof what, ", %d dependent FMAs + a barrier per symbol", work);
+        else what[0] = 0;
+        printf("frame kernel's stores (prefix + body)%s: %.0f GB/s (%.0f frames/s)\n", what,
                5.0 * B * kFrame * 8 / (ms2 * 1e-3) / 1e9, 5.0 * B / (ms2 * 1e-3));
     }
     for (int rep = 0; rep < 2; ++rep) hipLaunchKernelGGL(kseg<1>, dim3(B * 77), dim3(256), 0, 0, d, 1.0f);
