@@ -25,7 +25,12 @@ KERNELS = {
 # is the architectural one (two passes of the SIMD-32), which the clock-throttled microbenchmark understates
 COST = {"valu": 2.04, "valu_pk": 4.0, "valu_dpp": 3.0, "valu_trans": 4.0, "ds_read_b32": 6.0, "ds_read_b64": 6.2,
         "ds_read_b128": 11.4, "ds_read2": 11.6, "ds_write_b32": 11.2, "ds_write_b64": 16.5, "ds_write_b128": 35.5,
-        "ds_write2": 16.6, "ds_other": 6.0, "salu": 0.0, "vmem": 4.0}
+        "ds_write2": 16.6, "ds_other": 6.0, "salu": 0.0, "vmem": 4.0,
+        # global / buffer STORES: 28 cycles per 512 bytes.  Measured on the cfg 3 kernel itself: a build
+        # without its ten 8-byte stores per wave and symbol runs 280 SIMD cycles per wave and symbol shorter -- and at exactly
+        # the VALU + LDS sum of this model (2238 measured, 2266 modelled).  tools/microbench/issue_cost.cpp: 8- and 16-byte
+        # stores cost the same per byte (40 - 47 cycles per 512 bytes with every wave of the CU storing at once).
+        "vmem_store_b32": 14.0, "vmem_store_b64": 28.0, "vmem_store_b128": 56.0}
 
 
 def classify(op):
@@ -42,7 +47,10 @@ def classify(op):
             if w in ("u8", "i8", "u16", "i16"): w = "b32"
             return "ds_%s_%s" % (m.group(1), w)
         return "ds_other"
-    if op.startswith(("global_", "buffer_", "flat_", "scratch_")): return "vmem"
+    if op.startswith(("global_", "buffer_", "flat_", "scratch_")):
+        m = re.match(r"(global|buffer|flat|scratch)_store_(dwordx4|dwordx2|dwordx3|dword|short|byte)", op)
+        if m: return "vmem_store_" + {"dwordx4": "b128", "dwordx3": "b128", "dwordx2": "b64"}.get(m.group(2), "b32")
+        return "vmem"
     if op in ("s_waitcnt", "s_barrier", "s_nop") or op.startswith(("s_cbranch", "s_branch")): return op if op in ("s_waitcnt", "s_barrier", "s_nop") else "branch"
     if op.startswith("s_"): return "salu"
     return "other"
@@ -108,11 +116,12 @@ def main():
         ticks = {k: round(m[k] * COST[k], 1) for k in m if k in COST and m[k]}
         valu_t = sum(v for k, v in ticks.items() if k.startswith("valu"))
         lds_t = sum(v for k, v in ticks.items() if k.startswith("ds_"))
+        vmem_t = sum(v for k, v in ticks.items() if k.startswith("vmem"))
         res[wl] = {"kernel": hit[0], "loop_iteration": unit, "loop_instructions": sum(m.values()),
                    "mix": dict(sorted(m.items())), "valu_instructions": nv,
                    "packed_fraction_of_valu": round(m["valu_pk"] / max(nv, 1), 4),
-                   "issue_model_simd_ticks": {"valu": round(valu_t, 1), "lds": round(lds_t, 1),
-                                              "vmem": ticks.get("vmem", 0.0), "total": round(valu_t + lds_t + ticks.get("vmem", 0.0), 1)},
+                   "issue_model_simd_ticks": {"valu": round(valu_t, 1), "lds": round(lds_t, 1), "vmem": round(vmem_t, 1),
+                                              "total": round(valu_t + lds_t + vmem_t, 1)},
                    "kernel_instructions_total": sum(mix_of(body).values())}
     txt = json.dumps(res, indent=1)
     if "--json" in sys.argv:
@@ -153,14 +162,16 @@ def phase_table():
     for name, m in agg.items():
         valu = sum(m[k] * COST[k] for k in m if k.startswith("valu"))
         lds = sum(m[k] * COST[k] for k in m if k.startswith("ds_"))
+        vm = sum(m[k] * COST[k] for k in m if k.startswith("vmem"))
         rows.append((name, sum(m[k] for k in m if k.startswith("valu")), sum(m[k] for k in m if k.startswith("ds_read")),
-                     sum(m[k] for k in m if k.startswith("ds_write")), m["vmem"], m["salu"], m["s_barrier"], valu, lds))
-    tot = sum(r[7] + r[8] for r in rows)
+                     sum(m[k] for k in m if k.startswith("ds_write")), sum(m[k] for k in m if k.startswith("vmem")), m["salu"],
+                     m["s_barrier"], valu, lds, vm))
+    tot = sum(r[7] + r[8] + r[9] for r in rows)
     print("cfg 3 symbol iteration by phase (static, timing build; the stamps' own s_waitcnt / s_memtime / s_sub / s_add not counted as SALU work)")
-    print("%-14s %6s %8s %9s %5s %5s %8s %11s %10s %7s" % ("phase", "VALU", "LDS rd", "LDS wr", "VMEM", "SALU", "barriers", "VALU ticks", "LDS ticks", "share"))
+    print("%-14s %6s %8s %9s %5s %5s %8s %11s %10s %11s %7s" % ("phase", "VALU", "LDS rd", "LDS wr", "VMEM", "SALU", "barriers", "VALU ticks", "LDS ticks", "VMEM ticks", "share"))
     for r in rows:
-        print("%-14s %6d %8d %9d %5d %5d %8d %11.0f %10.0f %6.1f%%" % (r + (100 * (r[7] + r[8]) / tot,)))
-    print("%-14s %6d %8d %9d %5d %5d %8d %11.0f %10.0f %6.1f%%" % (("total",) + tuple(sum(r[i] for r in rows) for i in range(1, 9)) + (100.0,)))
+        print("%-14s %6d %8d %9d %5d %5d %8d %11.0f %10.0f %11.0f %6.1f%%" % (r + (100 * (r[7] + r[8] + r[9]) / tot,)))
+    print("%-14s %6d %8d %9d %5d %5d %8d %11.0f %10.0f %11.0f %6.1f%%" % (("total",) + tuple(sum(r[i] for r in rows) for i in range(1, 10)) + (100.0,)))
 
 
 if __name__ == "__main__":

@@ -21,7 +21,7 @@ enum Kind {
     K_FMA, K_PKFMA, K_PKADD, K_PKMUL, K_ADD, K_MOV_DPP, K_PERMLANE32, K_BPERMUTE,
     K_DSW128, K_DSW64, K_DSW32, K_DSWADDTID, K_DSR128, K_DSR64, K_DSR32,
     K_MIX_PK_DSW128, K_MIX_PK_DSR128, K_MIX_PK_DSW64, K_MIX_FMA_DSW128, K_MIX_PK_DSWADDTID, K_PKFMA_HALF,
-    K_MIX_PK_DSW32, K_DSW2ST64, K_DSR2ST64, K_GSTORE8, K_GSTORE16, K_SALU, K_MIX_FMA_SALU, K_MIX_PK_SALU, K_WAITCNT, K_MIX_FMA_WAITCNT, K_COUNT
+    K_MIX_PK_DSW32, K_DSW2ST64, K_DSR2ST64, K_GSTORE8, K_GSTORE16, K_GSTORE8_L2, K_GSTORE16_L2, K_MIX_FMA_GSTORE8_L2, K_FMA_AFTER_GSTORE8_L2, K_MIX_FMA_GSTORE16_L2, K_MIX_FMA_GSTORE8x4_L2, K_SALU, K_MIX_FMA_SALU, K_MIX_PK_SALU, K_WAITCNT, K_MIX_FMA_WAITCNT, K_COUNT
 };
 static const char *kNames[K_COUNT] = {
     "v_fma_f32 x32", "v_pk_fma_f32 x32", "v_pk_add_f32 x32", "v_pk_mul_f32 x32", "v_add_f32 x32", "v_mov_b32_dpp x32",
@@ -31,6 +31,9 @@ static const char *kNames[K_COUNT] = {
     "32 v_pk_fma + 8 ds_write_b128", "32 v_pk_fma + 8 ds_read_b128", "32 v_pk_fma + 16 ds_write_b64", "32 v_fma + 8 ds_write_b128",
     "32 v_pk_fma + 32 ds_write_addtid_b32", "v_pk_fma_f32 x16 (half block)", "32 v_pk_fma + 32 ds_write_b32",
     "ds_write2st64_b32 x32", "ds_read2st64_b32 x32", "global_store_dwordx2 x8 (8 KB/wave iter)", "global_store_dwordx4 x8",
+    "global_store_dwordx2 x8, the same 4 KB per wave (L2)", "global_store_dwordx4 x8, the same 8 KB per wave (L2)",
+    "8 global_store_dwordx2 (L2) + 32 v_fma interleaved", "8 global_store_dwordx2 (L2), then 32 v_fma",
+    "4 global_store_dwordx4 (L2) + 32 v_fma interleaved", "4 global_store_dwordx2 (L2) + 32 v_fma interleaved",
     "s_add_u32 x32", "32 v_fma + 32 s_add interleaved", "32 v_pk_fma + 32 s_add interleaved", "s_waitcnt lgkmcnt(0) x32", "32 v_fma + 32 s_waitcnt interleaved"};
 
 template <int KIND> __global__ __launch_bounds__(256) void k(int iters, unsigned long long *cyc, float *sink, float4 *gout)
@@ -186,6 +189,47 @@ template <int KIND> __global__ __launch_bounds__(256) void k(int iters, unsigned
 #pragma unroll
             for (int j = 0; j < 8; ++j) g2[(size_t)j * 65536 * 16 + (size_t)(i & 15) * 65536] = make_float2(a0.x, a1.x);
         }
+        // stores that stay in L2 (every wave rewrites its own lines): the cost of ISSUING a store, not of HBM
+        if (KIND == K_GSTORE8_L2) {
+            float2 *g2 = reinterpret_cast<float2 *>(gout) + ((size_t)blockIdx.x * 256 + t);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) g2[(size_t)j * 65536 * 4] = make_float2(a0.x, a1.x);
+        }
+        if (KIND == K_GSTORE16_L2) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) gp[(size_t)j * 65536 * 4] = make_float4(a0.x, a1.x, a2.x, a3.x);
+        }
+        if (KIND == K_MIX_FMA_GSTORE8_L2 || KIND == K_FMA_AFTER_GSTORE8_L2) {
+            float2 *g2 = reinterpret_cast<float2 *>(gout) + ((size_t)blockIdx.x * 256 + t);
+            if (KIND == K_FMA_AFTER_GSTORE8_L2) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) g2[(size_t)j * 65536 * 4] = make_float2(a0.x, a1.x);
+                asm volatile(REP4(F8) FREGS);
+            } else {
+#pragma unroll
+                for (int j = 0; j < 8; j += 2) {
+                    g2[(size_t)j * 65536 * 4] = make_float2(a0.x, a1.x);
+                    g2[(size_t)(j + 1) * 65536 * 4] = make_float2(a0.x, a1.x);
+                    asm volatile(F8 FREGS);
+                }
+            }
+        }
+        if (KIND == K_MIX_FMA_GSTORE16_L2) {
+            float4 *g4 = gout + ((size_t)blockIdx.x * 256 + t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {           // (four stores of 1 KB: the bytes of eight dwordx2 stores)
+                g4[(size_t)j * 65536 * 2] = make_float4(a0.x, a1.x, a2.x, a3.x);
+                asm volatile(F8 FREGS);
+            }
+        }
+        if (KIND == K_MIX_FMA_GSTORE8x4_L2) {
+            float2 *g2 = reinterpret_cast<float2 *>(gout) + ((size_t)blockIdx.x * 256 + t);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                g2[(size_t)j * 65536 * 4] = make_float2(a0.x, a1.x);
+                asm volatile(F8 FREGS);
+            }
+        }
         if (KIND == K_GSTORE16) {
 #pragma unroll
             for (int j = 0; j < 8; ++j) gp[(size_t)j * 65536 * 16 + (size_t)(i & 15) * 65536] = make_float4(a0.x, a1.x, a2.x, a3.x);
@@ -267,5 +311,11 @@ int main(int argc, char **argv)
     run<K_MIX_FMA_WAITCNT>(iters, dcyc, dsink, gout);
     run<K_GSTORE8>(iters / 4, dcyc, dsink, gout);
     run<K_GSTORE16>(iters / 4, dcyc, dsink, gout);
+    run<K_GSTORE8_L2>(iters, dcyc, dsink, gout);
+    run<K_GSTORE16_L2>(iters, dcyc, dsink, gout);
+    run<K_MIX_FMA_GSTORE8_L2>(iters, dcyc, dsink, gout);
+    run<K_FMA_AFTER_GSTORE8_L2>(iters, dcyc, dsink, gout);
+    run<K_MIX_FMA_GSTORE16_L2>(iters, dcyc, dsink, gout);
+    run<K_MIX_FMA_GSTORE8x4_L2>(iters, dcyc, dsink, gout);
     return 0;
 }
