@@ -224,7 +224,7 @@ DABGPU_API int dabgpu_fir_inverse_design(const float *taps, size_t ntaps, float 
 /* FormatConverter as the last step of the chain (the reference wires it after cifPoly when the output is not
  * complexf, src/DabModulator.cpp:270-276, :407): format = 0 (complexf, the default) or DABGPU_FMT_*.  With s16 the
  * chain's last kernel stores the integers itself where it has a variant for it (Mode I coded-bits chain ending in
- * the filter, or in the x2 / x4 resampler with or without the polynomial predistorter) -- half the bytes written,
+ * the guard interval or in the default-length filter, or in the x2 / x4 resampler with or without the polynomial predistorter) -- half the bytes written,
  * half the bytes copied to the host; every other combination converts in a kernel of its own.  Output sizes of
  * dabgpu_chain_out_bytes_per_frame / _process / _submit follow the format.  dabgpu_get_num_clipped: the number of
  * clipped components of the most recent chain call (FormatConverter::get_num_clipped_samples, :56-59), after

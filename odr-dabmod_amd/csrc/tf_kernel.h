@@ -1160,7 +1160,15 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
         return hipGetLastError();
     }
-    if (flags & TF_OUT_S16) return hipErrorInvalidValue;         // (callers ask tf_has_s16 first)
+    if (flags & TF_OUT_S16) {
+        // the reference's default chain (no FIRFilter) with s16 output, Mode I: any gain mode
+        if (LOGN != 11 || NT != 0 || !fb || !gd || fr || !a.clipped) return hipErrorInvalidValue;   // (callers ask tf_has_s16 first)
+        if constexpr (LOGN == 11 && NT == 0) {
+            if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, false, 0, false, false, false, 1>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<11, true, false, true, false, 0, false, false, false, 1>), grid, block, lds, s, a);
+        }
+        return hipGetLastError();
+    }
     if (fb) {
         if (gn) { if (fr) TF_LAUNCH(true, true, true, true); else if (gd) TF_LAUNCH(true, true, true, false); else TF_LAUNCH(true, true, false, false); }
         else    { if (fr) TF_LAUNCH(true, false, true, true); else if (gd) TF_LAUNCH(true, false, true, false); else TF_LAUNCH(true, false, false, false); }

@@ -67,8 +67,10 @@ bool tf_has_eq(const TfArgs &a, unsigned flags)
 bool tf_has_s16(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
-    return a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & TF_CFR) &&
-           (!(flags & TF_GAIN) || a.gain.mode != 1);
+    if (a.g.logN != 11 || (flags & (TF_CFR | TF_WINDOW))) return false;
+    // without FIRFilter (the reference's default): every gain mode
+    if ((flags & want) == (TF_FROM_BITS | TF_GUARD)) return true;
+    return a.ntaps == 45 && (flags & want) == want && (!(flags & TF_GAIN) || a.gain.mode != 1);
 }
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)

@@ -1423,6 +1423,19 @@ def test_chain_s16_stored_by_the_frame_kernel(pkg, gain):
         assert clipped > 0                                # the clip counter is exercised
 
 
+@pytest.mark.parametrize("gain", [(2, 1.0), (2, 2.5), (1, 1.0), (0, 1.0), (None, 0)])
+def test_chain_s16_stored_by_the_frame_kernel_without_firfilter(pkg, gain):
+    """The reference's default chain (firfilter.enabled = 0) with s16 output: the same fused store, every gain mode."""
+    def setup(md):
+        md._rs_out = 2048000
+        if gain[0] is not None:
+            md.set_gain(gain[0], gain[1], 1.0 if gain[0] != 1 else 0.9, 4.0)
+    stages = pkg.STAGE_GAIN if gain[0] is not None else 0
+    clipped = _chain_formats_case(pkg, 1, stages, "s16", setup)
+    if gain == (2, 2.5):
+        assert clipped > 0
+
+
 @pytest.mark.parametrize("out_rate,poly", [(8192000, True), (8192000, False), (4096000, True)])
 def test_chain_s16_stored_by_the_resampler(pkg, out_rate, poly):
     """cfg 4 with s16 output: the x2 / x4 resampler converts in its store (polynomial predistorter before it)."""

@@ -61,3 +61,4 @@ for rate in (4096000, 8192000, 3072000, 1024000, 2500000):
 run("resample 8192000, no poly", mask=7, setup=lambda m: m.set_resampler(2048000, 8192000), B=1024)
 run("poly only (native rate)", mask=7, setup=poly, B=1024)
 run("LUT only (native rate)", mask=7, setup=lambda m: m.set_lut(1.0 / 32768, np.linspace(1.0, 1.2, 32).astype(np.float32)), B=1024)
+run("no FIR -> s16", mask=1, fmt="s16")
