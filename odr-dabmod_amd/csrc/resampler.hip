@@ -271,7 +271,7 @@ void resampler_kernel(const ResamplerArgs a, int hops_per_run)
 }
 
 // ===========================================================================
-// a10 + a11 at the BASELINE config 4 shape (nin = 4096, x4): resampler16_kernel.
+// a10 + a11 at the BASELINE config 4 shape (nin = 4096, x4; also x2): resampler16_kernel.
 //
 // Two things differ from resampler_kernel above.
 // (1) HOPS ARE INDEPENDENT WORK ITEMS.  out_h = second_half(Y_{h-1}) + first_half(Y_h) and the interpolation
@@ -401,11 +401,12 @@ struct Fft16 {
     }
 };
 
-template <bool POLY, bool S16> __global__ __launch_bounds__(256, 2)
+template <bool POLY, bool S16, int Q = 4> __global__ __launch_bounds__(256, 2)
 void resampler16_kernel(const ResamplerArgs a, int hops_per_run)
 {
     typedef Fft16 F;
-    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, Q = 4, HOUT = HIN * Q, NOUT = NIN * Q;
+    static_assert(Q == 2 || Q == 4, "x2 and x4");
+    constexpr int NIN = F::N, T = F::T, HIN = NIN / 2, HOUT = HIN * Q, NOUT = NIN * Q;
     unsigned nclip = 0;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *xbuf = reinterpret_cast<cf *>(smem);                       // two exchange buffers
@@ -441,12 +442,12 @@ void resampler16_kernel(const ResamplerArgs a, int hops_per_run)
         const long i = (h + k) * HIN + q;
         return i < NIN ? a.halo[i] : a.in[i - NIN];
     };
-    // branch twiddle of bin t + 256 m for branch p:  W_nout^{kappa p} = W_nout^{t p} * e^{2 pi i m p / 64}
+    // branch twiddle of bin t + 256 m for branch p:  W_nout^{kappa p} = W_nout^{t p} * e^{2 pi i m p / (16 Q)}
     // (* (-i)^p for the negative-frequency half, kappa = k - nin): one table value per branch and lane, the rest are
     // compile-time rotations; the Nyquist bin (lane 0, slot 8), which the reference places at +nin/2 AND -nin/2
     // (src/Resampler.cpp:153-164), gets the sum of both twiddles
     auto branch_rot = [](int p, int m) __attribute__((always_inline)) -> cf {
-        const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % 64) / 64.0
+        const double ang = 2.0 * 3.14159265358979323846 * (double)((m * p) % (16 * Q)) / (double)(16 * Q)
                            - (m >= 8 ? 2.0 * 3.14159265358979323846 * (double)p / (double)Q : 0.0);
         return mk((float)__builtin_cos(ang), (float)__builtin_sin(ang));
     };
@@ -516,15 +517,19 @@ void resampler16_kernel(const ResamplerArgs a, int hops_per_run)
         uint32_t *dst16 = reinterpret_cast<uint32_t *>(a.out) + (size_t)h * HOUT;
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
-            cf a0 = mk(fmaf(fN, b0[m].x, sgn * ny.x), fmaf(fN, b0[m].y, sgn * ny.y)), a1 = o[m], a2 = o[8 + m], a3 = o[16 + m];
-            if (POLY) { poly_apply2(a0, a1, pc); poly_apply2(a2, a3, pc); }
+            cf a0 = mk(fmaf(fN, b0[m].x, sgn * ny.x), fmaf(fN, b0[m].y, sgn * ny.y)), a1 = o[m];
+            cf a2 = Q == 4 ? o[(Q == 4 ? 8 : 0) + m] : a0, a3 = Q == 4 ? o[(Q == 4 ? 16 : 0) + m] : a1;
+            if (POLY) { poly_apply2(a0, a1, pc); if (Q == 4) poly_apply2(a2, a3, pc); }
             const size_t at = (size_t)Q * (t + T * m);
             if (S16) {
-                *reinterpret_cast<uint4 *>(dst16 + at) = make_uint4(s16_pack(a0, nclip), s16_pack(a1, nclip), s16_pack(a2, nclip), s16_pack(a3, nclip));
+                if (Q == 4)
+                    *reinterpret_cast<uint4 *>(dst16 + at) = make_uint4(s16_pack(a0, nclip), s16_pack(a1, nclip), s16_pack(a2, nclip), s16_pack(a3, nclip));
+                else
+                    *reinterpret_cast<uint2 *>(dst16 + at) = make_uint2(s16_pack(a0, nclip), s16_pack(a1, nclip));
             } else {
                 float4 *d4 = reinterpret_cast<float4 *>(dst + at);
                 d4[0] = make_float4(a0.x, a0.y, a1.x, a1.y);
-                d4[1] = make_float4(a2.x, a2.y, a3.x, a3.y);
+                if (Q == 4) d4[1] = make_float4(a2.x, a2.y, a3.x, a3.y);
             }
         }
 #pragma unroll
@@ -546,35 +551,33 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
     const bool poly = a.poly != nullptr;
     switch (Q) {
         case 2:
-            if (a.clipped) {
-                if constexpr (LOGNIN == 12) {
-                    if (poly) hipLaunchKernelGGL((resampler_kernel<12, 2, true, true>), grid, block, lds, s, a, hpr);
-                    else hipLaunchKernelGGL((resampler_kernel<12, 2, false, true>), grid, block, lds, s, a, hpr);
-                    break;
-                }
-                return hipErrorInvalidValue;
-            }
-            if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, true>), grid, block, lds, s, a, hpr);
-            else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
-            break;
         case 4:
             if constexpr (LOGNIN == 12) {
-                // the BASELINE config 4 shape: hop-independent radix-16 kernel, three 256-lane workgroups per CU.  No run
-                // prologue, so short streams are cut into single hops; long ones into runs of 24 (four runs per frame)
+                // Mode I (the BASELINE config 4 shape, and x2): hop-independent radix-16 kernel, two 256-lane workgroups per CU.
+                // No run prologue, so short streams are cut into single hops; long ones into runs of 24 (four runs per frame)
                 const int hpr16 = (int)std::max<size_t>(1, std::min<size_t>(24, a.nhops / 1536));
                 const dim3 grid16((unsigned)((a.nhops + hpr16 - 1) / hpr16)), block16(256);
                 const size_t lds16 = (size_t)(2 * Fft16::LDS_ELEMS + 256 + 8) * sizeof(float2) + (size_t)(NIN / 2) * sizeof(float);
                 // (more than 64 KiB of dynamic LDS has to be asked for)
-#define RS16_LAUNCH(P, F)                                                                                              \
+#define RS16_LAUNCH(P, F, QQ)                                                                                          \
                 do {                                                                                                   \
-                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resampler16_kernel<P, F>),       \
+                    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resampler16_kernel<P, F, QQ>),   \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);        \
                     if (e != hipSuccess) return e;                                                                     \
-                    hipLaunchKernelGGL((resampler16_kernel<P, F>), grid16, block16, lds16, s, a, hpr16);               \
+                    hipLaunchKernelGGL((resampler16_kernel<P, F, QQ>), grid16, block16, lds16, s, a, hpr16);           \
                 } while (0)
-                if (a.clipped) { if (poly) RS16_LAUNCH(true, true); else RS16_LAUNCH(false, true); }
-                else           { if (poly) RS16_LAUNCH(true, false); else RS16_LAUNCH(false, false); }
+                if (Q == 4) {
+                    if (a.clipped) { if (poly) RS16_LAUNCH(true, true, 4); else RS16_LAUNCH(false, true, 4); }
+                    else           { if (poly) RS16_LAUNCH(true, false, 4); else RS16_LAUNCH(false, false, 4); }
+                } else {
+                    if (a.clipped) { if (poly) RS16_LAUNCH(true, true, 2); else RS16_LAUNCH(false, true, 2); }
+                    else           { if (poly) RS16_LAUNCH(true, false, 2); else RS16_LAUNCH(false, false, 2); }
+                }
 #undef RS16_LAUNCH
+            } else if (Q == 2) {
+                if (a.clipped) return hipErrorInvalidValue;
+                if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, true>), grid, block, lds, s, a, hpr);
+                else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
             } else {
                 if (a.clipped) return hipErrorInvalidValue;
                 if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
