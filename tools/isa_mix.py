@@ -19,7 +19,7 @@ KERNELS = {
              r"tf_kernel<11, false, false, true, false, 0, false, false, false, 0, false, false>", "OFDM symbol"),
     "ifft_fir_stage": ("tf_inst.hip", ["-DTF_LOGN=11", "-DTF_NT=45"],
                        r"tf_kernel<11, false, true, true, true, 45, false, true, true, 0, false, false>", "OFDM symbol"),
-    "cfg4": ("resampler.hip", [], r"resampler16_kernel<true, false>", "hop (2048 samples in, 8192 out)"),
+    "cfg4": ("resampler.hip", [], r"resampler16_kernel<true, false, 4>", "hop (2048 samples in, 8192 out)"),
 }
 # SIMD ticks per wave-instruction with >= 3 waves per SIMD (profiles/r02_issue_cost_microbench.txt); the packed VALU cost
 # is the architectural one (two passes of the SIMD-32), which the clock-throttled microbenchmark understates
