@@ -43,6 +43,21 @@ def test_drop_in_headers_keep_the_reference_constructor_signatures():
         assert sig in text, sig
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is not on this machine")
+def test_drop_in_adapters_compile_against_the_reference_headers(tmp_path):
+    """INTEGRATION.md's claim, checked where the reference is at hand: GpuStages.{h,cpp} alone in a directory -- no host-mirror
+    header beside them -- compile against the reference's own ModPlugin.h / Buffer.h / RemoteControl.h (-I<reference>/src
+    -I<reference>/lib) and the C-ABI header (-I<repo>/include).  PACKAGE_NAME is what the reference's generated config.h
+    defines for lib/Log.h."""
+    import shutil
+    for f in ("GpuStages.cpp", "GpuStages.h"):
+        shutil.copy(os.path.join(HOST, f), str(tmp_path / f))
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DPACKAGE_NAME=\"odr-dabmod\"", "-I/root/reference/src",
+                        "-I/root/reference/lib", "-I/root/reference", "-I" + os.path.join(ROOT, "include"), "GpuStages.cpp"],
+                       cwd=str(tmp_path), capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [1, 2])
 def test_flowgraph_of_drop_in_stages_matches_oracle(tmp_path, mode):
