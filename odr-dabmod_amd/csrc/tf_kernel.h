@@ -91,7 +91,7 @@ template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, boo
 // FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
 // 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             EQ ? 4 : CFR ? (FROM_BITS && GUARD ? 3 : 2) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+                             EQ ? 4 : CFR ? (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
@@ -100,7 +100,7 @@ void tf_kernel(const TfArgs a)
     static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR),
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
-    static_assert(!WIN || (FROM_BITS && GUARD && !CFR && OFMT == 0), "WIN: coded-bits chain with guard interval");
+    static_assert(!WIN || (FROM_BITS && GUARD && OFMT == 0), "WIN: coded-bits chain with guard interval");
     static_assert(!(WIN && FIR) || (!ZONLY && !EQ && NT == 0 && !GVAR),
                   "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count");
     static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY && !WIN),
@@ -175,7 +175,7 @@ void tf_kernel(const TfArgs a)
     // [x[N-W-C .. N) | x[0 .. W)] (C + 2W each), the next symbol's x[N-cp-W .. N-cp+W+C) (2W + C), the windowed stream
     // U around the seam (2W + 2C), the window
     const int wfC = (WIN && FIR) ? a.ntaps - 1 : 0, wfLP = wfC + 2 * W;
-    cf *wfb = tw8_l + 56;
+    cf *wfb = tw8_l + 56 + (CFR ? 3 * ((T + 63) / 64) : 0);        // (behind cfr_red: 6 floats per wave)
     cf *wf_cur = wfb + 2 * wfLP, *wf_U = wf_cur + (2 * W + wfC);
     if (WIN && FIR) win_l = reinterpret_cast<float *>(wf_U + (2 * W + 2 * wfC));
     if (WIN)
@@ -838,7 +838,7 @@ void tf_kernel(const TfArgs a)
             if (CFR) {
                 cf refv[8];
                 place(val, refv);
-                cfr_symbol(v, z, refv, s, true);
+                cfr_symbol(v, z, refv, s, !lookahead);       // (WIN without FIR looks one symbol ahead: no statistics for it)
             }
         }
 
@@ -1101,7 +1101,15 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         // with the whole fused epilogue (guard + FIR) or with none of it; from coded bits also with the guard interval alone
         // (firfilter is off by default in the reference's configuration: src/ConfigParser.cpp:198)
         if ((gd != fr && !(fb && gd)) || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
-        if (gd && !fr) {
+        if (flags & TF_WINDOW) {
+            // OFDM windowing with crest-factor reduction (coded-bits chain): the windowed variants with the CFR'd symbol
+            if (!tf_has_window(a, flags)) return hipErrorInvalidValue;
+#define TF_LAUNCH_CFR_WIN(GN, FR) \
+            hipLaunchKernelGGL((tf_kernel<LOGN, true, GN, true, FR, 0, true, false, false, 0, true>), grid, block, lds, s, a)
+            if (fr) { if (gn) TF_LAUNCH_CFR_WIN(true, true); else TF_LAUNCH_CFR_WIN(false, true); }
+            else    { if (gn) TF_LAUNCH_CFR_WIN(true, false); else TF_LAUNCH_CFR_WIN(false, false); }
+#undef TF_LAUNCH_CFR_WIN
+        } else if (gd && !fr) {
             if (gn) TF_LAUNCH_CFR_GUARD(true); else TF_LAUNCH_CFR_GUARD(false);
         } else if (fr) {
             if (fb) { if (gn) TF_LAUNCH_CFR(true, true, true); else TF_LAUNCH_CFR(true, false, true); }

@@ -40,10 +40,10 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
 }
 
 // the frame-kernel variants that window the guard interval themselves: coded-bits chain with guard interval and
-// without FIR / CFR / s16 store, overlap up to kWinMax (and inside the cyclic prefix)
+// without s16 store (with or without FIRFilter, with or without CFR), overlap up to kWinMax (and inside the cyclic prefix)
 bool tf_has_window(const TfArgs &a, unsigned flags)
 {
-    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_CFR | TF_OUT_S16;
+    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_OUT_S16;
     if ((flags & want) != want || (flags & never) || a.overlap < 1 || a.overlap > kWinMax) return false;
     // with FIR: the filter's look-ahead and the window must both fit into the cyclic prefix
     if (flags & TF_FIR)

@@ -697,6 +697,35 @@ def test_chain_cfg3_with_cfr(pkg, mode, chunks, stages):
         md.close()
 
 
+@pytest.mark.parametrize("stages,overlap,chunks", [(3, 10, 1), (3, 100, 5), (1, 10, 1), (1, 64, 7), (3, 10, 77)])
+def test_chain_cfr_with_windowed_guard(pkg, stages, overlap, chunks):
+    """CFR and OFDM windowing together (the two crest / spectrum options a transmitter enables side by side): the windowed
+    frame-kernel variants run on the CFR'd symbol, with FIRFilter (stages 3) and without (1); samples and statistics."""
+    md = pkg.Modulator(mode=1, max_frames=2, chunks_per_frame=chunks)
+    try:
+        N = md.geometry["spacing"]
+        clip, eclip = 50.0, 0.1
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_cfr(True, clip, eclip)
+        md.set_window_overlap(overlap)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=1700 + i) for i in range(3)])
+        ch = O.Chain(mode=1, stages=stages, gain_mode=2, normalise=1.0 / 50000.0, cfr=(clip, eclip), window_overlap=overlap)
+        ref = ch.process(bits)
+        want = [ch.cfr_stats(f) for f in range(3)]
+        y01 = md.chain(bits[:2], stages)
+        got = [md.cfr_stats(0), md.cfr_stats(1)]
+        y2 = md.chain(bits[2:], stages)
+        got.append(md.cfr_stats(0))
+        y = np.concatenate([y01, y2])
+        for f in range(3):
+            assert rel_rms(y[f], ref[f]) < REL_RMS, (f, rel_rms(y[f], ref[f]))
+            assert got[f]["mer_symbol"] == f + 1
+            _check_cfr_stats(got[f], want[f][0], want[f][1], N)
+    finally:
+        md.close()
+
+
 def test_chain_cfr_with_tii_and_resampler(pkg):
     """CFR acts per symbol, so the cached TII null-symbol response simply goes through it as well."""
     def setup(md):
