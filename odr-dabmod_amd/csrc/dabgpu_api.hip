@@ -866,7 +866,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
         HIPCHK(c, hipMemsetAsync(c->d_clip.p, 0, 16, s));
         clip = (unsigned long long *)c->d_clip.p;
         c->clip_stream = s;
-        if (fmt == DABGPU_FMT_S16 && !tii && !windowed && from_bits) {
+        if (fmt == DABGPU_FMT_S16 && from_bits) {
             // ask the kernels' own predicates (the ones their launchers test), so that the separate convert kernel is taken
             // whenever a variant does not exist in this build
             const bool poly_ok = !(mask & DABGPU_STAGE_POLY) || (!c->cur.poly_is_lut && (mask & DABGPU_STAGE_RESAMPLE));
@@ -877,7 +877,9 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             const unsigned tflags = TF_FROM_BITS | ((mask & DABGPU_STAGE_GAIN) ? TF_GAIN : 0) |
                                     ((mask & DABGPU_STAGE_NOGUARD) ? 0 : TF_GUARD) | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0) |
                                     (c->cur.cfr_enable ? TF_CFR : 0);
-            fuse_native = !post && tf_has_s16(ta, tflags);
+            // (TII is added to the native-rate complexf stream after the frame kernel, a windowed guard interval has variants
+            // without the s16 store only: the frame kernel's own s16 store is out then, the resampler's is not)
+            fuse_native = !post && !tii && !windowed && tf_has_s16(ta, tflags);
             ResamplerArgs ra{};
             ra.nin = c->rs_nin;
             ra.nout = c->rs_nout;

@@ -1478,6 +1478,23 @@ def test_chain_s16_stored_by_the_resampler(pkg, out_rate, poly):
     _chain_formats_case(pkg, 1, stages, "s16", setup)
 
 
+@pytest.mark.parametrize("case", ["tii", "windowed", "tii_windowed_cfr"])
+def test_chain_s16_stored_by_the_resampler_behind_tii_and_windowing(pkg, case):
+    """TII and a windowed guard interval happen at the native rate; the x4 resampler behind them still stores s16 itself."""
+    def setup(md):
+        md._rs_out = 8192000
+        md.set_gain(2, 1.0, 30000.0 / 50000.0, 4.0)
+        md.set_resampler(2048000, 8192000)
+        md.set_poly(POLY_AM, POLY_PM)
+        if "tii" in case:
+            md.set_tii(True, 3, 5)
+        if "windowed" in case:
+            md.set_window_overlap(10)
+        if "cfr" in case:
+            md.set_cfr(True, 50.0, 0.1)
+    _chain_formats_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY, "s16", setup)
+
+
 @pytest.mark.parametrize("case", ["mode2", "u8", "s8", "tii", "windowed", "rational", "nofir"])
 def test_chain_output_format_on_every_other_path(pkg, case):
     """Where no kernel variant stores the format itself the chain converts in format_kernel: same bytes."""
