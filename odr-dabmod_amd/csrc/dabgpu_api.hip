@@ -662,10 +662,13 @@ size_t bytes_per_sample(int fmt) { return fmt ? dabgpu_format_size(fmt) : sizeof
 // The chain on device pointers.  from_bits: d_in is coded bits, else carriers.
 // The native-rate part of the chain (everything up to and including FIRFilter) for n_frames frames
 // into native_out (`native` samples per frame).
+// tii_seg / tii_done: the caller's cached TII segment; *tii_done says whether the frame kernel added it itself (else the caller
+// runs launch_tii_add on the result)
 int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,
                float2 *native_out, size_t native, float *gain1, hipStream_t s, bool keep_stats = true,
-               unsigned long long *s16_clipped = nullptr)
+               unsigned long long *s16_clipped = nullptr, const float2 *tii_seg = nullptr, bool *tii_done = nullptr)
 {
+    if (tii_done) *tii_done = false;
     TfArgs a{};
     a.clipped = s16_clipped;
 #ifdef DABGPU_PHASE_TIMING
@@ -725,6 +728,11 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
         a.out = native_out;
         a.out_stride = native;
+        if (tii_seg && tf_has_tii(a, flags)) {
+            a.tii_seg = tii_seg;
+            a.tii_insert0 = c->tii_insert ? 1 : 0;
+            if (tii_done) *tii_done = true;
+        }
         HIPCHK(c, launch_tf(a, flags, s));
     } else if (tf_has_window(a, flags | TF_GUARD | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0))) {
         // OFDM windowing on the coded-bits chain, with or without FIRFilter: the frame kernel windows the guard interval
@@ -872,14 +880,19 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             const bool poly_ok = !(mask & DABGPU_STAGE_POLY) || (!c->cur.poly_is_lut && (mask & DABGPU_STAGE_RESAMPLE));
             TfArgs ta{};
             ta.g = c->g;
+            ta.t = tables_of(c);
             ta.gain = gain_of(c);
             ta.ntaps = (int)c->cur.taps.size();
-            const unsigned tflags = TF_FROM_BITS | ((mask & DABGPU_STAGE_GAIN) ? TF_GAIN : 0) |
-                                    ((mask & DABGPU_STAGE_NOGUARD) ? 0 : TF_GUARD) | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0) |
-                                    (c->cur.cfr_enable ? TF_CFR : 0);
-            // (TII is added to the native-rate complexf stream after the frame kernel, a windowed guard interval has variants
-            // without the s16 store only: the frame kernel's own s16 store is out then, the resampler's is not)
-            fuse_native = !post && !tii && !windowed && tf_has_s16(ta, tflags);
+            ta.chunks_per_frame = auto_chunks(c, n_frames);
+            ta.syms_per_chunk = (c->g.nb_symbols + 1 + ta.chunks_per_frame - 1) / ta.chunks_per_frame;
+            unsigned tflags = TF_FROM_BITS | ((mask & DABGPU_STAGE_GAIN) ? TF_GAIN : 0) |
+                              ((mask & DABGPU_STAGE_NOGUARD) ? 0 : TF_GUARD) | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0) |
+                              (c->cur.cfr_enable ? TF_CFR : 0);
+            if (c->use_eq && tf_has_eq(ta, tflags)) tflags |= TF_EQ;
+            // (a windowed guard interval has variants without the s16 store only, and TII is added to the native-rate complexf
+            // stream afterwards unless the frame kernel adds it itself: the frame kernel's own s16 store is out then, the
+            // resampler's is not)
+            fuse_native = !post && !windowed && (!tii || tf_has_tii(ta, tflags)) && tf_has_s16(ta, tflags);
             ResamplerArgs ra{};
             ra.nin = c->rs_nin;
             ra.nout = c->rs_nout;
@@ -907,12 +920,15 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             gain1 = (float *)c->d_gain1.p;
         }
     }
+    bool tii_done = false;
     if ((rc = run_native(c, d_in, from_bits, n_frames, mask, windowed, native_out, native, gain1, s, true,
-                         fuse_native ? clip : nullptr)))
+                         fuse_native ? clip : nullptr, tii ? (const float2 *)c->d_tii_frame.p : nullptr, &tii_done)))
         return rc;
-    if (tii)
+    if (tii && !tii_done) {
+        if (fuse_native) return fail(c, DABGPU_E_DEVICE, "s16 stored by the frame kernel, TII still to be added");
         HIPCHK(c, launch_tii_add(native_out, native, (const float2 *)c->d_tii_frame.p, c->tii_seg_len, gain1,
                                  c->tii_insert ? 1 : 0, n_frames, s));
+    }
     // the insert flag toggles once per frame of the stream whether or not TII is enabled (src/TII.cpp:241-242)
     if (from_bits && (n_frames & 1)) c->tii_insert = !c->tii_insert;
 

@@ -56,6 +56,11 @@ struct TfArgs {
     float2 *out;
     size_t out_stride;        // samples per frame in `out`
     float *gain1;             // FROM_BITS, optional: per frame, the multiplier applied to symbol 1 (TII)
+    // TII inside the frame kernel (f-4; variants tf_has_tii names): the unit-gain response of the TII null symbol (its segment,
+    // g.null_size samples), added -- times the multiplier of symbol 1 -- on the frames whose index parity says so
+    // (TII::m_insert, src/TII.cpp:241-242).  nullptr: blank null symbol (launch_tii_add adds it afterwards, or TII is off).
+    const float2 *tii_seg;
+    int tii_insert0;          // frame 0 of this launch carries TII (then every other one)
     // TF_CFR: crest-factor reduction inside OfdmGenerator (f-3) and its statistics
     float cfr_clip, cfr_errclip;
     int cfr_mer_base;         // the MER symbol of frame f is (cfr_mer_base + f) % (nb_symbols + 1)
@@ -80,6 +85,7 @@ int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones 
 bool tf_has_eq(const TfArgs &a, unsigned flags);     // the equalised-boundary variant exists for this chain (TF_EQ; needs t.eq_g)
 bool tf_has_window(const TfArgs &a, unsigned flags); // a frame-kernel variant windows the guard interval itself (TF_WINDOW)
 bool tf_has_s16(const TfArgs &a, unsigned flags);   // a frame-kernel variant stores s16 itself (TF_OUT_S16)
+bool tf_has_tii(const TfArgs &a, unsigned flags);   // the variant these flags select adds the TII null symbol itself (a.tii_seg)
 
 // Stand-alone stage kernels (per-stage drop-ins and the non-fused fallbacks).
 hipError_t launch_qpsk(const uint8_t *in, size_t nbytes, int K, float2 *out, hipStream_t s);

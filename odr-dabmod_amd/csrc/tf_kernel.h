@@ -189,6 +189,13 @@ void tf_kernel(const TfArgs a)
     const int chunk = blockIdx.x - frame * a.chunks_per_frame;
     const int s_begin = chunk * a.syms_per_chunk;
     const int s_end = min(nsym, s_begin + a.syms_per_chunk);
+    // TII (f-4) inside the kernel: everything after the IFFT is linear and the null symbol takes the multiplier of symbol 1,
+    // so on a frame that carries TII the null symbol's segment is g_1 times a constant segment (a.tii_seg, computed once per
+    // setting) instead of zeros: stored by the workgroup that owns symbols 0 and 1 when its run is over, its last C
+    // samples added to the boundary outputs that symbol 1 completes.
+    constexpr bool TII_IN = FROM_BITS && GUARD && !WIN && !CFR && (EQ || !FIR);
+    const bool tii_on = TII_IN && a.tii_seg != nullptr && s_begin == 0 && (((frame & 1) == 0) == (a.tii_insert0 != 0));
+    float g1s = 1.0f;            // the multiplier of symbol 1 (wave-uniform: a scalar register)
     if (frame >= a.n_frames || s_begin >= nsym) return;
 
     const int ntaps = NT ? NT : a.ntaps;
@@ -706,7 +713,12 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
             for (int k = 0; k < 11; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
             quad_sum2_dpp(y.x, y.y);
-            if (t < 4 * C && q == 0) put(prev_pos + prev_seg - C, t >> 2, cadd(y, zp[kEqQL - C + i]));
+            y = cadd(y, zp[kEqQL - C + i]);
+            if (TII_IN && tii_on && prev_pos == 0) {          // (the null symbol's boundary outputs: plus the TII segment's)
+                const cf ts = a.tii_seg[len0 - C + i];
+                y = mk(fmaf(g1s, ts.x, y.x), fmaf(g1s, ts.y, y.y));
+            }
+            if (t < 4 * C && q == 0) put(prev_pos + prev_seg - C, t >> 2, y);
         }
     };
 
@@ -723,8 +735,9 @@ void tf_kernel(const TfArgs a)
     int s_loop = s_begin;
     if (FROM_BITS && s_begin == 0) {
         const int nz = len0 - C - W;                  // the last C outputs belong to `boundary` (W: to the seam)
-        for (int i0 = 0; i0 < nz; i0 += kThreads)
-            if (i0 + t < nz) put(i0, t, mk(0.f, 0.f));
+        if (!tii_on)
+            for (int i0 = 0; i0 < nz; i0 += kThreads)
+                if (i0 + t < nz) put(i0, t, mk(0.f, 0.f));
         if (EQ) {
             for (int i = t; i < kEqW; i += (int)blockDim.x) eq_zp[cur * kEqW + i] = mk(0.f, 0.f);
         } else if (FIR && !WIN) {
@@ -877,6 +890,7 @@ void tf_kernel(const TfArgs a)
             // TII (f-4): the null symbol of the coded-bits path is added afterwards, scaled by the
             // multiplier of symbol 1 (src/GainControl.cpp:139-144)
             if (FROM_BITS && a.gain1 != nullptr && s == 1 && t == 0) a.gain1[frame] = g;
+            if (TII_IN && s == 1) g1s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g)));
             if (MAG_IN_GAIN) g *= mag_l[s - 1];
         }
 
@@ -1047,6 +1061,16 @@ void tf_kernel(const TfArgs a)
         have_prev = true;
         prev_pos = pos;
         prev_seg = seg;
+    }
+    if (TII_IN && tii_on) {
+        // the TII null symbol (all of it without FIRFilter; up to the boundary outputs with it)
+        const int nz = len0 - C;
+        for (int i0 = 0; i0 < nz; i0 += kThreads) {
+            if (i0 + t < nz) {
+                const cf ts = a.tii_seg[i0 + t];
+                put(i0, t, mk(fmaf(g1s, ts.x, 0.f), fmaf(g1s, ts.y, 0.f)));
+            }
+        }
     }
     if (EQ && s_end == nsym && have_prev) {
         // end of the frame: nothing follows (a zero symbol: w = -z_prev), missing terms are dropped

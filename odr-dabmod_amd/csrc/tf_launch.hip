@@ -62,6 +62,16 @@ bool tf_has_eq(const TfArgs &a, unsigned flags)
            (!(flags & TF_GAIN) || a.gain.mode != 1);
 }
 
+// TII inside the frame kernel: the coded-bits chain with guard interval, without windowing and CFR, ending in the equalised
+// variant (TF_EQ set by the caller) or without FIRFilter; a workgroup that owns the null symbol must own symbol 1 as well
+// (its multiplier is the null symbol's)
+bool tf_has_tii(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD;
+    if ((flags & want) != want || (flags & (TF_CFR | TF_WINDOW)) || a.syms_per_chunk < 2) return false;
+    return (flags & TF_EQ) ? tf_has_eq(a, flags) : !(flags & TF_FIR);
+}
+
 // the frame-kernel variants that store s16 themselves: Mode I coded-bits chain, guard + default-length filter,
 // gain none / fix / var, no CFR
 bool tf_has_s16(const TfArgs &a, unsigned flags)

@@ -800,8 +800,10 @@ def _tii_chain_case(pkg, mode, stages, oracle_kw, setup, tii=(3, 5, False), chun
 
 
 @pytest.mark.parametrize("mode", [1, 2])
-@pytest.mark.parametrize("chunks", [1, 5])
+@pytest.mark.parametrize("chunks", [1, 5, 39, 77])
 def test_chain_cfg3_with_tii(pkg, mode, chunks):
+    """(Mode I: the frame kernel adds the TII null symbol itself when the workgroup that owns the null symbol owns symbol 1 too
+    -- 1, 5 and 39 runs per frame; with 77 single-symbol runs, and in the other modes, tii_add_kernel adds it afterwards.)"""
     _tii_chain_case(pkg, mode, pkg.STAGE_GAIN | pkg.STAGE_FIR, dict(gain_mode=2, normalise=1.0 / 50000.0),
                     lambda md: md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0), chunks=chunks)
 
@@ -814,6 +816,13 @@ def test_chain_tii_other_gain_modes_and_old_variant(pkg, gain_mode):
 
 def test_chain_tii_without_gain_and_without_fir(pkg):
     _tii_chain_case(pkg, 1, 0, {}, lambda md: None, tii=(0, 0, False))
+
+
+@pytest.mark.parametrize("chunks", [1, 11])
+def test_chain_tii_on_the_default_chain(pkg, chunks):
+    """Gain control, no FIRFilter (the reference's default): the whole TII null symbol is stored by the frame kernel."""
+    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN, dict(gain_mode=2, normalise=1.0 / 50000.0),
+                    lambda md: md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0), chunks=chunks)
 
 
 def test_chain_tii_windowed_guard(pkg):

@@ -70,3 +70,5 @@ run("TII + window 10", setup=lambda m: (m.set_tii(True, 3, 5), m.set_window_over
 run("TII -> s16", setup=lambda m: m.set_tii(True, 3, 5), fmt="s16")
 run("gain max -> s16", setup=lambda m: m.set_gain(1, 1.0, 0.9, 4.0), fmt="s16")
 run("gain max, no FIR", mask=1, setup=lambda m: m.set_gain(1, 1.0, 1 / 50000., 4.0))
+run("TII, no FIR", mask=1, setup=lambda m: m.set_tii(True, 3, 5))
+run("TII, no FIR -> s16", mask=1, setup=lambda m: m.set_tii(True, 3, 5), fmt="s16")
