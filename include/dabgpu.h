@@ -216,7 +216,8 @@ DABGPU_API int dabgpu_format_process_dev(dabgpu_ctx *ctx, const void *d_in, size
  * real filter with  x[n] = sum_j g[j] z[n - (j - 56)]  wherever z[n] = sum_j taps[j] x[n + j] (cyclically) and x
  * has energy on the 1536 occupied carriers of a 2048-point symbol only; *fit = max |G H - 1| over those carriers.
  * Returns DABGPU_OK when such a filter exists to 1e-7 (the chain then uses it), DABGPU_E_INVALID when the taps
- * have no well-conditioned inverse there or ntaps != 45 (the chain keeps the packed dual transform). */
+ * have no well-conditioned inverse there or ntaps is outside 1 ... 45 (the chain keeps the packed dual transform; a
+ * filter of fewer than 45 taps runs as the 45-tap filter with zero taps behind it). */
 DABGPU_API int dabgpu_fir_inverse_design(const float *taps, size_t ntaps, float *g, double *fit);
 
 /* ---- the fused chain ----------------------------------------------------- */

@@ -144,7 +144,7 @@ def load_library():
 
 
 def fir_inverse_design(taps):
-    """Host-side helper (no device): the 160-tap inverse of a 45-tap FIR on the occupied carriers of a Mode I symbol,
+    """Host-side helper (no device): the 160-tap inverse of a FIR of up to 45 taps on the occupied carriers of a Mode I symbol,
     as the frame kernel's equalised-boundary variant uses it.  Returns (ok, g, fit)."""
     lib = load_library()
     taps = np.ascontiguousarray(taps, np.float32)

@@ -438,9 +438,10 @@ int apply_settings_groups(dabgpu_ctx *c)
             h[k] = make_float2((float)re, (float)im);
         }
         HIPCHK(c, upload(c->d_firh, h, s));
-        // the equalised-boundary variant of the frame kernel (Mode I, 45 taps): the taps' inverse on the occupied bins
+        // the equalised-boundary variant of the frame kernel (Mode I, up to 45 taps: a shorter filter is the same filter with
+        // zero taps behind it -- fused_ntaps): the taps' inverse on the occupied bins
         c->eq_ok = false;
-        if (c->g.logN == 11 && c->cur.taps.size() == 45) {
+        if (c->g.logN == 11 && !c->cur.taps.empty() && c->cur.taps.size() <= 45) {
             std::vector<float> g;
             c->eq_ok = cached_inverse_filter(c->cur.taps, N, c->g.K, g, &c->eq_fit);
             if (c->eq_ok) HIPCHK(c, upload(c->d_eqg, g, s));
@@ -664,6 +665,15 @@ size_t bytes_per_sample(int fmt) { return fmt ? dabgpu_format_size(fmt) : sizeof
 // into native_out (`native` samples per frame).
 // tii_seg / tii_done: the caller's cached TII segment; *tii_done says whether the frame kernel added it itself (else the caller
 // runs launch_tii_add on the result)
+// Tap count the frame kernel is given.  Mode I: a filter of fewer than 45 taps runs as a 45-tap filter whose last taps are zero
+// (out[n] = sum_j taps[j] in[n + j]: zero taps add nothing; the device table is zero padded) -- the kernels with the compile-time
+// tap count, the equalised-boundary variant among them, then serve every filter up to the default length.
+int fused_ntaps(const dabgpu_ctx *c)
+{
+    const size_t n = c->cur.taps.size();
+    return (c->g.logN == 11 && n >= 1 && n < 45) ? 45 : (int)n;
+}
+
 int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,
                float2 *native_out, size_t native, float *gain1, hipStream_t s, bool keep_stats = true,
                unsigned long long *s16_clipped = nullptr, const float2 *tii_seg = nullptr, bool *tii_done = nullptr)
@@ -721,6 +731,7 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
         if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
         if (s16_clipped) flags |= TF_OUT_S16;
+        if (!(flags & TF_CFR)) a.ntaps = fused_ntaps(c);     // (the CFR variants loop over the run-time tap count)
         // cfg 3 chain: the filtered transform alone with equalised boundaries (DABGPU_EQ=0 at dabgpu_create: the packed
         // dual transform)
         if (c->use_eq && tf_has_eq(a, flags)) flags |= TF_EQ;
@@ -882,7 +893,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             ta.g = c->g;
             ta.t = tables_of(c);
             ta.gain = gain_of(c);
-            ta.ntaps = (int)c->cur.taps.size();
+            ta.ntaps = c->cur.cfr_enable ? (int)c->cur.taps.size() : fused_ntaps(c);
             ta.chunks_per_frame = auto_chunks(c, n_frames);
             ta.syms_per_chunk = (c->g.nb_symbols + 1 + ta.chunks_per_frame - 1) / ta.chunks_per_frame;
             unsigned tflags = TF_FROM_BITS | ((mask & DABGPU_STAGE_GAIN) ? TF_GAIN : 0) |
@@ -1538,7 +1549,7 @@ int dabgpu_poly_process(dabgpu_ctx *c, const void *in, size_t in_bytes, void *ou
 
 int dabgpu_fir_inverse_design(const float *taps, size_t ntaps, float *g, double *fit)
 {
-    if (!taps || !g || ntaps != 45) return DABGPU_E_INVALID;
+    if (!taps || !g || ntaps < 1 || ntaps > 45) return DABGPU_E_INVALID;
     std::vector<float> t(taps, taps + ntaps), out;
     double f = 0.0;
     const bool ok = cached_inverse_filter(t, 2048, 1536, out, &f);

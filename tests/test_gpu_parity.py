@@ -475,6 +475,32 @@ def test_cfg3_other_45_tap_filters_with_and_without_an_inverse(pkg):
         md.close()
 
 
+def test_cfg3_filters_shorter_than_the_default_run_as_45_tap_filters(pkg):
+    """A filter of fewer than 45 taps is the same filter with zero taps behind it: the chain hands it to the kernels with the
+    compile-time tap count -- the equalised-boundary variant when the taps have an inverse on the occupied carriers, the pruned
+    packed transform otherwise -- and the result is the oracle's for the short filter: a 31-tap low-pass, the 5 taps of the
+    reference's doc/fir-filter/simplefiltertaps.txt, an even-length filter.  Also with s16 output (the fused store) and with TII."""
+    from scipy.signal import firwin
+    lp31 = firwin(31, 880e3, window="hamming", fs=2.048e6).astype(np.float32)
+    simple = np.array([0.0, 0.0, 1.0, 0.0, 0.0], np.float32)          # (that file: a two-sample advance)
+    for taps in (lp31, simple, lp31[:30]):
+        def setup(md):
+            md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_fir_taps(taps)
+        for chunks in (1, 7):
+            _chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, chunks, 2, dict(gain_mode=2, normalise=1.0 / 50000.0, taps=taps),
+                        setup)
+    assert pkg.fir_inverse_design(lp31)[0] and pkg.fir_inverse_design(simple)[0]
+
+    def setup16(md):
+        md._rs_out = 2048000
+        md.set_gain(2, 1.0, 1.0, 4.0)
+        md.set_fir_taps(lp31)
+    _chain_formats_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, "s16", setup16)
+    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, dict(gain_mode=2, normalise=1.0 / 50000.0, taps=lp31),
+                    lambda md: (md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0), md.set_fir_taps(lp31)))
+
+
 @pytest.mark.parametrize("gain_mode", [0, 1])
 def test_chain_other_gain_modes_file_normalisation(pkg, gain_mode):
     def setup(md):

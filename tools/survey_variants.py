@@ -72,3 +72,4 @@ run("gain max -> s16", setup=lambda m: m.set_gain(1, 1.0, 0.9, 4.0), fmt="s16")
 run("gain max, no FIR", mask=1, setup=lambda m: m.set_gain(1, 1.0, 1 / 50000., 4.0))
 run("TII, no FIR", mask=1, setup=lambda m: m.set_tii(True, 3, 5))
 run("TII, no FIR -> s16", mask=1, setup=lambda m: m.set_tii(True, 3, 5), fmt="s16")
+run("custom 5 taps (simplefiltertaps.txt)", setup=lambda m: m.set_fir_taps(np.array([0, 0, 1, 0, 0], np.float32)))
