@@ -101,7 +101,7 @@ void tf_kernel(const TfArgs a)
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
     static_assert(!WIN || (FROM_BITS && GUARD && OFMT == 0), "WIN: coded-bits chain with guard interval");
-    static_assert(!(WIN && FIR) || (!ZONLY && !EQ && NT == 0 && !GVAR),
+    static_assert(!(WIN && FIR) || (!ZONLY && !EQ && (NT == 0 || (NT == 45 && !CFR)) && !GVAR),
                   "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count");
     static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY && !WIN),
                   "EQ: the Mode I coded-bits chain with the 45-tap filter");
@@ -582,8 +582,29 @@ void tf_kernel(const TfArgs a)
     // reads issued together and waited for once (one tap per trip is one LDS round trip per tap: twelve in a row for the
     // default filter).  Taps past the filter count as zero and read the lane's first sample again.  Same order of
     // accumulation as one tap per trip.  (Fully unrolled, the NT > 0 way, it pushes these variants into spilling.)
-    auto fir_quad_lane = [&](const cf *sp, int q) __attribute__((always_inline)) -> cf {
+    auto fir_quad_lane = [&](const cf *sp0, int q) __attribute__((always_inline)) -> cf {
         cf acc = mk(0.f, 0.f);
+        if (NT > 0) {
+            // tap count known: all reads of a lane at base + immediate, issued together and waited for once.  The last group of
+            // four runs past the filter for q > 0: the zero padding of the tap table cancels it, and its sample read is
+            // redirected to an address inside the buffer.
+            constexpr int KT = NT > 0 ? (NT + 3) / 4 : 1, REM = NT - 4 * (KT - 1);    // lanes q < REM own a tap in the last group
+            const cf *sp = sp0 + q;
+            const float *tq = taps_l + q;
+            cf x[KT];
+            float tp[KT];
+#pragma unroll
+            for (int k = 0; k < KT - 1; ++k) { x[k] = sp[4 * k]; tp[k] = tq[4 * k]; }
+            x[KT - 1] = (REM == 4 || q < REM) ? sp[4 * (KT - 1)] : sp[0];
+            tp[KT - 1] = tq[4 * (KT - 1)];
+#pragma unroll
+            for (int k = 0; k < KT; ++k) {
+                acc.x = fmaf(x[k].x, tp[k], acc.x);
+                acc.y = fmaf(x[k].y, tp[k], acc.y);
+            }
+            return acc;
+        }
+        const cf *sp = sp0;
 #pragma unroll 1
         for (int j = q; j < ntaps; j += 16) {
             cf x[4];
@@ -612,29 +633,7 @@ void tf_kernel(const TfArgs a)
         for (int i0 = 0; i0 < C; i0 += kThreads / 4) {
             const int i = i0 + (t >> 2), q = t & 3;
             const int ii = i < C ? i : 0;
-            cf acc = mk(0.f, 0.f);
-            if (NT > 0) {
-                // tap count known: all reads of a lane at base + immediate, issued together and waited for
-                // once (the rolled loop below pays one LDS round trip per tap).  The last group of four
-                // runs past the filter for q > 0: the zero padding of the tap table cancels it, and its
-                // sample read is redirected to an address inside the buffer.
-                constexpr int KT = NT > 0 ? (NT + 3) / 4 : 1, REM = NT - 4 * (KT - 1);    // lanes q < REM own a tap in the last group
-                const cf *sp = src + ii + q;
-                const float *tq = taps_l + q;
-                cf x[KT];
-                float tp[KT];
-#pragma unroll
-                for (int k = 0; k < KT - 1; ++k) { x[k] = sp[4 * k]; tp[k] = tq[4 * k]; }
-                x[KT - 1] = (REM == 4 || q < REM) ? sp[4 * (KT - 1)] : sp[0];
-                tp[KT - 1] = tq[4 * (KT - 1)];
-#pragma unroll
-                for (int k = 0; k < KT; ++k) {
-                    acc.x = fmaf(x[k].x, tp[k], acc.x);
-                    acc.y = fmaf(x[k].y, tp[k], acc.y);
-                }
-            } else {
-                acc = fir_quad_lane(src + ii, q);
-            }
+            cf acc = fir_quad_lane(src + ii, q);
             quad_sum2_dpp(acc.x, acc.y);                                    // the 4 lanes of an output are one DPP quad
             if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, t >> 2, acc);
         }
@@ -1156,11 +1155,11 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     }
 #undef TF_LAUNCH_GVAR
     if (flags & TF_WINDOW) {
-        if (!tf_has_window(a, flags) || NT != 0) return hipErrorInvalidValue;
+        if (!tf_has_window(a, flags) || (NT != 0 && !fr)) return hipErrorInvalidValue;
         if (fr) {
-            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, true, 0, false, false, false, 0, true>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, true, 0, false, false, false, 0, true>), grid, block, lds, s, a);
-        } else {
+            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, true, NT, false, false, false, 0, true>), grid, block, lds, s, a);
+            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, true, NT, false, false, false, 0, true>), grid, block, lds, s, a);
+        } else if constexpr (NT == 0) {
             if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
             else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
         }
