@@ -1111,7 +1111,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
     hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
 #define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
-    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, EPI, EPI, 0, true>), grid, block, lds, s, a)
+    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, EPI, EPI, (EPI ? NT : 0), true>), grid, block, lds, s, a)
 #define TF_LAUNCH_CFR_GUARD(GN)                                                                \
     hipLaunchKernelGGL((tf_kernel<LOGN, true, GN, true, false, 0, true>), grid, block, lds, s, a)
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
@@ -1123,7 +1123,8 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     if (flags & TF_CFR) {
         // with the whole fused epilogue (guard + FIR) or with none of it; from coded bits also with the guard interval alone
         // (firfilter is off by default in the reference's configuration: src/ConfigParser.cpp:198)
-        if ((gd != fr && !(fb && gd)) || NT != 0 || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr) return hipErrorInvalidValue;
+        if ((gd != fr && !(fb && gd)) || (NT != 0 && (!fr || (flags & TF_WINDOW))) || !a.cfr_counts || !a.cfr_mer || !a.cfr_papr)
+            return hipErrorInvalidValue;
         if (flags & TF_WINDOW) {
             // OFDM windowing with crest-factor reduction (coded-bits chain): the windowed variants with the CFR'd symbol
             if (!tf_has_window(a, flags)) return hipErrorInvalidValue;

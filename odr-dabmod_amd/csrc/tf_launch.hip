@@ -97,7 +97,7 @@ hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
         case 9: return launch_tf_9_0(a, flags, s);
         case 10: return launch_tf_10_0(a, flags, s);
         case 11:
-            return ((flags & TF_FIR) && a.ntaps == 45 && !(flags & TF_CFR)) ? launch_tf_11_45(a, flags, s)
+            return ((flags & TF_FIR) && a.ntaps == 45 && !((flags & TF_CFR) && (flags & TF_WINDOW))) ? launch_tf_11_45(a, flags, s)
                                                        : launch_tf_11_0(a, flags, s);
     }
     return hipErrorInvalidValue;
