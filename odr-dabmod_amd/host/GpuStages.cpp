@@ -161,6 +161,16 @@ int SignalMultiplexer::process(std::vector<Buffer *> dataIn, Buffer *dataOut)
 }
 
 // ---------------------------------------------------------------- OfdmGenerator
+// The fixed-point engine (reference src/OfdmGenerator.cpp:467-579) is not offloaded: refuse at construction, which
+// src/DabModulator.cpp:208-213 reaches on the first frame -- run_modulator reports it (src/DabMod.cpp:732-735).
+OfdmGeneratorFixed::OfdmGeneratorFixed(size_t, size_t, size_t, bool)
+{
+    throw std::runtime_error("OfdmGenerator: the fixed-point engine (fft_engine=kiss) is not offloaded to the GPU; "
+                             "set fft_engine=fftw");
+}
+
+int OfdmGeneratorFixed::process(Buffer *const, Buffer *) { return 0; }
+
 OfdmGeneratorCF32::OfdmGeneratorCF32(size_t nbSymbols, size_t nbCarriers, size_t spacing,
                                      bool &enableCfr, float &cfrClip, float &cfrErrorClip, bool inverse)
     : RemoteControllable("ofdm"), m_ctx(dabgpu_host::mode_from_spacing(spacing)),
@@ -376,7 +386,7 @@ GuardIntervalInserter::GuardIntervalInserter(size_t nbSymbols, size_t spacing, s
       m_windowOverlap(windowOverlap)
 {
     if (nullSize == 0) throw std::logic_error("NULL symbol must be present");
-    if (fftEngine != FFTEngine::FFTW) throw std::runtime_error("GuardIntervalInserter: only the float engine is offloaded");
+    if (static_cast<int>(fftEngine) != 0 /* FFTEngine::FFTW: the enumeration may be opaque here, GpuStages.h */) throw std::runtime_error("GuardIntervalInserter: only the float engine is offloaded");
     dabgpu_geometry g;
     m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
     if ((size_t)g.nb_symbols != nbSymbols || (size_t)g.null_size != nullSize || (size_t)g.sym_size != symSize)

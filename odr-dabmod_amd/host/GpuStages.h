@@ -25,7 +25,14 @@
 struct dabgpu_ctx;
 
 enum class GainMode { GAIN_FIX = 0, GAIN_MAX = 1, GAIN_VAR = 2 };  // reference src/GainControl.h:45
-enum class FFTEngine { FFTW, KISS, DEXTER };                       // reference src/ConfigParser.h:39-43
+// FFTEngine (reference src/ConfigParser.h:39-43).  Inside a reference tree ConfigParser.h defines it -- and includes this
+// header, through GainControl.h / TII.h, BEFORE it does: the adapters therefore need the opaque declaration only (a scoped
+// enumeration's underlying type is fixed, so it is a complete type), and the definition below exists only where no
+// ConfigParser.h is on the include path (the host mirror of this repository).
+enum class FFTEngine;
+#if !__has_include("ConfigParser.h")
+enum class FFTEngine { FFTW, KISS, DEXTER };
+#endif
 
 namespace dabgpu_host {
 // one device context per stage object; mode derived from the stage's geometry
@@ -131,6 +138,17 @@ private:
     std::atomic<bool> m_paprClearRequest{false};
     size_t m_paprBlocks;                                   // PAPRStats(nbSymbols * 50), reference :60-61
     std::deque<double> m_clipRatios, m_errorClipRatios, m_mers, m_paprBefore, m_paprAfter;
+};
+
+// reference src/OfdmGenerator.h:114-146: the fixed-point (KISS FFT) engine, FFTEngine::KISS in src/DabModulator.cpp:208-213.
+// Not offloaded (out of scope); the class exists so that the graph builder compiles unchanged, and
+// its constructor throws: a configuration with fft_engine=kiss fails at the first frame with a message that says why,
+// exactly like the reference's own FFTEngine::DEXTER branch without --enable-dexter (:222).
+class OfdmGeneratorFixed : public ModCodec {
+public:
+    OfdmGeneratorFixed(size_t nbSymbols, size_t nbCarriers, size_t spacing, bool inverse = true);
+    int process(Buffer *const dataIn, Buffer *dataOut) override;
+    const char *name() override { return "OfdmGenerator"; }
 };
 
 // reference src/GainControl.h:47-91, .cpp:48-192, RC :505-572

@@ -27,6 +27,10 @@ def build(with_ref=None):
         with_ref = os.path.isdir(os.path.join(REFERENCE_ROOT, "src"))
     if with_ref:
         subprocess.check_call(["make", "-s", "-C", _DIR, "-j4", "ref"])
+        # the reference's unmodified DabModulator.cpp linked with the MI355X drop-ins (needs libdabgpu.so: built first
+        # by __graft_entry__.build()); a test binary for the GPU box, see dropin_harness.cpp
+        if os.path.exists(os.path.join(_DIR, "..", "odr-dabmod_amd", "csrc", "libdabgpu.so")):
+            subprocess.check_call(["make", "-s", "-C", _DIR, "-j4", "dropin"])
 
 
 class _Mode(C.Structure):

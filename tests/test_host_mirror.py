@@ -58,6 +58,94 @@ def test_drop_in_adapters_compile_against_the_reference_headers(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
 
 
+@pytest.mark.skipif(not os.path.isdir("/root/reference/src"), reason="the reference tree is not on this machine")
+def test_unmodified_dabmodulator_compiles_against_the_drop_ins(tmp_path):
+    """SURVEY 8(b), "Construction signatures the drop-ins must keep (so DabModulator.cpp compiles unchanged)": a copy of
+    the reference's src/, the fifteen stage headers replaced by forwarding headers (odr-dabmod_amd/host/install_dropins.sh,
+    the recipe of INTEGRATION.md section B), and the UNMODIFIED DabModulator.cpp -- plus GpuStages.cpp in the same tree --
+    pass the compiler.  FFTEngine comes from the reference's ConfigParser.h there, OfdmGeneratorFixed is a declared
+    adapter (src/DabModulator.cpp:208-213).  `make -C oracle dropin` goes further and links + runs that build
+    (test_reference_graph_builder_runs_on_the_drop_ins)."""
+    import filecmp
+    import shutil
+    src = tmp_path / "src"
+    shutil.copytree("/root/reference/src", str(src))
+    r = subprocess.run(["sh", os.path.join(HOST, "install_dropins.sh"), str(src)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    assert filecmp.cmp(str(src / "DabModulator.cpp"), "/root/reference/src/DabModulator.cpp", shallow=False)
+    assert filecmp.cmp(str(src / "ConfigParser.h"), "/root/reference/src/ConfigParser.h", shallow=False)
+    for f in ("DabModulator.cpp", "GpuStages.cpp"):
+        r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-DPACKAGE_NAME=\"odr-dabmod\"",
+                            "-DPACKAGE_VERSION=\"3.0.1\"", "-DVERSION=\"3.0.1\"", "-I.", "-I/root/reference/lib",
+                            "-I/root/reference", "-I/root/reference/kiss", "-I" + os.path.join(ROOT, "include"), f],
+                           cwd=str(src), capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, f + ":\n" + r.stderr[-3000:]
+
+
+DROPIN = os.path.join(ROOT, "oracle", "_ref", "dabmod_dropin")
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dabmod_dropin is built where the reference tree is")
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg3", "cfg4", "window_s16"])
+def test_reference_graph_builder_runs_on_the_drop_ins(tmp_path, cfg):
+    """The reference's own DabModulator::process (src/DabModulator.cpp:125-424, compiled unchanged -- oracle/Makefile
+    `dropin`) builds its flowgraph from the GpuStages classes and modulates an ETI file on the MI355X; what its
+    OutputFile writes is compared with the oracle chain on the front-end's blocks.  Every PipelinedModCodec drops one
+    frame: N/4 - 1 frames with GainControl, - 2 with FIRFilter, - 3 with MemlessPoly."""
+    import importlib
+    import oracle as O
+    from tests.golden.synth import synth_eti
+    fe_mod = importlib.import_module("odr-dabmod_amd.frontend")
+    n_eti = 32
+    eti = synth_eti(n_eti)
+    fin, fout = str(tmp_path / "in.eti"), str(tmp_path / "out.iq")
+    eti.tofile(fin)
+    bits = fe_mod.Frontend().eti_to_bits(eti, 1)
+    n = n_eti // 4
+    args, drops, fmt = [], 1, None
+    if cfg == "cfg1":
+        chain = O.Chain(mode=1, stages=O.STAGE_GAIN, gain_mode=2, normalise=1.0)
+    elif cfg == "cfg3":
+        args, drops = ["--fir", "default", "--normalise", repr(1.0 / 50000.0)], 2
+        chain = O.Chain(mode=1, stages=O.STAGE_GAIN | O.STAGE_FIR, gain_mode=2, normalise=1.0 / 50000.0)
+    elif cfg == "cfg4":
+        coef = tmp_path / "poly.coef"
+        coef.write_text("1\n5\n" + "".join("%r\n" % v for v in POLY_AM + POLY_PM))
+        args, drops = ["--fir", "default", "--normalise", repr(1.0 / 50000.0), "--rate", "8192000", "--poly", str(coef)], 3
+        chain = O.Chain(mode=1, stages=O.STAGE_GAIN | O.STAGE_FIR | O.STAGE_RESAMPLE | O.STAGE_POLY, gain_mode=2,
+                        normalise=1.0 / 50000.0, out_rate=8192000, am=POLY_AM, pm=POLY_PM)
+    else:
+        args, fmt = ["--window", "10", "--gainmode", "max", "--normalise", repr(32767.0 / 50000.0), "--format", "s16"], "s16"
+        chain = O.Chain(mode=1, stages=O.STAGE_GAIN, gain_mode=1, normalise=32767.0 / 50000.0, window_overlap=10)
+    r = subprocess.run([DROPIN, fin, fout] + args, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    ref = chain.process(bits)[:n - drops]
+    if fmt is None:
+        got = np.fromfile(fout, dtype=np.complex64).reshape(-1, ref.shape[1])
+        assert got.shape[0] == n - drops
+        for f in range(n - drops):
+            assert np.linalg.norm(got[f] - ref[f]) / np.linalg.norm(ref[f]) < 1e-6, f
+    else:
+        want, _ = O.format_convert(ref, fmt)
+        got = np.fromfile(fout, dtype=np.int16)
+        d = np.abs(got.astype(np.int32) - want.reshape(-1).astype(np.int32))
+        assert got.size == want.size and d.max() <= 1 and (d != 0).mean() < 1e-2
+
+
+@pytest.mark.gpu
+@pytest.mark.skipif(not os.path.exists(DROPIN), reason="oracle/_ref/dabmod_dropin is built where the reference tree is")
+def test_reference_graph_builder_refuses_the_fixed_point_engine(tmp_path):
+    """fft_engine=kiss (src/DabModulator.cpp:142,208-213) is not offloaded: the drop-ins throw at construction, the
+    reference's loop reports it -- nothing is modulated on a silent substitute."""
+    from tests.golden.synth import synth_eti
+    fin = str(tmp_path / "in.eti")
+    synth_eti(8).tofile(fin)
+    r = subprocess.run([DROPIN, fin, str(tmp_path / "out.iq"), "--engine", "kiss"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "fixed-point engine is not offloaded" in r.stderr
+    assert not os.path.exists(str(tmp_path / "out.iq")) or os.path.getsize(str(tmp_path / "out.iq")) == 0
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("mode", [1, 2])
 def test_flowgraph_of_drop_in_stages_matches_oracle(tmp_path, mode):
