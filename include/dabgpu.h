@@ -220,6 +220,15 @@ DABGPU_API int dabgpu_format_process_dev(dabgpu_ctx *ctx, const void *d_in, size
  * filter of fewer than 45 taps runs as the 45-tap filter with zero taps behind it). */
 DABGPU_API int dabgpu_fir_inverse_design(const float *taps, size_t ntaps, float *g, double *fit);
 
+/* How the fused Mode I chain forms the FIRFilter outputs whose look-ahead crosses a symbol boundary (the last
+ * ntaps - 1 of every symbol; reference loop src/FIRFilter.cpp:168-191).  AUTO (the default): from the filtered
+ * symbols alone through the inverse above whenever the taps have one, otherwise as DIRECT.  DIRECT: always by the
+ * direct sum over the unfiltered samples (a second, pruned transform per symbol).  Same results within the FIRFilter
+ * bar either way; exists so that both kernels can be selected from a test or a measurement -- it is not read from
+ * the environment.  Takes effect at the next *_process call. */
+enum { DABGPU_FIR_BOUNDARY_AUTO = 0, DABGPU_FIR_BOUNDARY_DIRECT = 1 };
+DABGPU_API int dabgpu_set_fir_boundary_mode(dabgpu_ctx *ctx, int mode);
+
 /* ---- the fused chain ----------------------------------------------------- */
 
 /* FormatConverter as the last step of the chain (the reference wires it after cifPoly when the output is not

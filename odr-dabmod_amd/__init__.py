@@ -33,6 +33,7 @@ EXPORTS = [
     "dabgpu_cic_equalizer_process", "dabgpu_set_tii", "dabgpu_tii_process",
     "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
     "dabgpu_set_output_format", "dabgpu_get_num_clipped", "dabgpu_fir_inverse_design",
+    "dabgpu_set_fir_boundary_mode",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -110,6 +111,7 @@ def load_library():
     lib.dabgpu_set_fir_taps.argtypes = [vp, C.POINTER(C.c_float), sz]
     lib.dabgpu_set_fir_default_taps.argtypes = [vp]
     lib.dabgpu_set_window_overlap.argtypes = [vp, sz]
+    lib.dabgpu_set_fir_boundary_mode.argtypes = [vp, C.c_int]
     lib.dabgpu_set_resampler.argtypes = [vp, sz, sz]
     lib.dabgpu_set_poly.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.dabgpu_set_lut.argtypes = [vp, C.c_float, C.POINTER(C.c_float)]
@@ -354,6 +356,11 @@ class Modulator:
         return ob.value
 
     # ---- fused chain -------------------------------------------------------
+    def set_fir_boundary_mode(self, direct):
+        """False (default): boundary outputs of the fused FIRFilter through the taps' inverse where one exists;
+        True: always the direct sum over the unfiltered samples (packed dual transform)."""
+        self._chk(self._lib.dabgpu_set_fir_boundary_mode(self._h, 1 if direct else 0))
+
     def set_output_format(self, fmt=None):
         """FormatConverter as the chain's last step: None / "complexf", or "s16" / "u8" / "s8"."""
         code = 0 if fmt in (None, "complexf") else FORMATS.get(fmt, (99, None))[0]

@@ -118,7 +118,7 @@ struct dabgpu_ctx {
 
     // constant tables
     DevBuf d_twiddle, d_src, d_dst, d_phq, d_mag, d_taps, d_firh, d_window, d_coef, d_eqg;
-    bool use_eq = true;                   // tuning aid: environment DABGPU_EQ=0 when the context is created turns TF_EQ off
+    bool use_eq = true;                   // dabgpu_set_fir_boundary_mode: false = always the packed dual transform
     bool eq_ok = false;                   // d_eqg holds a well-conditioned inverse of the current taps (TF_EQ may be used)
     double eq_fit = 0.0;                  // max |G H - 1| over the occupied bins
     // resampler
@@ -560,12 +560,15 @@ int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
     // split into runs of symbols so that the launch still has about 1024 of them.  Every run pays a prologue (the
     // differential state up to its first symbol: a bit-sliced sum over the blocks before it, a few microseconds whatever
     // the depth) and, with FIR, one look-ahead transform.  Measured optimum, Mode I (tools/sweep_chunks.py, round 3):
-    // 1024 / B runs down to B = 32, two symbols per run for 12 ... 31 frames, single symbols below (latency, not
+    // 1024 / B runs down to B = 32, two symbols per run for 14 ... 31 frames, single symbols below (latency, not
     // efficiency, counts there: 10 us per Mode-I frame).
     const int nsym = c->g.nb_symbols + 1;
     const size_t n = n_frames;
-    const int want = n >= 1024 ? 1 : (int)((1024 + n - 1) / n);
-    return std::max(1, std::min(want, nsym));
+    const int want = std::max(1, std::min(n >= 1024 ? 1 : (int)((1024 + n - 1) / n), nsym));
+    // no empty runs: the callers give every run ceil(nsym / chunks) symbols, so ask for exactly as many runs as that
+    // run length needs (74 wanted -> 2 symbols per run -> 39 runs, not 74 workgroups of which 35 return after the prologue)
+    const int per_run = (nsym + want - 1) / want;
+    return (nsym + per_run - 1) / per_run;
 }
 
 bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
@@ -732,7 +735,7 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
         if (s16_clipped) flags |= TF_OUT_S16;
         if (!(flags & TF_CFR)) a.ntaps = fused_ntaps(c);     // (the CFR variants loop over the run-time tap count)
-        // cfg 3 chain: the filtered transform alone with equalised boundaries (DABGPU_EQ=0 at dabgpu_create: the packed
+        // cfg 3 chain: the filtered transform alone with equalised boundaries (dabgpu_set_fir_boundary_mode(ctx, 1): the packed
         // dual transform)
         if (c->use_eq && tf_has_eq(a, flags)) flags |= TF_EQ;
         a.chunks_per_frame = auto_chunks(c, n_frames);
@@ -822,7 +825,10 @@ int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t nativ
     HIPCHK(c, launch_phase_reference((const uint8_t *)c->d_phq.p, c->g.K, phase, s));
     HIPCHK(c, launch_tii(phase, (const uint8_t *)c->d_acp.p, c->g.K, c->cur.tii_old_variant ? 1 : 0, 1,
                          (float2 *)c->d_tii_car.p, s));
-    int rc = run_native(c, c->d_tii_car.p, false, 1, key, windowed, (float2 *)c->d_tii_frame.p, native, nullptr, s,
+    // the segment is built from CARRIERS: CFR with the guard interval alone is fused from coded bits only (run_chain's
+    // `windowed` is false for it), so here that combination takes the unfused IFFT + CFR -> guard kernels
+    const bool seg_windowed = windowed || (c->cur.cfr_enable && !(key & (DABGPU_STAGE_FIR | DABGPU_STAGE_NOGUARD)));
+    int rc = run_native(c, c->d_tii_car.p, false, 1, key, seg_windowed, (float2 *)c->d_tii_frame.p, native, nullptr, s,
                         false);
     if (rc) return rc;
     // the response of the null symbol: its own segment plus whatever a windowed guard interval spills
@@ -1044,7 +1050,6 @@ int dabgpu_create(const dabgpu_config *cfg, dabgpu_ctx **out)
     c->device = cfg->device;
     c->max_frames = std::max(1, cfg->max_frames);
     c->chunks_cfg = cfg->chunks_per_frame;
-    { const char *e = getenv("DABGPU_EQ"); c->use_eq = !e || atoi(e) != 0; }
     auto bail = [&](int rc) {
         g_create_error = c->err;
         dabgpu_destroy(c);
@@ -1217,6 +1222,16 @@ int dabgpu_set_resampler(dabgpu_ctx *c, size_t in_rate, size_t out_rate)
     std::lock_guard<std::mutex> lk(c->mu);
     c->set.rs_in = in_rate; c->set.rs_out = out_rate; c->set.resampler_reset = true;
     ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_fir_boundary_mode(dabgpu_ctx *c, int mode)
+{
+    if (!c) return DABGPU_E_INVALID;
+    if (mode != DABGPU_FIR_BOUNDARY_AUTO && mode != DABGPU_FIR_BOUNDARY_DIRECT)
+        return fail(c, DABGPU_E_INVALID, "FIRFilter: unknown boundary mode");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->use_eq = mode == DABGPU_FIR_BOUNDARY_AUTO;
     return DABGPU_OK;
 }
 

@@ -395,28 +395,18 @@ def test_chain_cfg3_gain_var_fir(pkg, mode, chunks):
                         np.abs(y - ref).max() / np.abs(ref).max(), 7e-7)
 
 
-def _with_env(name, value, fn):
-    old = os.environ.get(name)
-    os.environ[name] = value
-    try:
-        return fn()
-    finally:
-        if old is None:
-            del os.environ[name]
-        else:
-            os.environ[name] = old
-
-
 @pytest.mark.parametrize("gain", [(2, 1.0 / 50000.0), (0, 1.0), (None, 0)])
 @pytest.mark.parametrize("chunks", [1, 7, 77])
 def test_cfg3_equalised_boundary_variant_against_the_packed_dual_transform(pkg, gain, chunks):
     """The two Mode I frame kernels of the cfg 3 chain -- filtered transform alone with the boundary outputs
-    reconstructed through the taps' inverse (default), and the packed unfiltered + filtered pair (DABGPU_EQ=0 when
-    the context is created) -- against the oracle and against each other, every chunking (one symbol per workgroup:
+    reconstructed through the taps' inverse (default), and the packed unfiltered + filtered pair
+    (dabgpu_set_fir_boundary_mode DIRECT) -- against the oracle and against each other, every chunking (one symbol per workgroup:
     every boundary crosses a run), frame start and frame end included."""
-    def make(eq):
-        return _with_env("DABGPU_EQ", eq, lambda: pkg.Modulator(mode=1, max_frames=3, chunks_per_frame=chunks))
-    a, b = make("1"), make("0")
+    def make(direct):
+        md = pkg.Modulator(mode=1, max_frames=3, chunks_per_frame=chunks)
+        md.set_fir_boundary_mode(direct)
+        return md
+    a, b = make(False), make(True)
     try:
         stages = pkg.STAGE_FIR | (pkg.STAGE_GAIN if gain[0] is not None else 0)
         kw = {}
@@ -760,6 +750,34 @@ def test_chain_cfr_with_tii_and_resampler(pkg):
         md.set_resampler(2048000, 4096000)
     _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE,
                     dict(gain_mode=2, normalise=1.0 / 50000.0, out_rate=4096000, cfr=(50.0, 0.1)), setup)
+
+
+@pytest.mark.parametrize("chunks", [1, 7])
+def test_chain_cfr_with_tii_without_firfilter(pkg, chunks):
+    """TII + CFR on the reference's default filter setting (firfilter.enabled = 0): the frame kernel runs the coded-bits
+    CFR + guard variant, the cached TII segment is built from carriers through the unfused IFFT + CFR -> guard kernels
+    (round-3 advisor finding: that segment asked the launcher for a variant that does not exist)."""
+    def setup(md):
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_cfr(True, 50.0, 0.1)
+    y, ref = _tii_chain_case(pkg, 1, pkg.STAGE_GAIN, dict(gain_mode=2, normalise=1.0 / 50000.0, cfr=(50.0, 0.1)), setup,
+                             chunks=chunks)
+    # and with s16 output: the bytes FormatConverter makes of the chain's own complexf frames
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=1100 + i) for i in range(3)])
+    outs = []
+    for fmt in (None, "s16"):
+        md = pkg.Modulator(mode=1, max_frames=3, chunks_per_frame=chunks)
+        try:
+            md.set_gain(2, 1.0, 32767.0 / 50000.0, 4.0)
+            md.set_cfr(True, 50.0, 0.1)
+            md.set_tii(True, 3, 5, False)
+            md.set_output_format(fmt)
+            outs.append(md.chain(bits, pkg.STAGE_GAIN))
+        finally:
+            md.close()
+    want, _ = O.format_convert(outs[0], "s16")
+    assert outs[1].dtype == np.int16 and np.array_equal(outs[1].reshape(-1), want.reshape(-1))
 
 
 # --------------------------------------------------------------------------- f-4 TII
