@@ -42,6 +42,15 @@ ALGO_BYTES = {
 }
 
 
+# Nominal fp32 operations per transmission frame of what the kernels EXECUTE: 5 N log2 N per
+# N-point transform, 2 per real-by-complex multiply-add, 40 per predistorted sample.  cfg 3: 77 transforms of 2048 points +
+# the spectral multiply (77 x 1536 x 6) + per boundary a 160-tap inverse filter over 44 outputs and a 990-term triangular
+# correction ((7040 + 990) x 4).  cfg 4: cfg 3 + per hop four 4096-point transforms and 8192 predistorted samples (96 hops).
+VALU_PEAK_TFLOPS = 157.3   # MI355X_MICROARCH.md: fp32 vector peak
+_CFG3_FLOPS = 77 * 5 * 2048 * 11 + 77 * 1536 * 6 + 77 * (7040 + 990) * 4
+EXEC_FLOPS = {"cfg3": _CFG3_FLOPS, "cfg4": _CFG3_FLOPS + 96 * (4 * 5 * 4096 * 12 + 8192 * 40)}
+
+
 def pkg():
     mod = importlib.import_module("odr-dabmod_amd")
     sys.modules["odr_dabmod_amd"] = mod
@@ -389,7 +398,11 @@ def main():
     KEEP = ("valu_busy", "lds_busy", "hbm_frac", "packed_fraction_of_valu", "wave_active_frac", "wave_issue_stall_frac",
             "wave_issue_stall_lds_frac", "wave_parked_frac", "lds_bank_conflict_share", "traffic_over_algorithmic")
 
-    def live_counters():
+    def live_counters(workload=None, frames=None):
+        workload = workload or args.workload
+        frames = frames or B
+        packed = packed_fraction if workload == args.workload else mj.get(workload, {}).get("packed_fraction_of_valu", 0.0) \
+            if mj.get("source_hash") == P.source_hash() else 0.0
         import glob
         import shutil
         import subprocess
@@ -404,7 +417,7 @@ def main():
             for i, pmc in enumerate(passes):
                 out = os.path.join(top, "p%d" % i)
                 cmd = ["rocprofv3", "--pmc"] + pmc.split() + ["-d", out, "-o", "pmc", "--", sys.executable,
-                       os.path.join(ROOT, "tools", "prof_run.py"), args.workload, str(B), "3"]
+                       os.path.join(ROOT, "tools", "prof_run.py"), workload, str(frames), "3"]
                 r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), capture_output=True, text=True, timeout=150)
                 found = glob.glob(os.path.join(out, "**", "*.db"), recursive=True)
                 if r.returncode != 0 or not found:
@@ -413,7 +426,7 @@ def main():
             blocks = counter_math.read_rocpd(dbs)
             if not blocks:
                 return None, "no kernel of the workload in the rocprofv3 output"
-            return counter_math.figures(blocks, algo * B, packed_fraction, "resampler" if "resampler" in blocks else "tf_kernel"), None
+            return counter_math.figures(blocks, ALGO_BYTES[workload] * frames, packed, "resampler" if "resampler" in blocks else "tf_kernel"), None
         except Exception as ex:                               # (timeout, unreadable output, ...)
             return None, "%s: %s" % (type(ex).__name__, str(ex)[:120])
         finally:
@@ -531,6 +544,8 @@ def main():
                      "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                      "kernel": "tf_kernel" if args.workload != "cfg4" else "tf_kernel+resampler_kernel",
                      "algorithmic_bytes_per_frame": algo, "kernel_ms_per_launch": round(kern_ms, 4), **busy,
+                     "valu_frac_of_peak": round(EXEC_FLOPS[args.workload] * value / world / 1e12 / VALU_PEAK_TFLOPS, 4)
+                     if args.workload in EXEC_FLOPS else None,
                      "limiter": limiter_of(busy), "issue_model": issue,
                      "counters_source": replay},
     }
@@ -563,6 +578,26 @@ def main():
                     gbps = algo2 * b2 / (k2 * 1e-3) / 1e9
                     extra[wl] = {"frames_per_s": round(b2 * k / w2, 2), "frames_per_step": b2,
                                  "achieved_GBps": round(gbps, 2), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4)}
+                    if wl == "cfg4":
+                        # "report fp32 VALU utilisation alongside" -- cfg 4 is bound by instruction issue, not by
+                        # HBM: the executed fp32 operations against the vector peak, and the same counters as the headline
+                        # kernel's (three more rocprofv3 --pmc passes, same launch shape)
+                        tf_s = b2 * k / w2
+                        extra[wl].update({"exec_flops_per_frame": EXEC_FLOPS["cfg4"],
+                                          "valu_TFLOPs": round(EXEC_FLOPS["cfg4"] * tf_s / 1e12, 2),
+                                          "valu_frac_of_peak": round(EXEC_FLOPS["cfg4"] * tf_s / 1e12 / VALU_PEAK_TFLOPS, 4),
+                                          "valu_peak_TFLOPs": VALU_PEAK_TFLOPS})
+                        if args.counters == "live":
+                            torch.cuda.empty_cache()
+                            t4, why4 = live_counters("cfg4", b2)
+                            if t4:
+                                extra[wl].update({k4: t4[k4] for k4 in KEEP if k4 in t4})
+                                extra[wl]["traffic"] = t4.get("hbm_bytes_per_launch")
+                                extra[wl]["effective_clock_GHz"] = t4.get("effective_clock_GHz_profiled")
+                                extra[wl]["limiter"] = limiter_of({k4: t4[k4] for k4 in KEEP if k4 in t4})
+                                extra[wl]["counters_source"] = "collected in this run: rocprofv3 --pmc, 3 passes of tools/prof_run.py cfg4 %d" % b2
+                            else:
+                                extra[wl]["counters_source"] = "live collection failed (%s)" % why4
                 except Exception as ex:  # secondary numbers must never break the contract line
                     extra[wl] = {"error": str(ex)[:200]}
             line["other_workloads"] = extra

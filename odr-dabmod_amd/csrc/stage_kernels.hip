@@ -315,7 +315,9 @@ void guard_fir_kernel(const cf *__restrict__ in, Geometry g, int W, const float 
     }
 }
 
-// a11 MemlessPoly polynomial (src/MemlessPoly.cpp:237-276), literal constants.
+// a11 MemlessPoly polynomial (src/MemlessPoly.cpp:237-276), literal constants.  The stand-alone drop-in is bound by
+// memory, not arithmetic, so it rounds every product and every sum on its own -- the reference's default x86-64 build has
+// no fused multiply-add -- and returns the reference's samples bit for bit (the resampler's fused epilogue keeps FMAs).
 __global__ void poly_kernel(const float4 *__restrict__ in, size_t npairs, const float *__restrict__ am,
                             const float *__restrict__ pm, float4 *__restrict__ out)
 {
@@ -326,6 +328,7 @@ __global__ void poly_kernel(const float4 *__restrict__ in, size_t npairs, const 
     const float4 x = in[i];
     float4 y;
     auto one = [&](float xr, float xi, float &yr, float &yi) {
+#pragma clang fp contract(off)
         const float m = xr * xr + xi * xi;
         const float a = a0 + m * (a1 + m * (a2 + m * (a3 + m * a4)));
         const float p = -1.0f * (p0 + m * (p1 + m * (p2 + m * (p3 + m * p4))));

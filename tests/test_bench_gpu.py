@@ -65,6 +65,24 @@ def test_bench_gpus_2_launches_two_ranks():
     assert one["n_gpus"] == 1
 
 
+def test_bench_gpus_2_on_the_full_chain_of_config_5():
+    """BASELINE config 5 says "full chain": two ranks of `bench.py --gpus 2 --workload cfg4` (frame kernel -> x4 resampler
+    with the polynomial predistorter), both on the one leased GPU over gloo -- the cfg 4 allocations (native-rate
+    intermediate, 4x output) and the per-rank resampler state under the launcher."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DABGPU_BENCH_DEVICES="0,0", DABGPU_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "cfg4", "--steps", "3",
+                        "--warmup", "1", "--frames", "128", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["frames_per_step_per_gpu"] == 128 and "config 4" in d["config"]["workload"]
+    assert d["roofline"]["algorithmic_bytes_per_frame"] == 28800 + 6291456 and d["value"] > 0
+    assert abs(d["value"] - 2 * 128 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+
+
 def test_bench_gpus_beyond_the_node_fails_loudly():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DABGPU_BENCH_DEVICES")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
