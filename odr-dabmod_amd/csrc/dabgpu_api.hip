@@ -550,6 +550,11 @@ GainParams gain_of(const dabgpu_ctx *c)
     gp.mode = c->cur.gain_mode;
     gp.constant = c->cur.normalise * c->cur.digital;  // src/GainControl.cpp:118
     gp.var_variance = c->cur.var_variance;
+    // (the reference forms normalise * digital in fp32, src/GainControl.cpp:118: gp.constant)
+    const double c1 = c->cur.var_variance != 0.f ? 32767.0 * (double)gp.constant / (double)c->cur.var_variance : 0.0;
+    gp.var_c1 = (float)c1;                                       // (var_variance 0: every symbol takes gain 1, var_sq = 0)
+    gp.var_c1_lo = (float)(c1 - (double)gp.var_c1);
+    gp.var_sq = c->cur.var_variance * c->cur.var_variance;
     return gp;
 }
 

@@ -40,6 +40,10 @@ struct GainParams {
     int mode;            // 0 fix, 1 max, 2 var
     float constant;      // normalise * digital  (reference src/GainControl.cpp:118)
     float var_variance;
+    float var_c1;        // mode var: 32767 * constant / var_variance, formed in float64 (the fused kernel's multiplier is
+                         // var_c1 / sqrt(exact variance): two roundings instead of seven)
+    float var_c1_lo;     // var_c1 + var_c1_lo = the float64 value to 48 bits
+    float var_sq;        // var_variance^2 (the "(int)(var_variance sigma) == 0" test on sigma^2)
 };
 
 // Arguments of the fused per-transmission-frame kernel.

@@ -864,6 +864,7 @@ void tf_kernel(const TfArgs a)
 
         float g = 1.0f;
         if (GAIN) {
+            bool g_final = false;                             // g already carries `constant` (and the carrier magnitude)
             if (FROM_BITS && !CFR && a.gain.mode == 2) {
                 const float *redf = reinterpret_cast<const float *>(red + 8 * (s & 1));
                 float S = 0.f;
@@ -872,10 +873,27 @@ void tf_kernel(const TfArgs a)
                 // |X| of the symbol: the table holds the COMPONENT magnitude; diagonal states
                 // (odd phase, the same parity on every carrier) have modulus sqrt(2) times that
                 const float mg = mag_l[s - 1];                               // the loop never sees s = 0 here
-                const float m2 = mg * mg * (float)(1u + ((unsigned)(s - 1) & 1u));   // (the carriers' own parts are even)
-                const float vr = fast_sqrt(m2 * fmaxf((float)(K / 2) + S, 0.f)) * a.gain.var_variance;
-                const float vi = fast_sqrt(m2 * fmaxf((float)(K / 2) - S, 0.f)) * a.gain.var_variance;
-                g = ((int)vr == 0) ? 1.0f : 32767.0f * fast_rcp(fmaxf(vr, vi));
+                const float par1 = (float)(1u + ((unsigned)(s - 1) & 1u));   // (the carriers' own parts are even)
+                const float m2 = mg * mg * par1;
+                // The multiplier in as few roundings as it takes (round 4: the scalar is held to 2e-7 of the EXACT value):
+                //     g constant = [32767 constant / var_variance] / sqrt(|X|^2 (K/2 + |S|)),
+                // the bracket formed in float64 on the host and handed over as a float pair (GainParams::var_c1 + var_c1_lo: its
+                // own rounding alone was a constant -4e-8 at normalise = 1/50000), K/2 + |S| an exact integer, the inverse root
+                // as v_rsq_f32 (1 ulp) plus one Newton step.  |X| = (1 - dlt) with dlt ~ 1e-7 the drift of the reference's
+                // fp32 recurrence (the table holds the COMPONENT magnitude: |X| = mg, or mg sqrt 2 on the diagonal states):
+                // 1 / |X| = 1 + dlt goes into the low word.  Where the carrier magnitude rides on the multiplier (MAG_IN_GAIN)
+                // it cancels against |X| up to the factor 1 or sqrt 2, and (1 + parity)(K/2 + |S|) is an exact integer too.
+                const float A = (float)(K / 2) + fabsf(S);
+                const float u = MAG_IN_GAIN ? par1 * A : A;
+                float r = fast_rsq(u);
+                r = fmaf(0.5f * r, fmaf(-u * r, r, 1.0f), r);
+                const float dlt = MAG_IN_GAIN ? 0.f
+                                  : (par1 == 1.0f ? 1.0f - mg : fmaf(-mg, 2.4203e-8f, fmaf(-mg, 1.41421354f, 1.0f)));
+                // "(int)(var_variance sigma_re) == 0 -> gain 1" (src/GainControl.cpp:324-331): sigma_re^2 var^2 < 1
+                const bool blank = m2 * fmaxf((float)(K / 2) + S, 0.f) * a.gain.var_sq < 1.0f;
+                g = blank ? a.gain.constant * (MAG_IN_GAIN ? mg : 1.0f)
+                          : fmaf(a.gain.var_c1, r, fmaf(a.gain.var_c1, dlt, a.gain.var_c1_lo) * r);
+                g_final = true;
             } else if (!FROM_BITS && !CFR && (GVAR || a.gain.mode == 2) && s > 0) {
                 g = spectral_gain(reinterpret_cast<const float *>(red + 8 * (s & 1)));
             } else if (GVAR) {
@@ -885,12 +903,12 @@ void tf_kernel(const TfArgs a)
             } else {
                 g = (s == 0) ? g_null : symbol_gain_fused<T>(v, a.gain, red + 8 * (s & 1), tt, lane_on);
             }
-            g = g * a.gain.constant;
+            if (!g_final) g = g * a.gain.constant;
             // TII (f-4): the null symbol of the coded-bits path is added afterwards, scaled by the
             // multiplier of symbol 1 (src/GainControl.cpp:139-144)
             if (FROM_BITS && a.gain1 != nullptr && s == 1 && t == 0) a.gain1[frame] = g;
             if (TII_IN && s == 1) g1s = __builtin_bit_cast(float, __builtin_amdgcn_readfirstlane(__builtin_bit_cast(int, g)));
-            if (MAG_IN_GAIN) g *= mag_l[s - 1];
+            if (MAG_IN_GAIN && !g_final) g *= mag_l[s - 1];   // (symbol 1's |y| is exactly 1: the exported g1 is the plain multiplier)
         }
 
         // FIR variants: both transforms of the symbol take the gain here, as packed multiplies on the

@@ -355,13 +355,18 @@ def test_chain_rational_rate_with_poly(pkg):
 
 
 # --------------------------------------------------------------------------- the fused chain
+def _chain_case_bits(mode, n_frames):
+    per = O.tf_input_bytes(mode)
+    return np.concatenate([golden_bits(mode)] + [synth_bits(per, seed=1000 + i) for i in range(n_frames - 1)])
+
+
 def _chain_case(pkg, mode, stages, chunks, n_frames, oracle_kw, setup):
     md = pkg.Modulator(mode=mode, max_frames=n_frames, chunks_per_frame=chunks)
     try:
         setup(md)
         per = md.geometry["tf_input_bytes"]
-        bits = np.concatenate([golden_bits(mode)] +
-                              [synth_bits(per, seed=1000 + i) for i in range(n_frames - 1)])
+        bits = _chain_case_bits(mode, n_frames)
+        assert bits.size == n_frames * per
         y = md.chain(bits, stages)
         ref = O.Chain(mode=mode, stages=stages & 0xF, **oracle_kw).process(bits)
         assert y.shape == ref.shape
@@ -372,20 +377,46 @@ def _chain_case(pkg, mode, stages, chunks, n_frames, oracle_kw, setup):
         md.close()
 
 
-def _split_gain_scalar(y, ref, mode):
-    """Attribute the error of a native-rate chain with GainControl to the two stages that own it: per OFDM
-    symbol the real scale alpha between device and oracle (a7: the gain SCALAR, bar rel 2e-7 -- the reference's fp32
-    running-variance recurrence against the exact population variance the fused kernel evaluates) and what is left once
-    that scale is taken out (a6 / a8 / a9: the transform's, the seam's and the filter's own rounding).  Returns
-    (max |alpha - 1|, max |y - alpha ref| / |ref|_inf)."""
+def _split_gain_scalar(y, ref, mode, bits=None, gain_mode=None, normalise=1.0, head=0, tail=0):
+    """Attribute the error of a native-rate chain with GainControl to the stages that own it.  Per OFDM symbol
+    the real scale alpha between device and oracle is the ratio of the two gain SCALARS (a7); what is left once that scale
+    is taken out is the transform's, the seam's and the filter's own rounding (a6 / a8 / a9).
+
+    Gain mode var: the reference's scalar comes out of an fp32 running-mean / running-variance recurrence
+    (src/GainControl.cpp:251-340) that is itself up to 6e-7 away from the exact population variance of its own samples
+    (tests/test_oracle_golden.py::test_reference_var_gain_recurrence_against_the_exact_variance), and the fused kernel
+    evaluates that exact variance.  With `bits` given, the device scalar is therefore ALSO compared with the exact value
+    (float64 statistics of the oracle's own symbols): that is the part the kernel's arithmetic is answerable for.
+
+    `head` / `tail`: samples at either end of a symbol's segment that also carry the NEIGHBOURING symbol's scalar (a
+    windowed seam: the overlap; FIRFilter: its ntaps - 1 look-ahead samples) -- alpha is fitted and the residual taken on
+    the rest, those samples stay under the chain's total bar.
+
+    Returns (max |alpha - 1|, max |y - alpha ref| / |ref|_inf, max |g_device / g_exact - 1| or None)."""
     g = O.mode_params(mode)
-    ns, ss, nsym = g["null_size"], g["sym_size"], g["nb_symbols"]
+    ns, ss, nsym, K, N = g["null_size"], g["sym_size"], g["nb_symbols"], g["carriers"], g["spacing"]
     peak = np.abs(ref).max()
-    da, res = 0.0, 0.0
+    da, res, dex = 0.0, 0.0, None
     for f in range(ref.shape[0]):
+        ratio = None
+        if bits is not None and gain_mode == 2:
+            # g_reference / g_exact per symbol, from the oracle's own stages
+            pr, _ = O.phase_reference(mode)
+            fb = np.asarray(bits).reshape(ref.shape[0], -1)[f]
+            z = O.signal_mux(np.zeros(K, np.complex64), O.diff_mod(pr, O.freq_interleave(O.qpsk_map(fb, K), mode), K))
+            x = O.ofdm_generate(z, nsym + 1, K, N).reshape(nsym + 1, N)
+            yg = O.gain_control(x.reshape(-1), N, 2, 1.0, normalise, 4.0).reshape(nsym + 1, N)
+            ratio = np.ones(nsym + 1)
+            for s_ in range(1, nsym + 1):
+                xs, ys = x[s_].astype(np.complex128), yg[s_].astype(np.complex128)
+                g_ref = np.vdot(xs, ys).real / np.vdot(xs, xs).real
+                g_exact = 32767.0 / (4.0 * max(xs.real.std(), xs.imag.std())) * float(np.float32(normalise))
+                ratio[s_] = g_ref / g_exact
+            ratio[0] = ratio[1]                                  # the null symbol takes symbol 1's multiplier
         for s_ in range(nsym + 1):
             lo = 0 if s_ == 0 else ns + (s_ - 1) * ss
-            hi = ns if s_ == 0 else lo + ss
+            hi = (ns if s_ == 0 else lo + ss) - tail
+            lo += head
             r = ref[f, lo:hi].astype(np.complex128)
             d = y[f, lo:hi].astype(np.complex128)
             e = np.vdot(r, r).real
@@ -395,7 +426,27 @@ def _split_gain_scalar(y, ref, mode):
             alpha = np.vdot(r, d).real / e
             da = max(da, abs(alpha - 1.0))
             res = max(res, np.abs(d - alpha * r).max() / peak)
-    return da, res
+            if ratio is not None:
+                dex = max(dex or 0.0, abs(alpha * ratio[s_] - 1.0))
+    return da, res, dex
+
+
+def _hold_gain_bars(tag, y, ref, mode, bits, gain_mode, normalise, residual_limit, total_limit, head=0, tail=0):
+    """The bars of a native-rate chain with GainControl, one per stage.  residual_limit: the bar of the stages besides the
+    scalar -- chains with FIRFilter: a9's 5e-7 plus the two roundings of the gain multiply itself (device and reference
+    each round sample x multiplier once: 2 x 2^-24), 6.2e-7 of the largest sample.  a7: mode var -- the device scalar within 2e-7 of
+    the EXACT value, and within 8e-7 of the reference's (2e-7 + the 6e-7 the reference's own recurrence is off); mode max --
+    within 3.5e-7 of the reference's: the largest component of two different fp32 transforms, i.e. a6's rounding at that one
+    sample (its 2e-5 absolute on a largest component of 50 ... 110, Mode III ... Mode I)."""
+    da, res, dex = _split_gain_scalar(y, ref, mode, bits, gain_mode, normalise, head, tail)
+    ok = True
+    if gain_mode == 2:
+        ok &= record_bound("a7 gain scalar against the exact variance, rel, " + tag, dex, 2e-7)
+        ok &= record_bound("a7 gain scalar against the reference's recurrence, rel, " + tag, da, 8e-7)
+    else:
+        ok &= record_bound("a7 gain scalar (mode %s) against the reference's, rel, " % gain_mode + tag, da, 3.5e-7)
+    ok &= record_bound("max-abs / |out|_inf after the gain scalar (symbol interiors), " + tag, res, residual_limit)
+    return ok and np.abs(y - ref).max() / np.abs(ref).max() <= total_limit
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
@@ -416,11 +467,8 @@ def test_chain_cfg3_gain_var_fir(pkg, mode, chunks):
     # The per-stage bounds of SURVEY 8(a) along the chain, each held on its own: a7 -- the gain scalar of every symbol
     # within 2e-7 of the reference's -- and a9 -- 5e-7 * |in|_inf of the filter on what is left once that scalar is taken
     # out (the IFFT's own rounding, rel-RMS 1e-7, is inside it).  Their sum (7e-7 of the largest sample) bounds the total.
-    da, res = _split_gain_scalar(y, ref, mode)
-    assert record_bound("a7 gain scalar of the fused chain cfg3, rel, mode %d chunks %d" % (mode, chunks), da, 2e-7)
-    assert record_bound("a6+a9 fused chain cfg3 max-abs / |out|_inf after the gain scalar, mode %d chunks %d" % (mode, chunks),
-                        res, 5e-7)
-    assert np.abs(y - ref).max() / np.abs(ref).max() <= 7e-7
+    assert _hold_gain_bars("a6+a9 fused chain cfg3, mode %d chunks %d" % (mode, chunks), y, ref, mode,
+                           _chain_case_bits(mode, 3), 2, 1.0 / 50000.0, 6.2e-7, 1e-6, tail=44)
 
 
 @pytest.mark.parametrize("gain", [(2, 1.0 / 50000.0), (0, 1.0), (None, 0)])
@@ -585,10 +633,8 @@ def test_chain_windowed_guard_without_fir_is_windowed_by_the_frame_kernel(pkg, m
     if gain_mode is None:
         assert record_bound("a6+a8 windowed chain max-abs / |out|_inf, " + tag, np.abs(y - ref).max() / np.abs(ref).max(), 3e-7)
     else:
-        da, res = _split_gain_scalar(y, ref, mode)
-        assert record_bound("a7 gain scalar of the windowed chain, rel, " + tag, da, 2e-7)
-        assert record_bound("a6+a8 windowed chain max-abs / |out|_inf after the gain scalar, " + tag, res, 3e-7)
-        assert np.abs(y - ref).max() / np.abs(ref).max() <= 5e-7
+        assert _hold_gain_bars("a6+a8 windowed chain, " + tag, y, ref, mode, _chain_case_bits(mode, 2), gain_mode,
+                               1.0 / 50000.0 if gain_mode == 2 else 1.0, 3e-7, 8e-7, head=overlap, tail=overlap)
 
 
 @pytest.mark.parametrize("mode,overlap", [(1, 10), (1, 1), (1, 128), (2, 10), (2, 80), (3, 7), (3, 19), (4, 10)])
@@ -614,10 +660,8 @@ def test_chain_windowed_guard_with_fir_is_one_kernel_too(pkg, mode, overlap, chu
         assert record_bound("a6+a8+a9 windowed chain with FIR max-abs / |out|_inf, " + tag,
                             np.abs(y - ref).max() / np.abs(ref).max(), 5e-7)
     else:
-        da, res = _split_gain_scalar(y, ref, mode)
-        assert record_bound("a7 gain scalar of the windowed chain with FIR, rel, " + tag, da, 2e-7)
-        assert record_bound("a6+a8+a9 windowed chain with FIR max-abs / |out|_inf after the gain scalar, " + tag, res, 5e-7)
-        assert np.abs(y - ref).max() / np.abs(ref).max() <= 7e-7
+        assert _hold_gain_bars("a6+a8+a9 windowed chain with FIR, " + tag, y, ref, mode, _chain_case_bits(mode, 2), gain_mode,
+                               1.0 / 50000.0 if gain_mode == 2 else 1.0, 6.2e-7, 1e-6, head=overlap, tail=overlap + 44)
 
 
 def test_chain_windowed_guard_with_a_short_and_a_long_filter(pkg):
