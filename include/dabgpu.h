@@ -273,6 +273,14 @@ DABGPU_API int dabgpu_chain_submit(dabgpu_ctx *ctx, const uint8_t *bits, size_t 
                                    unsigned stage_mask);
 DABGPU_API int dabgpu_chain_collect(dabgpu_ctx *ctx, const void **iq, size_t *out_bytes);
 
+/* Which kernels did the most recent chain call (dabgpu_chain_process / _process_dev / _submit, dabgpu_symbols_process_dev)
+ * launch?  A "; "-separated list of kernel names in launch order, the frame kernel with the VALUES of its template arguments
+ * ("tf_kernel<logn=11 bits=1 gain=1 guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=0 win=0 eq=1>").  The fused chain picks
+ * one of ~120 instantiations from the settings (mode, gain mode, filter length, windowing, CFR, TII, output format): this
+ * makes the choice observable, so that a test can walk the whole matrix (tests/test_dispatch_matrix.py) and a user can see
+ * what a configuration costs.  Diagnostic: not part of the reference's interface. */
+DABGPU_API int dabgpu_debug_last_variant(dabgpu_ctx *ctx, char *buf, size_t cap);
+
 /* wait for everything queued on the context's own stream */
 DABGPU_API int dabgpu_synchronize(dabgpu_ctx *ctx);
 

@@ -108,7 +108,35 @@ struct Settings {
 
 }  // namespace
 
+// ---- launch trace (dabgpu_internal.h) -------------------------------------------------------------------------------
+namespace dabgpu {
+namespace {
+thread_local std::string *g_trace_sink = nullptr;
+}
+bool trace_on() { return g_trace_sink != nullptr; }
+void trace_launch(const char *what)
+{
+    if (!g_trace_sink) return;
+    // (the macro stringifies "(kernel<...>)": drop the outer parentheses)
+    std::string w(what);
+    if (w.size() > 2 && w.front() == '(' && w.back() == ')') w = w.substr(1, w.size() - 2);
+    if (!g_trace_sink->empty()) *g_trace_sink += "; ";
+    *g_trace_sink += w;
+}
+}  // namespace dabgpu
+
+namespace {
+// names the kernels of one chain call into ctx->last_variant
+struct TraceScope {
+    std::string *prev;
+    explicit TraceScope(std::string *sink) : prev(g_trace_sink_ref()) { sink->clear(); g_trace_sink_ref() = sink; }
+    ~TraceScope() { g_trace_sink_ref() = prev; }
+    static std::string *&g_trace_sink_ref() { return dabgpu::g_trace_sink; }
+};
+}  // namespace
+
 struct dabgpu_ctx {
+    std::string last_variant;             // dabgpu_debug_last_variant: the kernels the most recent chain call launched
     Geometry g{};
     int device = 0;
     int max_frames = 1;
@@ -1230,6 +1258,15 @@ int dabgpu_set_resampler(dabgpu_ctx *c, size_t in_rate, size_t out_rate)
     return DABGPU_OK;
 }
 
+int dabgpu_debug_last_variant(dabgpu_ctx *c, char *buf, size_t cap)
+{
+    if (!c || !buf || cap == 0) return DABGPU_E_INVALID;
+    const std::string &v = c->last_variant;
+    if (v.size() + 1 > cap) return fail(c, DABGPU_E_CAPACITY, "buffer too small for the launch trace");
+    std::memcpy(buf, v.c_str(), v.size() + 1);
+    return DABGPU_OK;
+}
+
 int dabgpu_set_fir_boundary_mode(dabgpu_ctx *c, int mode)
 {
     if (!c) return DABGPU_E_INVALID;
@@ -1650,6 +1687,7 @@ int dabgpu_chain_process_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames,
     CTXCHK(c);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     c->clip_from_collect = false;
+    TraceScope trace(&c->last_variant);
     return run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
 }
 
@@ -1659,6 +1697,7 @@ int dabgpu_symbols_process_dev(dabgpu_ctx *c, const void *d_car, size_t n_frames
     CTXCHK(c);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     c->clip_from_collect = false;
+    TraceScope trace(&c->last_variant);
     return run_chain(c, d_car, false, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
 }
 
@@ -1680,7 +1719,10 @@ int dabgpu_chain_process(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, un
     // final output lives in its own buffer: d_a / d_b / d_c are the chain's scratch
     HIPCHK(c, c->d_out.reserve(std::max<size_t>(need, 16)));
     size_t ob = 0;
-    rc = run_chain(c, c->d_in.p, true, n_frames, mask, (float2 *)c->d_out.p, need, &ob, c->stream);
+    {
+        TraceScope trace(&c->last_variant);
+        rc = run_chain(c, c->d_in.p, true, n_frames, mask, (float2 *)c->d_out.p, need, &ob, c->stream);
+    }
     if (rc) return rc;
     return io.out(iq_out, c->d_out.p, need);
 }
@@ -1725,7 +1767,10 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     std::memcpy(sl.h_in, bits, in_bytes);                       // 28.8 kB per frame
     if (in_bytes) HIPCHK(c, hipMemcpyAsync(sl.d_in.p, sl.h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
     size_t ob = 0;
-    rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, c->stream);
+    {
+        TraceScope trace(&c->last_variant);
+        rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, c->stream);
+    }
     if (rc) return rc;
     sl.out_format = c->cur.out_format;
     if (sl.out_format) {

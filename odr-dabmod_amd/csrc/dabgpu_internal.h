@@ -36,6 +36,17 @@ struct Tables {
     const float *eq_g;            // TF_EQ: kEqTaps + 1 floats, the inverse of the taps on the occupied bins (see tf_kernel<..., EQ>)
 };
 
+// Launch trace (dabgpu_debug_last_variant): every kernel launch of the library goes through DABGPU_LAUNCH, which names the
+// kernel to the calling thread's trace sink when one is set -- the chain entry points set it for the duration of the call.
+// Off the traced path this is one thread-local pointer test per launch.
+bool trace_on();
+void trace_launch(const char *what);
+#define DABGPU_LAUNCH(kernel, ...)                                      \
+    do {                                                                \
+        if (::dabgpu::trace_on()) ::dabgpu::trace_launch(#kernel);      \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__);                        \
+    } while (0)
+
 struct GainParams {
     int mode;            // 0 fix, 1 max, 2 var
     float constant;      // normalise * digital  (reference src/GainControl.cpp:118)

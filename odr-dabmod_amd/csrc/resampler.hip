@@ -564,7 +564,7 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
                     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(resampler16_kernel<P, F, QQ>),   \
                                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds16);        \
                     if (e != hipSuccess) return e;                                                                     \
-                    hipLaunchKernelGGL((resampler16_kernel<P, F, QQ>), grid16, block16, lds16, s, a, hpr16);           \
+                    DABGPU_LAUNCH((resampler16_kernel<P, F, QQ>), grid16, block16, lds16, s, a, hpr16);           \
                 } while (0)
                 if (Q == 4) {
                     if (a.clipped) { if (poly) RS16_LAUNCH(true, true, 4); else RS16_LAUNCH(false, true, 4); }
@@ -576,12 +576,12 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
 #undef RS16_LAUNCH
             } else if (Q == 2) {
                 if (a.clipped) return hipErrorInvalidValue;
-                if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, true>), grid, block, lds, s, a, hpr);
-                else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
+                if (poly) DABGPU_LAUNCH((resampler_kernel<LOGNIN, 2, true>), grid, block, lds, s, a, hpr);
+                else DABGPU_LAUNCH((resampler_kernel<LOGNIN, 2, false>), grid, block, lds, s, a, hpr);
             } else {
                 if (a.clipped) return hipErrorInvalidValue;
-                if (poly) hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
-                else hipLaunchKernelGGL((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
+                if (poly) DABGPU_LAUNCH((resampler_kernel<LOGNIN, 4, true>), grid, block, lds, s, a, hpr);
+                else DABGPU_LAUNCH((resampler_kernel<LOGNIN, 4, false>), grid, block, lds, s, a, hpr);
             }
             break;
         default: return hipErrorInvalidValue;

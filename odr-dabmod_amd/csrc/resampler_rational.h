@@ -343,10 +343,10 @@ template <int LOGNIN, int LOGS> hipError_t launch_resampler_rational(const Resam
     hipError_t e;
     if (a.nout < a.nin) {
         if ((e = allow_lds(resampler_rational_kernel<LOGNIN, LOGS, true>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((resampler_rational_kernel<LOGNIN, LOGS, true>), grid, block, lds, s, a, hpr, cl_in_lds);
+        DABGPU_LAUNCH((resampler_rational_kernel<LOGNIN, LOGS, true>), grid, block, lds, s, a, hpr, cl_in_lds);
     } else {
         if ((e = allow_lds(resampler_rational_kernel<LOGNIN, LOGS, false>, lds)) != hipSuccess) return e;
-        hipLaunchKernelGGL((resampler_rational_kernel<LOGNIN, LOGS, false>), grid, block, lds, s, a, hpr, cl_in_lds);
+        DABGPU_LAUNCH((resampler_rational_kernel<LOGNIN, LOGS, false>), grid, block, lds, s, a, hpr, cl_in_lds);
     }
     return hipGetLastError();
 }
@@ -359,7 +359,7 @@ template <int LOGNIN, int LOGS> hipError_t launch_resampler_lane(const Resampler
     const size_t lds = rational_lds_bytes<LOGNIN>(0, nullptr);
     hipError_t e = allow_lds(resampler_lane_kernel<LOGNIN, LOGS>, lds);
     if (e != hipSuccess) return e;
-    hipLaunchKernelGGL((resampler_lane_kernel<LOGNIN, LOGS>), grid, block, lds, s, a, hpr);
+    DABGPU_LAUNCH((resampler_lane_kernel<LOGNIN, LOGS>), grid, block, lds, s, a, hpr);
     return hipGetLastError();
 }
 

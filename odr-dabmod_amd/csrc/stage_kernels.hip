@@ -365,7 +365,7 @@ hipError_t launch_qpsk(const uint8_t *in, size_t nbytes, int K, float2 *out, hip
 {
     const size_t npairs = nbytes * 2;
     if (npairs == 0) return hipSuccess;
-    hipLaunchKernelGGL(qpsk_kernel, dim3(blocks_for(npairs, 256)), dim3(256), 0, s, in, npairs, K,
+    DABGPU_LAUNCH(qpsk_kernel, dim3(blocks_for(npairs, 256)), dim3(256), 0, s, in, npairs, K,
                        reinterpret_cast<float4 *>(out));
     return hipGetLastError();
 }
@@ -374,14 +374,14 @@ hipError_t launch_freq_interleave(const float2 *in, size_t nsamples, int K,
                                   const uint16_t *src_carrier, float2 *out, hipStream_t s)
 {
     if (nsamples == 0) return hipSuccess;
-    hipLaunchKernelGGL(freq_interleave_kernel, dim3(blocks_for(nsamples, 256)), dim3(256), 0, s, in,
+    DABGPU_LAUNCH(freq_interleave_kernel, dim3(blocks_for(nsamples, 256)), dim3(256), 0, s, in,
                        nsamples, K, src_carrier, out);
     return hipGetLastError();
 }
 
 hipError_t launch_phase_reference(const uint8_t *phase_q, int K, float2 *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(phase_reference_kernel, dim3(blocks_for((size_t)K, 256)), dim3(256), 0, s,
+    DABGPU_LAUNCH(phase_reference_kernel, dim3(blocks_for((size_t)K, 256)), dim3(256), 0, s,
                        phase_q, K, out);
     return hipGetLastError();
 }
@@ -389,7 +389,7 @@ hipError_t launch_phase_reference(const uint8_t *phase_q, int K, float2 *out, hi
 hipError_t launch_diff_mod(const float2 *phase, const float2 *data, size_t nsym_data, int K,
                            float2 *out, hipStream_t s)
 {
-    hipLaunchKernelGGL(diff_mod_kernel, dim3(blocks_for((size_t)K, 64)), dim3(64), 0, s, phase, data,
+    DABGPU_LAUNCH(diff_mod_kernel, dim3(blocks_for((size_t)K, 64)), dim3(64), 0, s, phase, data,
                        nsym_data, K, out);
     return hipGetLastError();
 }
@@ -400,10 +400,10 @@ hipError_t launch_gain(const float2 *in, size_t nsym, int N, GainParams gp, floa
     if (nsym == 0) return hipSuccess;
     const dim3 grid((unsigned)nsym);
     switch (N) {
-        case 256: hipLaunchKernelGGL(gain_kernel<8>, grid, dim3(64), 0, s, in, nsym, gp, out); break;
-        case 512: hipLaunchKernelGGL(gain_kernel<9>, grid, dim3(64), 0, s, in, nsym, gp, out); break;
-        case 1024: hipLaunchKernelGGL(gain_kernel<10>, grid, dim3(128), 0, s, in, nsym, gp, out); break;
-        case 2048: hipLaunchKernelGGL(gain_kernel<11>, grid, dim3(256), 0, s, in, nsym, gp, out); break;
+        case 256: DABGPU_LAUNCH(gain_kernel<8>, grid, dim3(64), 0, s, in, nsym, gp, out); break;
+        case 512: DABGPU_LAUNCH(gain_kernel<9>, grid, dim3(64), 0, s, in, nsym, gp, out); break;
+        case 1024: DABGPU_LAUNCH(gain_kernel<10>, grid, dim3(128), 0, s, in, nsym, gp, out); break;
+        case 2048: DABGPU_LAUNCH(gain_kernel<11>, grid, dim3(256), 0, s, in, nsym, gp, out); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
@@ -414,7 +414,7 @@ hipError_t launch_guard_copy(const float2 *in, size_t n_frames, Geometry g, floa
 {
     const size_t n = n_frames * ((size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(guard_copy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, n_frames, g,
+    DABGPU_LAUNCH(guard_copy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, n_frames, g,
                        out);
     return hipGetLastError();
 }
@@ -424,7 +424,7 @@ hipError_t launch_guard_window(const float2 *in, size_t n_frames, Geometry g, in
 {
     const size_t n = n_frames * ((size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size);
     if (n == 0) return hipSuccess;
-    hipLaunchKernelGGL(guard_window_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, n_frames,
+    DABGPU_LAUNCH(guard_window_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, n_frames,
                        g, overlap, window, out);
     return hipGetLastError();
 }
@@ -438,15 +438,15 @@ hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, c
     if (ntaps <= 48) {
         FirTaps<48> t{};
         std::copy(taps, taps + ntaps, t.t);
-        hipLaunchKernelGGL(fir_kernel<48>, grid, dim3(256), 0, s, in, frame_samples, t, out);
+        DABGPU_LAUNCH(fir_kernel<48>, grid, dim3(256), 0, s, in, frame_samples, t, out);
     } else if (ntaps <= 128) {
         FirTaps<128> t{};
         std::copy(taps, taps + ntaps, t.t);
-        hipLaunchKernelGGL(fir_kernel<128>, grid, dim3(256), 0, s, in, frame_samples, t, out);
+        DABGPU_LAUNCH(fir_kernel<128>, grid, dim3(256), 0, s, in, frame_samples, t, out);
     } else {
         FirTaps<512> t{};
         std::copy(taps, taps + ntaps, t.t);
-        hipLaunchKernelGGL(fir_kernel<512>, grid, dim3(256), 0, s, in, frame_samples, t, out);
+        DABGPU_LAUNCH(fir_kernel<512>, grid, dim3(256), 0, s, in, frame_samples, t, out);
     }
     return hipGetLastError();
 }
@@ -461,15 +461,15 @@ hipError_t launch_guard_fir(const float2 *in, size_t n_frames, Geometry g, int o
     if (ntaps <= 48) {
         FirTaps<48> t{};
         std::copy(taps, taps + ntaps, t.t);
-        hipLaunchKernelGGL(guard_fir_kernel<48>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+        DABGPU_LAUNCH(guard_fir_kernel<48>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
     } else if (ntaps <= 128) {
         FirTaps<128> t{};
         std::copy(taps, taps + ntaps, t.t);
-        hipLaunchKernelGGL(guard_fir_kernel<128>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+        DABGPU_LAUNCH(guard_fir_kernel<128>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
     } else {
         FirTaps<512> t{};
         std::copy(taps, taps + ntaps, t.t);
-        hipLaunchKernelGGL(guard_fir_kernel<512>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+        DABGPU_LAUNCH(guard_fir_kernel<512>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
     }
     return hipGetLastError();
 }
@@ -481,7 +481,7 @@ hipError_t launch_poly(const float2 *in, size_t nsamples, const float *am, const
     // pairs of samples as float4; an odd tail sample is handled as a second tiny launch
     const size_t npairs = nsamples / 2;
     if (npairs)
-        hipLaunchKernelGGL(poly_kernel, dim3(blocks_for(npairs, 256)), dim3(256), 0, s,
+        DABGPU_LAUNCH(poly_kernel, dim3(blocks_for(npairs, 256)), dim3(256), 0, s,
                            reinterpret_cast<const float4 *>(in), npairs, am, pm,
                            reinterpret_cast<float4 *>(out));
     if (nsamples & 1) {
@@ -495,7 +495,7 @@ hipError_t launch_lut(const float2 *in, size_t nsamples, float scale, const floa
                       hipStream_t s)
 {
     if (nsamples == 0) return hipSuccess;
-    hipLaunchKernelGGL(lut_kernel, dim3(blocks_for(nsamples, 256)), dim3(256), 0, s, in, nsamples,
+    DABGPU_LAUNCH(lut_kernel, dim3(blocks_for(nsamples, 256)), dim3(256), 0, s, in, nsamples,
                        scale, lut, out);
     return hipGetLastError();
 }
@@ -608,14 +608,14 @@ void format_kernel(const float *__restrict__ in, size_t n, void *__restrict__ ou
 hipError_t launch_cic(const float2 *in, size_t nsamples, int K, const float *filter, float2 *out, hipStream_t s)
 {
     if (nsamples == 0) return hipSuccess;
-    hipLaunchKernelGGL(cic_kernel, dim3(blocks_for(nsamples, 256)), dim3(256), 0, s, in, nsamples, K, filter, out);
+    DABGPU_LAUNCH(cic_kernel, dim3(blocks_for(nsamples, 256)), dim3(256), 0, s, in, nsamples, K, filter, out);
     return hipGetLastError();
 }
 
 hipError_t launch_tii(const float2 *in, const uint8_t *acp, int K, int old_variant, int insert, float2 *out,
                       hipStream_t s)
 {
-    hipLaunchKernelGGL(tii_kernel, dim3((K + 255) / 256), dim3(256), 0, s, in, acp, K, old_variant, insert, out);
+    DABGPU_LAUNCH(tii_kernel, dim3((K + 255) / 256), dim3(256), 0, s, in, acp, K, old_variant, insert, out);
     return hipGetLastError();
 }
 
@@ -623,7 +623,7 @@ hipError_t launch_tii_add(float2 *out, size_t stride, const float2 *seg, int seg
                           int insert0, size_t n_frames, hipStream_t s)
 {
     if (n_frames == 0 || seg_len <= 0) return hipSuccess;
-    hipLaunchKernelGGL(tii_add_kernel, dim3((seg_len + 255) / 256, (unsigned)n_frames), dim3(256), 0, s, out,
+    DABGPU_LAUNCH(tii_add_kernel, dim3((seg_len + 255) / 256, (unsigned)n_frames), dim3(256), 0, s, out,
                        stride, seg, seg_len, gain1, insert0);
     return hipGetLastError();
 }
@@ -634,9 +634,9 @@ hipError_t launch_format(const float *in, size_t nfloats, int fmt, void *out, un
     if (nfloats == 0) return hipSuccess;
     const dim3 grid(blocks_for((nfloats + 7) / 8, 256)), block(256);
     switch (fmt) {
-        case 1: hipLaunchKernelGGL(format_kernel<1>, grid, block, 0, s, in, nfloats, out, clipped); break;
-        case 2: hipLaunchKernelGGL(format_kernel<2>, grid, block, 0, s, in, nfloats, out, clipped); break;
-        case 3: hipLaunchKernelGGL(format_kernel<3>, grid, block, 0, s, in, nfloats, out, clipped); break;
+        case 1: DABGPU_LAUNCH(format_kernel<1>, grid, block, 0, s, in, nfloats, out, clipped); break;
+        case 2: DABGPU_LAUNCH(format_kernel<2>, grid, block, 0, s, in, nfloats, out, clipped); break;
+        case 3: DABGPU_LAUNCH(format_kernel<3>, grid, block, 0, s, in, nfloats, out, clipped); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();

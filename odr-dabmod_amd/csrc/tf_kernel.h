@@ -28,6 +28,7 @@
 //
 // No MFMA (no dense contraction in this path), wave64 throughout.
 #pragma once
+#include <cstdio>
 #include "device_common.h"
 #include "tf_layout.h"
 
@@ -1115,6 +1116,20 @@ void tf_kernel(const TfArgs a)
     pt.flush(a.phase_cycles, pt_iterations);
 }
 
+// one launch of one instantiation, named to the launch trace by its template arguments' VALUES
+template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
+          bool ZONLY = false, int OFMT = 0, bool WIN = false, bool EQ = false>
+inline void tf_go(dim3 grid, dim3 block, size_t lds, hipStream_t s, const TfArgs &a)
+{
+    if (trace_on()) {
+        char name[200];
+        snprintf(name, sizeof name, "tf_kernel<logn=%d bits=%d gain=%d guard=%d fir=%d nt=%d cfr=%d gvar=%d zonly=%d ofmt=%d win=%d eq=%d>",
+                 LOGN, (int)FROM_BITS, (int)GAIN, (int)GUARD, (int)FIR, NT, (int)CFR, (int)GVAR, (int)ZONLY, OFMT, (int)WIN, (int)EQ);
+        trace_launch(name);
+    }
+    hipLaunchKernelGGL((tf_kernel<LOGN, FROM_BITS, GAIN, GUARD, FIR, NT, CFR, GVAR, ZONLY, OFMT, WIN, EQ>), grid, block, lds, s, a);
+}
+
 template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned flags, hipStream_t s)
 {
     constexpr int T = (1 << LOGN) / 8;
@@ -1127,11 +1142,11 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const bool gvar = !(flags & TF_FROM_BITS) && (flags & TF_GAIN) && !(flags & TF_CFR) && a.gain.mode == 2;
     const size_t lds = tf_lds_bytes(LOGN, flags | (gvar ? TF_GVAR : 0), (flags & TF_FIR) ? NT : 0, a.overlap, a.ntaps);
 #define TF_LAUNCH(FB, GN, GD, FR)                                                              \
-    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>), grid, block, lds, s, a)
+    tf_go<LOGN, FB, GN, GD, FR, (FR ? NT : 0)>(grid, block, lds, s, a)
 #define TF_LAUNCH_CFR(FB, GN, EPI)                                                             \
-    hipLaunchKernelGGL((tf_kernel<LOGN, FB, GN, EPI, EPI, (EPI ? NT : 0), true>), grid, block, lds, s, a)
+    tf_go<LOGN, FB, GN, EPI, EPI, (EPI ? NT : 0), true>(grid, block, lds, s, a)
 #define TF_LAUNCH_CFR_GUARD(GN)                                                                \
-    hipLaunchKernelGGL((tf_kernel<LOGN, true, GN, true, false, 0, true>), grid, block, lds, s, a)
+    tf_go<LOGN, true, GN, true, false, 0, true>(grid, block, lds, s, a)
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
@@ -1147,7 +1162,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
             // OFDM windowing with crest-factor reduction (coded-bits chain): the windowed variants with the CFR'd symbol
             if (!tf_has_window(a, flags)) return hipErrorInvalidValue;
 #define TF_LAUNCH_CFR_WIN(GN, FR) \
-            hipLaunchKernelGGL((tf_kernel<LOGN, true, GN, true, FR, 0, true, false, false, 0, true>), grid, block, lds, s, a)
+            tf_go<LOGN, true, GN, true, FR, 0, true, false, false, 0, true>(grid, block, lds, s, a)
             if (fr) { if (gn) TF_LAUNCH_CFR_WIN(true, true); else TF_LAUNCH_CFR_WIN(false, true); }
             else    { if (gn) TF_LAUNCH_CFR_WIN(true, false); else TF_LAUNCH_CFR_WIN(false, false); }
 #undef TF_LAUNCH_CFR_WIN
@@ -1163,10 +1178,10 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         return hipGetLastError();
     }
 #define TF_LAUNCH_GVAR(GD, FR)                                                                 \
-    hipLaunchKernelGGL((tf_kernel<LOGN, false, true, GD, FR, (FR ? NT : 0), false, true>), grid, block, lds, s, a)
+    tf_go<LOGN, false, true, GD, FR, (FR ? NT : 0), false, true>(grid, block, lds, s, a)
     if (gvar) {
         if (LOGN == 11 && NT == 45 && fr && gd) {
-            hipLaunchKernelGGL((tf_kernel<11, false, true, true, true, 45, false, true, true>), grid, block, lds, s, a);
+            tf_go<11, false, true, true, true, 45, false, true, true>(grid, block, lds, s, a);
             return hipGetLastError();
         }
         if (fr) TF_LAUNCH_GVAR(true, true); else if (gd) TF_LAUNCH_GVAR(true, false); else TF_LAUNCH_GVAR(false, false);
@@ -1176,16 +1191,16 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     if (flags & TF_WINDOW) {
         if (!tf_has_window(a, flags) || (NT != 0 && !fr)) return hipErrorInvalidValue;
         if (fr) {
-            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, true, NT, false, false, false, 0, true>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, true, NT, false, false, false, 0, true>), grid, block, lds, s, a);
+            if (gn) tf_go<LOGN, true, true, true, true, NT, false, false, false, 0, true>(grid, block, lds, s, a);
+            else tf_go<LOGN, true, false, true, true, NT, false, false, false, 0, true>(grid, block, lds, s, a);
         } else if constexpr (NT == 0) {
-            if (gn) hipLaunchKernelGGL((tf_kernel<LOGN, true, true, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((tf_kernel<LOGN, true, false, true, false, 0, false, false, false, 0, true>), grid, block, lds, s, a);
+            if (gn) tf_go<LOGN, true, true, true, false, 0, false, false, false, 0, true>(grid, block, lds, s, a);
+            else tf_go<LOGN, true, false, true, false, 0, false, false, false, 0, true>(grid, block, lds, s, a);
         }
         return hipGetLastError();
     }
     if (LOGN == 11 && NT == 45 && !fb && !gn && fr && gd) {
-        hipLaunchKernelGGL((tf_kernel<11, false, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        tf_go<11, false, false, true, true, 45, false, false, true>(grid, block, lds, s, a);
         return hipGetLastError();
     }
     if (LOGN == 11 && NT == 45 && fb && fr && gd && (!gn || a.gain.mode != 1)) {
@@ -1193,7 +1208,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
             // ... or the one that runs the filtered transform alone and equalises the boundary (needs the taps' inverse)
             if (!a.t.eq_g || ((flags & TF_OUT_S16) && !a.clipped)) return hipErrorInvalidValue;
 #define TF_LAUNCH_EQ(GN, OF) \
-            hipLaunchKernelGGL((tf_kernel<11, true, GN, true, true, 45, false, false, false, OF, false, true>), grid, block, lds, s, a)
+            tf_go<11, true, GN, true, true, 45, false, false, false, OF, false, true>(grid, block, lds, s, a)
             if (flags & TF_OUT_S16) { if (gn) TF_LAUNCH_EQ(true, 1); else TF_LAUNCH_EQ(false, 1); }
             else                    { if (gn) TF_LAUNCH_EQ(true, 0); else TF_LAUNCH_EQ(false, 0); }
 #undef TF_LAUNCH_EQ
@@ -1202,20 +1217,20 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         // Mode I, default filter length, gain fix / var (or none): the variant that prunes the unfiltered transform
         if (flags & TF_OUT_S16) {
             if (!a.clipped) return hipErrorInvalidValue;
-            if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true, 1>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true, 1>), grid, block, lds, s, a);
+            if (gn) tf_go<11, true, true, true, true, 45, false, false, true, 1>(grid, block, lds, s, a);
+            else tf_go<11, true, false, true, true, 45, false, false, true, 1>(grid, block, lds, s, a);
             return hipGetLastError();
         }
-        if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, true, 45, false, false, true>), grid, block, lds, s, a);
-        else hipLaunchKernelGGL((tf_kernel<11, true, false, true, true, 45, false, false, true>), grid, block, lds, s, a);
+        if (gn) tf_go<11, true, true, true, true, 45, false, false, true>(grid, block, lds, s, a);
+        else tf_go<11, true, false, true, true, 45, false, false, true>(grid, block, lds, s, a);
         return hipGetLastError();
     }
     if (flags & TF_OUT_S16) {
         // the reference's default chain (no FIRFilter) with s16 output, Mode I: any gain mode
         if (LOGN != 11 || NT != 0 || !fb || !gd || fr || !a.clipped) return hipErrorInvalidValue;   // (callers ask tf_has_s16 first)
         if constexpr (LOGN == 11 && NT == 0) {
-            if (gn) hipLaunchKernelGGL((tf_kernel<11, true, true, true, false, 0, false, false, false, 1>), grid, block, lds, s, a);
-            else hipLaunchKernelGGL((tf_kernel<11, true, false, true, false, 0, false, false, false, 1>), grid, block, lds, s, a);
+            if (gn) tf_go<11, true, true, true, false, 0, false, false, false, 1>(grid, block, lds, s, a);
+            else tf_go<11, true, false, true, false, 0, false, false, false, 1>(grid, block, lds, s, a);
         }
         return hipGetLastError();
     }
