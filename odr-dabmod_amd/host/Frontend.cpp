@@ -360,6 +360,19 @@ int EtiReader::loadEtiData(const Buffer &dataIn)
         switch (m_state) {
             case State::Sync:                                  // ERR + FSYNC
                 if (left < 4) return static_cast<int>(dataIn.getLength() - left);
+                if (m_resync) {
+                    // after a refused frame the stream position is no longer known to be a frame start (a caller that
+                    // feeds pieces not aligned to frames): look for ERR = 0xFF followed by one of the two FSYNC words
+                    // (src/Eti.h:50-61, doc/README-Fileinput) instead of taking the next four bytes on trust
+                    const bool sync = in[0] == 0xFF && ((in[1] == 0x07 && in[2] == 0x3A && in[3] == 0xB6) ||
+                                                         (in[1] == 0xF8 && in[2] == 0xC5 && in[3] == 0x49));
+                    if (!sync) {
+                        ++in;
+                        --left;
+                        break;
+                    }
+                    m_resync = false;
+                }
                 m_remaining = 6144;
                 take(4);
                 m_state = State::Fc;
@@ -406,6 +419,7 @@ int EtiReader::loadEtiData(const Buffer &dataIn)
                         const size_t beyond = m_remaining > left ? m_remaining - left : 0;
                         m_remaining = beyond;
                         m_state = beyond ? State::Pad : State::Sync;
+                        m_resync = true;                       // (the next frame start is searched for, not assumed)
                         m_stc.clear();
                         mySources.clear();
                         throw std::runtime_error("EtiReader: stream characterisation exceeds the 6144-byte ETI frame");

@@ -868,6 +868,10 @@ DabGpuChain::DabGpuChain(const Settings &s)
 
 void DabGpuChain::submit(const void *bits, size_t n_frames)
 {
+    // (the start-up emulation lives in process(): a streaming caller that wants the reference's frame count holds the
+    // frames back itself, as dabmod_file --batch --reference-latency does -- never silently N frames where N - k were asked)
+    if (m_drops)
+        throw std::runtime_error("DabGpuChain::submit: Settings::emulatePipelineDrops applies to process() only");
     m_ctx.check(dabgpu_chain_submit(m_ctx.get(), static_cast<const uint8_t *>(bits), n_frames, m_mask));
 }
 

@@ -337,7 +337,8 @@ public:
         // them emits frame i - k on call i and N - k frames for N calls.  With emulatePipelineDrops = k, process() does
         // the same: the first k calls return 0 (Flowgraph::run stops the walk, src/Flowgraph.cpp:334-336), call i
         // returns frame i - k, the last k frames never leave.  referencePipelineDepth() is the k of the equivalent
-        // reference graph.
+        // reference graph.  process() ONLY: submit() throws when the option is set (a streaming caller holds the frames
+        // back itself, see dabmod_file --batch --reference-latency).
         unsigned emulatePipelineDrops = 0;
         unsigned referencePipelineDepth() const
         {

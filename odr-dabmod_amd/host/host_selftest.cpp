@@ -307,6 +307,24 @@ int run_cpu()
         try { used = rd.loadEtiData(Buffer(rest.size(), rest.data())); } catch (const std::exception &) { threw2 = true; }
         CHECK(!threw2 && used == static_cast<int>(rest.size()));
         CHECK(rd.getSubchannels().size() == 1 && rd.getSubchannels()[0]->framesize() == 48 * 8);
+        // the other case: the offending frame ENDS inside the buffer that is refused (the exception drops the rest of that
+        // buffer, the first 100 bytes of the following frame with it), so the next call starts in the middle of a frame:
+        // the reader looks for ERR + FSYNC and picks up the first whole frame
+        EtiReader rd2(tist_offset);
+        std::vector<uint8_t> first(bad);
+        first.insert(first.end(), good.begin(), good.begin() + 100);
+        refused = false;
+        try { rd2.loadEtiData(Buffer(first.size(), first.data())); } catch (const std::runtime_error &) { refused = true; }
+        CHECK(refused);
+        std::vector<uint8_t> next(good.begin() + 100, good.end());           // 6044 bytes without a frame start
+        std::vector<uint8_t> good2 = frame(1, 48);
+        const uint8_t sync2[4] = {0xFF, 0xF8, 0xC5, 0x49};
+        std::memcpy(good2.data(), sync2, 4);
+        next.insert(next.end(), good2.begin(), good2.end());
+        threw2 = false;
+        try { used = rd2.loadEtiData(Buffer(next.size(), next.data())); } catch (const std::exception &) { threw2 = true; }
+        CHECK(!threw2 && used == static_cast<int>(next.size()));
+        CHECK(rd2.getSubchannels().size() == 1 && rd2.getSubchannels()[0]->framesize() == 48 * 8);
     }
     std::printf("host_selftest cpu: OK (%d checks)\n", g_checks);
     return 0;
