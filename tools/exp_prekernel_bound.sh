@@ -19,9 +19,8 @@ old = '''            lds_barrier();                    // bitbuf[bb] written (pr
             if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
             pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)'''
 new = '''            if (EQ) {
-                P = pf_prev & 0x333333u;          // EXPERIMENT: the phases arrive as one dword per lane and symbol
+                P = pf_prev;                      // EXPERIMENT: the phases arrive as one dword per lane and symbol
                 pf = reinterpret_cast<const uint32_t *>(fbits)[(size_t)(min(s, 74)) * (K / 16) + (t % (K / 16))];
-                pf_prev = pf;
             } else {
             lds_barrier();                    // bitbuf[bb] written (prologue / previous iteration)
             if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
@@ -30,7 +29,8 @@ new = '''            if (EQ) {
 assert old in s
 s = s.replace(old, new, 1)
 old = '''            bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;'''
-new = '''            if (!EQ) bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;'''
+new = '''            if (!EQ) bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;
+            else { pf_prev = pf & 0x333333u; asm volatile("" : "+v"(pf_prev)); }   // (the wait for the load lands HERE, before the stores)'''
 assert old in s
 s = s.replace(old, new, 1)
 old = '''    int bb = 0;                 // which bitbuf half holds the block of the current symbol'''
