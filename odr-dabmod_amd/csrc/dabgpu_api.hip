@@ -604,6 +604,15 @@ int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
     return (nsym + per_run - 1) / per_run;
 }
 
+// Symbols per run of a frame cut into `chunks` runs.  A run of a chain with FIRFilter or a windowed guard interval transforms
+// one symbol MORE than it stores (the look-ahead symbol its last boundary needs) -- except the frame's last run, which ends
+// with the frame.  So the last run takes one symbol more than the others where that evens them out: 77 symbols in four runs
+// are 19 + 1, 19 + 1, 19 + 1, 20 transforms, not 20 + 1, 20 + 1, 20 + 1, 17 (the kernel gives the last run whatever is left).
+int run_symbols(int nsym, int chunks, bool lookahead)
+{
+    return std::max(1, (nsym - (lookahead ? 1 : 0) + chunks - 1) / chunks);
+}
+
 bool is_pow2(size_t x) { return x && !(x & (x - 1)); }
 
 // ratios with a dedicated kernel (integer 2 and 4: packed dual transforms, fused predistorter)
@@ -772,7 +781,7 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         // dual transform)
         if (c->use_eq && tf_has_eq(a, flags)) flags |= TF_EQ;
         a.chunks_per_frame = auto_chunks(c, n_frames);
-        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.syms_per_chunk = run_symbols(c->g.nb_symbols + 1, a.chunks_per_frame, flags & TF_FIR);
         a.out = native_out;
         a.out_stride = native;
         if (tii_seg && tf_has_tii(a, flags)) {
@@ -786,7 +795,7 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         // itself (and filters across the seams)
         flags |= TF_GUARD | TF_WINDOW | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0);
         a.chunks_per_frame = auto_chunks(c, n_frames);
-        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.syms_per_chunk = run_symbols(c->g.nb_symbols + 1, a.chunks_per_frame, true);
         a.out = native_out;
         a.out_stride = native;
         HIPCHK(c, launch_tf(a, flags, s));
@@ -795,7 +804,7 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         const size_t nsymN = (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.N;
         HIPCHK(c, c->d_b.reserve(n_frames * nsymN * sizeof(float2)));
         a.chunks_per_frame = auto_chunks(c, n_frames);
-        a.syms_per_chunk = (c->g.nb_symbols + 1 + a.chunks_per_frame - 1) / a.chunks_per_frame;
+        a.syms_per_chunk = run_symbols(c->g.nb_symbols + 1, a.chunks_per_frame, false);
         a.out = (float2 *)c->d_b.p;
         a.out_stride = nsymN;
         HIPCHK(c, launch_tf(a, flags, s));
@@ -934,7 +943,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             ta.gain = gain_of(c);
             ta.ntaps = c->cur.cfr_enable ? (int)c->cur.taps.size() : fused_ntaps(c);
             ta.chunks_per_frame = auto_chunks(c, n_frames);
-            ta.syms_per_chunk = (c->g.nb_symbols + 1 + ta.chunks_per_frame - 1) / ta.chunks_per_frame;
+            ta.syms_per_chunk = run_symbols(c->g.nb_symbols + 1, ta.chunks_per_frame, mask & DABGPU_STAGE_FIR);
             unsigned tflags = TF_FROM_BITS | ((mask & DABGPU_STAGE_GAIN) ? TF_GAIN : 0) |
                               ((mask & DABGPU_STAGE_NOGUARD) ? 0 : TF_GUARD) | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0) |
                               (c->cur.cfr_enable ? TF_CFR : 0);

@@ -189,7 +189,8 @@ void tf_kernel(const TfArgs a)
     const int frame = blockIdx.x / a.chunks_per_frame;
     const int chunk = blockIdx.x - frame * a.chunks_per_frame;
     const int s_begin = chunk * a.syms_per_chunk;
-    const int s_end = min(nsym, s_begin + a.syms_per_chunk);
+    // (the frame's last run takes whatever is left: run_symbols, dabgpu_api.hip)
+    const int s_end = chunk == a.chunks_per_frame - 1 ? nsym : min(nsym, s_begin + a.syms_per_chunk);
     // TII (f-4) inside the kernel: everything after the IFFT is linear and the null symbol takes the multiplier of symbol 1,
     // so on a frame that carries TII the null symbol's segment is g_1 times a constant segment (a.tii_seg, computed once per
     // setting) instead of zeros: stored by the workgroup that owns symbols 0 and 1 when its run is over, its last C

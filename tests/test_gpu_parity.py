@@ -457,9 +457,10 @@ def test_chain_cfg2_ifft_guard(pkg, mode, chunks):
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
-@pytest.mark.parametrize("chunks", [1, 3, 11])
+@pytest.mark.parametrize("chunks", [1, 3, 4, 11])
 def test_chain_cfg3_gain_var_fir(pkg, mode, chunks):
-    """BASELINE config 3: full native-rate chain, gain var, default 45 taps, normalise 1/50000."""
+    """BASELINE config 3: full native-rate chain, gain var, default 45 taps, normalise 1/50000.  (4 runs per frame: the
+    uneven split -- 19 + look-ahead, 19 + 1, 19 + 1, 20 symbols in Mode I -- that a batch of 256 frames takes.)"""
     def setup(md):
         md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
     y, ref = _chain_case(pkg, mode, pkg.STAGE_GAIN | pkg.STAGE_FIR, chunks, 3,
