@@ -280,6 +280,10 @@ DABGPU_API int dabgpu_chain_collect(dabgpu_ctx *ctx, const void **iq, size_t *ou
  * makes the choice observable, so that a test can walk the whole matrix (tests/test_dispatch_matrix.py) and a user can see
  * what a configuration costs.  Diagnostic: not part of the reference's interface. */
 DABGPU_API int dabgpu_debug_last_variant(dabgpu_ctx *ctx, char *buf, size_t cap);
+/* The trace is OFF by default (a launch then costs one pointer test); dabgpu_debug_trace(ctx, 1) turns it on for the chain
+ * calls that follow.  Both calls belong to the thread that issues the chain calls (the trace is not guarded by the settings
+ * mutex). */
+DABGPU_API int dabgpu_debug_trace(dabgpu_ctx *ctx, int enable);
 
 /* wait for everything queued on the context's own stream */
 DABGPU_API int dabgpu_synchronize(dabgpu_ctx *ctx);

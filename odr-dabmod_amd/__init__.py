@@ -33,7 +33,7 @@ EXPORTS = [
     "dabgpu_cic_equalizer_process", "dabgpu_set_tii", "dabgpu_tii_process",
     "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
     "dabgpu_set_output_format", "dabgpu_get_num_clipped", "dabgpu_fir_inverse_design",
-    "dabgpu_set_fir_boundary_mode", "dabgpu_debug_last_variant",
+    "dabgpu_set_fir_boundary_mode", "dabgpu_debug_last_variant", "dabgpu_debug_trace",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -113,6 +113,7 @@ def load_library():
     lib.dabgpu_set_window_overlap.argtypes = [vp, sz]
     lib.dabgpu_set_fir_boundary_mode.argtypes = [vp, C.c_int]
     lib.dabgpu_debug_last_variant.argtypes = [vp, C.c_char_p, sz]
+    lib.dabgpu_debug_trace.argtypes = [vp, C.c_int]
     lib.dabgpu_set_resampler.argtypes = [vp, sz, sz]
     lib.dabgpu_set_poly.argtypes = [vp, C.POINTER(C.c_float), C.POINTER(C.c_float)]
     lib.dabgpu_set_lut.argtypes = [vp, C.c_float, C.POINTER(C.c_float)]
@@ -361,6 +362,10 @@ class Modulator:
         """False (default): boundary outputs of the fused FIRFilter through the taps' inverse where one exists;
         True: always the direct sum over the unfiltered samples (packed dual transform)."""
         self._chk(self._lib.dabgpu_set_fir_boundary_mode(self._h, 1 if direct else 0))
+
+    def trace(self, enable=True):
+        """Turn the launch trace behind last_variant() on or off (off by default)."""
+        self._chk(self._lib.dabgpu_debug_trace(self._h, 1 if enable else 0))
 
     def last_variant(self):
         """The kernels the most recent chain call launched (dabgpu_debug_last_variant), as a list of names."""

@@ -129,7 +129,12 @@ namespace {
 // names the kernels of one chain call into ctx->last_variant
 struct TraceScope {
     std::string *prev;
-    explicit TraceScope(std::string *sink) : prev(g_trace_sink_ref()) { sink->clear(); g_trace_sink_ref() = sink; }
+    // (sink == nullptr: tracing is off for this context -- nothing is installed, a launch costs one pointer test)
+    explicit TraceScope(std::string *sink) : prev(g_trace_sink_ref())
+    {
+        if (sink) sink->clear();
+        g_trace_sink_ref() = sink;
+    }
     ~TraceScope() { g_trace_sink_ref() = prev; }
     static std::string *&g_trace_sink_ref() { return dabgpu::g_trace_sink; }
 };
@@ -137,6 +142,7 @@ struct TraceScope {
 
 struct dabgpu_ctx {
     std::string last_variant;             // dabgpu_debug_last_variant: the kernels the most recent chain call launched
+    bool trace_enabled = false;           // dabgpu_debug_trace: off by default (names are formatted per launch when on)
     Geometry g{};
     int device = 0;
     int max_frames = 1;
@@ -1267,6 +1273,14 @@ int dabgpu_set_resampler(dabgpu_ctx *c, size_t in_rate, size_t out_rate)
     return DABGPU_OK;
 }
 
+int dabgpu_debug_trace(dabgpu_ctx *c, int enable)
+{
+    if (!c) return DABGPU_E_INVALID;
+    c->trace_enabled = enable != 0;
+    if (!enable) c->last_variant.clear();
+    return DABGPU_OK;
+}
+
 int dabgpu_debug_last_variant(dabgpu_ctx *c, char *buf, size_t cap)
 {
     if (!c || !buf || cap == 0) return DABGPU_E_INVALID;
@@ -1696,7 +1710,7 @@ int dabgpu_chain_process_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames,
     CTXCHK(c);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     c->clip_from_collect = false;
-    TraceScope trace(&c->last_variant);
+    TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
     return run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
 }
 
@@ -1706,7 +1720,7 @@ int dabgpu_symbols_process_dev(dabgpu_ctx *c, const void *d_car, size_t n_frames
     CTXCHK(c);
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
     c->clip_from_collect = false;
-    TraceScope trace(&c->last_variant);
+    TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
     return run_chain(c, d_car, false, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
 }
 
@@ -1729,7 +1743,7 @@ int dabgpu_chain_process(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, un
     HIPCHK(c, c->d_out.reserve(std::max<size_t>(need, 16)));
     size_t ob = 0;
     {
-        TraceScope trace(&c->last_variant);
+        TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
         rc = run_chain(c, c->d_in.p, true, n_frames, mask, (float2 *)c->d_out.p, need, &ob, c->stream);
     }
     if (rc) return rc;
@@ -1777,7 +1791,7 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     if (in_bytes) HIPCHK(c, hipMemcpyAsync(sl.d_in.p, sl.h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
     size_t ob = 0;
     {
-        TraceScope trace(&c->last_variant);
+        TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
         rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, c->stream);
     }
     if (rc) return rc;

@@ -128,6 +128,8 @@ _rows = []
 @pytest.fixture(scope="module")
 def mods(pkg):
     m = {mode: pkg.Modulator(mode=mode, max_frames=2, chunks_per_frame=1) for mode in (1, 2, 3, 4)}
+    for md in m.values():
+        md.trace(True)
     yield m
     for md in m.values():
         md.close()
