@@ -1181,7 +1181,7 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 #define TF_LAUNCH_GVAR(GD, FR)                                                                 \
     tf_go<LOGN, false, true, GD, FR, (FR ? NT : 0), false, true>(grid, block, lds, s, a)
     if (gvar) {
-        if (LOGN == 11 && NT == 45 && fr && gd) {
+        if constexpr (LOGN == 11 && NT == 45) if (fr && gd) {
             tf_go<11, false, true, true, true, 45, false, true, true>(grid, block, lds, s, a);
             return hipGetLastError();
         }
@@ -1200,11 +1200,11 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         }
         return hipGetLastError();
     }
-    if (LOGN == 11 && NT == 45 && !fb && !gn && fr && gd) {
+    if constexpr (LOGN == 11 && NT == 45) if (!fb && !gn && fr && gd) {
         tf_go<11, false, false, true, true, 45, false, false, true>(grid, block, lds, s, a);
         return hipGetLastError();
     }
-    if (LOGN == 11 && NT == 45 && fb && fr && gd && (!gn || a.gain.mode != 1)) {
+    if constexpr (LOGN == 11 && NT == 45) if (fb && fr && gd && (!gn || a.gain.mode != 1)) {
         if (flags & TF_EQ) {
             // ... or the one that runs the filtered transform alone and equalises the boundary (needs the taps' inverse)
             if (!a.t.eq_g || ((flags & TF_OUT_S16) && !a.clipped)) return hipErrorInvalidValue;
