@@ -535,7 +535,12 @@ def main():
     # unit is saturated and the limiter is instruction ISSUE -- a SIMD retires one instruction at a time, VALU or LDS, so
     # their times add (the sum of the per-instruction issue costs of the hot loop, profiles/isa_mix.json,
     # reproduces the measured time per symbol) -- reported with the share of their life the waves spend stalled at issue.
-    def limiter_of(b):
+    def limiter_of(b, pw=None):
+        if pw and pw.get("watts_cap") and pw.get("watts_avg", 0.0) >= 0.95 * pw["watts_cap"]:
+            # measured by this run: the board sits at its power limit, the clock is what the limit leaves
+            return ("board power: %.0f W of the %.0f W limit, shader clock %.2f of 2.40 GHz (%.3g mJ per frame); inside that "
+                    "budget -- %s" % (pw["watts_avg"], pw["watts_cap"], pw.get("sclk_MHz_avg", 0.0) / 1e3,
+                                      1e3 * pw.get("joules_per_frame", 0.0), limiter_of(b)))
         if not b:
             return "not profiled for this build"
         units = {"valu": b.get("valu_busy", 0.0), "lds": b.get("lds_busy", 0.0), "hbm": b.get("hbm_frac", 0.0)}
@@ -618,7 +623,7 @@ def main():
                      "valu_frac_of_peak": round(EXEC_FLOPS[args.workload] * value / world / 1e12 / VALU_PEAK_TFLOPS, 4)
                      if args.workload in EXEC_FLOPS else None,
                      "power": power_of.get((args.workload, None, None, B)),
-                     "limiter": limiter_of(busy), "issue_model": issue,
+                     "limiter": limiter_of(busy, power_of.get((args.workload, None, None, B))), "issue_model": issue,
                      "counters_source": replay},
     }
     if rank == 0 and world == 1 and not args.no_extra:
@@ -671,7 +676,7 @@ def main():
                                 extra[wl].update({k4: t4[k4] for k4 in KEEP if k4 in t4})
                                 extra[wl]["traffic"] = t4.get("hbm_bytes_per_launch")
                                 extra[wl]["effective_clock_GHz"] = t4.get("effective_clock_GHz_profiled")
-                                extra[wl]["limiter"] = limiter_of({k4: t4[k4] for k4 in KEEP if k4 in t4})
+                                extra[wl]["limiter"] = limiter_of({k4: t4[k4] for k4 in KEEP if k4 in t4}, pw2)
                                 extra[wl]["counters_source"] = "collected in this run: rocprofv3 --pmc, 3 passes of tools/prof_run.py cfg4 %d" % b2
                             else:
                                 extra[wl]["counters_source"] = "live collection failed (%s)" % why4
