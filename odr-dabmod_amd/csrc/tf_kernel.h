@@ -258,12 +258,21 @@ void tf_kernel(const TfArgs a)
         reinterpret_cast<char *>(a.out) + (size_t)frame * a.out_stride * kOutBytes, 0, (int)(a.out_stride * kOutBytes), 0x00020000);
     unsigned nclip = 0;
     typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
+    // NON-TEMPORAL output stores on the coded-bits chain (round 4; aux bit 1 = nt).  In a pure bandwidth test a non-temporal
+    // store is the SLOWER one (-10 %), but these kernels do not run at a bandwidth limit: they run at the
+    // board's 1400 W power limit, where the stores are a third of a frame's energy (tools/microbench/energy_cost.hip) and the
+    // cheaper path wins -- cfg 3 +2.5 ... 3.8 %, 16 frames per launch +10 %, 256 +4 %, cfg 4 +0.5 %, the default chain, CFR and
+    // windowing unchanged (tools/exp_store_policy.sh, exp_store_policy2.sh; same-box A/B).  (16-byte stores, which the same
+    // microbenchmark prices a third cheaper per byte, were tried too: neighbouring lanes swap half of their samples by DPP and
+    // store pairs -- parity green, -2 % with either policy: the 40 instructions of the swap and two 512-byte halves per store.)  The chains from carriers (cfg 2, the
+    // IFFT + FIR stage) ARE bandwidth-bound, at the nominal clock with power to spare, and lose 0 ... 1.5 %: they keep plain stores.
+    constexpr int kStoreAux = FROM_BITS ? 2 : 0;
     auto put = [&](int soff, int voff, cf y) __attribute__((always_inline)) {
         if (OFMT == 1) {
-            __builtin_amdgcn_raw_buffer_store_b32(s16_pack(y, nclip), orsrc, voff * 4, soff * 4, 0);
+            __builtin_amdgcn_raw_buffer_store_b32(s16_pack(y, nclip), orsrc, voff * 4, soff * 4, kStoreAux);
         } else {
             const v2u_ d = {__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.y)};
-            __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, voff * 8, soff * 8, 0);
+            __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, voff * 8, soff * 8, kStoreAux);
         }
     };
 

@@ -19,10 +19,13 @@
 
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); exit(1); } } while (0)
 
-enum Kind { K_NOP, K_FMA, K_PKFMA, K_ADD_DPP, K_DSR64, K_DSW64, K_DSR32, K_DSR128, K_DSW128, K_GSTORE8, K_GLOAD8_L2, K_COUNT };
+enum Kind { K_NOP, K_FMA, K_PKFMA, K_ADD_DPP, K_DSR64, K_DSW64, K_DSR32, K_DSR128, K_DSW128, K_GSTORE8, K_GLOAD8_L2, K_GSTORE8_NT, K_GSTORE16, K_GSTORE16_NT, K_GSTORE16_PAIR32, K_COUNT };
 static const char *kNames[K_COUNT] = {"s_nop 0 (baseline: waves resident, clocks running)", "v_fma_f32", "v_pk_fma_f32", "v_add_f32 row_ror dpp",
                                       "ds_read_b64", "ds_write_b64", "ds_read_b32", "ds_read_b128", "ds_write_b128",
-                                      "global_store_dwordx2 (streaming to HBM)", "global_load_dwordx2 (L2-resident 8 MB)"};
+                                      "global_store_dwordx2 (streaming to HBM)", "global_load_dwordx2 (L2-resident 8 MB)",
+                                      "global_store_dwordx2 nt (streaming to HBM)", "global_store_dwordx4 (streaming to HBM)",
+                                      "global_store_dwordx4 nt (streaming to HBM)",
+                                      "2 x global_store_dwordx4, 32 B per lane (the resampler's pattern)"};
 
 typedef float v2f __attribute__((ext_vector_type(2)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -99,6 +102,36 @@ template <int KIND> __global__ __launch_bounds__(256) void k(long iters, float *
                 gi += gstride;
                 if (gi >= gelems) gi -= gelems;
             }
+        } else if (KIND == K_GSTORE8_NT) {
+            typedef float v2f_ __attribute__((ext_vector_type(2)));
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                __builtin_nontemporal_store((v2f_){a0, a1}, reinterpret_cast<v2f_ *>(gbuf + gi));
+                gi += gstride;
+                if (gi >= gelems) gi -= gelems;
+            }
+        } else if (KIND == K_GSTORE16 || KIND == K_GSTORE16_NT) {
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            v4f_ *g4 = reinterpret_cast<v4f_ *>(gbuf);
+            size_t g = gi % (gelems >> 1);                       // 16-byte elements, one per lane
+#pragma unroll
+            for (int u = 0; u < 32; ++u) {
+                if (KIND == K_GSTORE16_NT) __builtin_nontemporal_store((v4f_){a0, a1, a2, a3}, g4 + g);
+                else g4[g] = (v4f_){a0, a1, a2, a3};
+                g += gstride;
+                if (g >= (gelems >> 1)) g -= (gelems >> 1);
+            }
+        } else if (KIND == K_GSTORE16_PAIR32) {
+            typedef float v4f_ __attribute__((ext_vector_type(4)));
+            v4f_ *g4 = reinterpret_cast<v4f_ *>(gbuf);
+            size_t g = (2 * gi) % (gelems >> 1);                 // 16-byte elements, two per lane, side by side
+#pragma unroll
+            for (int u = 0; u < 16; ++u) {
+                g4[g] = (v4f_){a0, a1, a2, a3};
+                g4[g + 1] = (v4f_){a4, a5, a6, a7};
+                g += 2 * gstride;
+                if (g >= (gelems >> 1)) g -= (gelems >> 1);
+            }
         } else if (KIND == K_GLOAD8_L2) {
 #pragma unroll
             for (int u = 0; u < 32; ++u) {
@@ -136,7 +169,7 @@ int main(int argc, char **argv)
     CK(hipMemset(gbuf, 0, ge * sizeof(float2)));
     hipStream_t s; CK(hipStreamCreate(&s));
     const Fn fns[K_COUNT] = {launch<K_NOP>, launch<K_FMA>, launch<K_PKFMA>, launch<K_ADD_DPP>, launch<K_DSR64>, launch<K_DSW64>, launch<K_DSR32>,
-                             launch<K_DSR128>, launch<K_DSW128>, launch<K_GSTORE8>, launch<K_GLOAD8_L2>};
+                             launch<K_DSR128>, launch<K_DSW128>, launch<K_GSTORE8>, launch<K_GLOAD8_L2>, launch<K_GSTORE8_NT>, launch<K_GSTORE16>, launch<K_GSTORE16_NT>, launch<K_GSTORE16_PAIR32>};
     const auto mons = hwmons();
     std::vector<double> idle;
     for (auto &m : mons) idle.push_back(rd(m + "/power1_input"));
