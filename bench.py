@@ -682,6 +682,44 @@ def main():
                                 extra[wl]["counters_source"] = "live collection failed (%s)" % why4
                 except Exception as ex:  # secondary numbers must never break the contract line
                     extra[wl] = {"error": str(ex)[:200]}
+            # Small batches with TWO streams of frames in flight (two contexts, two HIP streams, launches alternating): what a
+            # caller that keeps two batches in flight gets -- the shape of dabgpu_chain_submit / _collect -- next to the
+            # single-stream figures above, whose launches wait for one another (3.6 ... 4 us of every small launch is the gap
+            # between two kernels of ONE stream).  Each context has its own input and output buffers.
+            if args.workload == "cfg3":
+                for b2 in (16, 256):
+                    try:
+                        mds, bufs, sts = [], [], []
+                        for i in range(2):
+                            md2 = P.Modulator(mode=1, device=local_rank, max_frames=b2, chunks_per_frame=args.chunks)
+                            md2.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+                            st2 = torch.cuda.Stream(device=dev)
+                            with torch.cuda.stream(st2):
+                                bi = torch.randint(0, 256, (b2, 28800), dtype=torch.uint8, device=dev)
+                                bo = torch.empty((b2, 196608), dtype=torch.complex64, device=dev)
+                            mds.append(md2); bufs.append((bi, bo)); sts.append(st2)
+                        stg = P.STAGE_GAIN | P.STAGE_FIR
+                        nrep = 100
+                        for r in range(10):
+                            for i in range(2):
+                                mds[i].chain_dev(bufs[i][0], b2, stg, bufs[i][1], stream=sts[i].cuda_stream)
+                        torch.cuda.synchronize()
+                        t0 = time.perf_counter()
+                        for r in range(nrep):
+                            for i in range(2):
+                                mds[i].chain_dev(bufs[i][0], b2, stg, bufs[i][1], stream=sts[i].cuda_stream)
+                        torch.cuda.synchronize()
+                        dt = time.perf_counter() - t0
+                        fps = 2 * nrep * b2 / dt
+                        gb = ALGO_BYTES["cfg3"] * fps / 1e9
+                        extra["cfg3_B%d_two_streams" % b2] = {"frames_per_s": round(fps, 2), "frames_per_step": b2, "streams": 2,
+                                                              "achieved_GBps": round(gb, 2), "roofline_frac": round(gb / HBM_PEAK_GBPS, 4),
+                                                              "timing": "host clock around %d launches per stream" % nrep}
+                        for md2 in mds:
+                            md2.close()
+                        del bufs
+                    except Exception as ex:
+                        extra["cfg3_B%d_two_streams" % b2] = {"error": str(ex)[:200]}
             line["other_workloads"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)
