@@ -32,6 +32,7 @@ sys.path.insert(0, ROOT)
 
 PREWARM = 3            # untimed steps run before the W warm-up steps of the contract
 HBM_PEAK_GBPS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured copy)
+SMALL_BATCH_LANES = 3   # the library's default (dabgpu_set_lanes): batches in flight inside one context, B = 1 / 16 / 256
 
 # ALGORITHMIC (compulsory) bytes per transmission frame, SURVEY 8(d) / BASELINE.md section 3
 ALGO_BYTES = {
@@ -51,52 +52,8 @@ _CFG3_FLOPS = 77 * 5 * 2048 * 11 + 77 * 1536 * 6 + 77 * (7040 + 990) * 4
 EXEC_FLOPS = {"cfg3": _CFG3_FLOPS, "cfg4": _CFG3_FLOPS + 96 * (4 * 5 * 4096 * 12 + 8192 * 40)}
 
 
-class PowerProbe:
-    """Board power (hwmon power1_input, uW: the socket's PPT) and shader clock (freq1_input, Hz) of the card under load,
-    sampled from sysfs by the host thread while the device works through queued launches.  The leased GPU is HIP device 0 but
-    one of several cards in /sys/class/drm: it is the card whose power RISES between the idle reading and the loaded ones."""
-
-    def __init__(self):
-        import glob
-        self.cards = []
-        for d in sorted(glob.glob("/sys/class/drm/card*/device/hwmon/hwmon*")):
-            if os.path.exists(os.path.join(d, "power1_input")):
-                self.cards.append(d)
-        self.idle = self._read_all("power1_input")
-
-    def _read_all(self, name):
-        out = []
-        for d in self.cards:
-            try:
-                out.append(float(open(os.path.join(d, name)).read().strip()))
-            except (OSError, ValueError):
-                out.append(float("nan"))
-        return out
-
-    def measure(self, busy, interval=0.02):
-        """busy() -> bool: is the device still working?  Samples until it is not."""
-        pw, fq = [], []
-        while busy():
-            pw.append(self._read_all("power1_input"))
-            fq.append(self._read_all("freq1_input"))
-            time.sleep(interval)
-        if len(pw) < 8 or not self.cards:
-            return None
-        import numpy as np
-        p, f = np.array(pw), np.array(fq)
-        steady = p[(3 * len(p)) // 5:]                         # (the sensor is a running average about a second long: the
-                                                               #  last two fifths of a three-second load are the settled part)
-        rise = np.nanmean(steady, axis=0) - np.array(self.idle)
-        c = int(np.nanargmax(rise))
-        cap = None
-        try:
-            cap = float(open(os.path.join(self.cards[c], "power1_cap")).read()) / 1e6
-        except (OSError, ValueError):
-            pass
-        return {"watts_avg": round(float(np.nanmean(steady[:, c])) / 1e6, 1), "watts_max": round(float(np.nanmax(p[:, c])) / 1e6, 1),
-                "watts_before": round(self.idle[c] / 1e6, 1), "watts_cap": cap,
-                "sclk_MHz_avg": round(float(np.nanmean(f[(3 * len(f)) // 5:, c])) / 1e6, 0), "samples": int(len(p)),
-                "source": "hwmon power1_input (PPT) / freq1_input, %d ms apart" % int(interval * 1e3)}
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+from power_probe import PowerProbe  # noqa: E402  (board power / shader clock of the HIP device's own card, by PCI address)
 
 
 def pkg():
@@ -334,8 +291,14 @@ def main():
 
     power_of = {}
 
-    def run_workload(workload, B, steps, warmup, fmt=None, option=None, power_seconds=0.0):
+    def run_workload(workload, B, steps, warmup, fmt=None, option=None, power_seconds=0.0, lanes=0):
+        """lanes > 0: the calls go to the context's OWN stream (dabgpu_chain_process_dev with stream NULL) and rotate over
+        that many internal lanes -- batches in flight inside ONE context, include/dabgpu.h -- ordered against the timing
+        stream by the two fences, so that the HIP events on it bracket all of them.  lanes = 0: every call on the timing
+        stream itself, one after the other."""
         md = P.Modulator(mode=1, device=local_rank, max_frames=B, chunks_per_frame=args.chunks)
+        if lanes:
+            md.set_lanes(lanes)
         # rows f-3 / f-4 on the cfg 3 chain, with the values doc/example.ini of the reference suggests
         if option == "cfr":
             md.set_cfr(True, 50.0, 0.1)
@@ -378,13 +341,16 @@ def main():
             h = stream.cuda_stream
 
             def step():
-                if from_bits:
+                if lanes:
+                    md.chain_dev_queued(d_in, B, stages, d_out, from_bits=from_bits)
+                elif from_bits:
                     md.chain_dev(d_in, B, stages, d_out, stream=h)
                 else:
                     md.symbols_dev(d_in, B, stages, d_out, stream=h)
 
             for _ in range(warmup + PREWARM):     # W warm-up steps as asked, after a fixed pre-warm (clock ramp-up,
                 step()                            # first-touch of the output pages); none of them is timed
+            md.synchronize()
             stream.synchronize()
             e0 = torch.cuda.Event(enable_timing=True)
             e1 = torch.cuda.Event(enable_timing=True)
@@ -392,8 +358,12 @@ def main():
             def timed_steps():
                 # HIP events on the stream the kernels are launched on: per-launch kernel time
                 e0.record(stream)
+                if lanes:
+                    md.wait_for_stream(h)         # the lanes start after e0 ...
                 for _ in range(steps):
                     step()
+                if lanes:
+                    md.stream_wait_for(h)         # ... and e1 after every lane
                 e1.record(stream)
 
             # barrier + synchronize | K steps | synchronize + barrier, MAX over ranks
@@ -404,7 +374,7 @@ def main():
                 # board's power and clock while the device works through them (verdict round 3: "the part is power-limited:
                 # report W and J / frame beside the clock")
                 try:
-                    probe = PowerProbe()
+                    probe = PowerProbe(device_index)
                     n = max(8, int(power_seconds / (ev_ms / steps * 1e-3)))
                     done = torch.cuda.Event()
                     for _ in range(n):
@@ -412,7 +382,9 @@ def main():
                     done.record(stream)
                     pw = probe.measure(lambda: not done.query())
                     stream.synchronize()
-                    if pw:
+                    if pw and "error" in pw:
+                        power_of[(workload, option, fmt, B)] = pw
+                    elif pw:
                         fps = B / (ev_ms / steps * 1e-3)
                         pw["joules_per_frame"] = round(pw["watts_avg"] / fps, 6)
                         pw["launches_sampled"] = n
@@ -641,6 +613,8 @@ def main():
             # (batch B in {1, 16, 256} next to the best; "_s16": FormatConverter fused into the last store)
             for wl, b2 in (("cfg2", bs), ("ifft_fir_stage", bs), ("cfg4", max(64, bs // 4)),
                            (args.workload + "_B1", 1), (args.workload + "_B16", 16), (args.workload + "_B256", 256),
+                           (args.workload + "_B1_one_lane", 1), (args.workload + "_B16_one_lane", 16),
+                           (args.workload + "_B256_one_lane", 256),
                            ("cfg3_s16", B), ("cfg4_s16", max(64, bs // 4)),
                            ("cfg3_cfr", max(64, bs // 2)), ("cfg3_window", max(64, bs // 2)), ("cfg3_nofir", B)):
                 if wl == args.workload:
@@ -648,14 +622,22 @@ def main():
                 try:
                     base = wl.split("_B")[0].replace("_s16", "").replace("_cfr", "").replace("_window", "").replace("_nofir", "")
                     option = wl.rsplit("_", 1)[1] if wl.endswith(("_cfr", "_window", "_nofir")) else None
-                    k = max(3, args.steps // 4) if b2 > 256 else (200 if b2 == 1 else 50)
+                    k = max(3, args.steps // 4) if b2 > 256 else (400 if b2 <= 16 else 100)
+                    # B = 1 / 16 / 256: ONE context, its own stream, the library's lanes (SMALL_BATCH_LANES); "_one_lane":
+                    # the same calls in order on one stream (what rounds 1-4 reported under these names)
+                    small = "_B" in wl
+                    nl = 0 if not small else (1 if wl.endswith("_one_lane") else SMALL_BATCH_LANES)
                     w2, k2 = run_workload(base, b2, k, 1, fmt="s16" if wl.endswith("_s16") else None, option=option,
-                                          power_seconds=3.0 if wl in ("cfg4", "cfg2", "cfg3_nofir") else 0.0)
+                                          power_seconds=3.0 if wl in ("cfg4", "cfg2", "cfg3_nofir") else 0.0, lanes=nl)
                     algo2 = ALGO_BYTES[base] if not wl.endswith("_s16") else \
                         28800 + (ALGO_BYTES[base] - 28800) // 2                 # 4 bytes per sample written
                     gbps = algo2 * b2 / (k2 * 1e-3) / 1e9
                     extra[wl] = {"frames_per_s": round(b2 * k / w2, 2), "frames_per_step": b2,
                                  "achieved_GBps": round(gbps, 2), "roofline_frac": round(gbps / HBM_PEAK_GBPS, 4)}
+                    if small:
+                        extra[wl].update({"contexts": 1, "lanes": nl, "us_per_call": round(k2 * 1e3, 2),
+                                          "timing": "HIP events on the caller's stream around %d calls on the context's own "
+                                                    "stream, ordered by dabgpu_wait_for_stream / dabgpu_stream_wait_for" % k})
                     pw2 = power_of.get((base, option, "s16" if wl.endswith("_s16") else None, b2)) \
                         if wl in ("cfg4", "cfg2", "cfg3_nofir") else None
                     if pw2:
@@ -682,44 +664,6 @@ def main():
                                 extra[wl]["counters_source"] = "live collection failed (%s)" % why4
                 except Exception as ex:  # secondary numbers must never break the contract line
                     extra[wl] = {"error": str(ex)[:200]}
-            # Small batches with TWO streams of frames in flight (two contexts, two HIP streams, launches alternating): what a
-            # caller that keeps two batches in flight gets -- the shape of dabgpu_chain_submit / _collect -- next to the
-            # single-stream figures above, whose launches wait for one another (3.6 ... 4 us of every small launch is the gap
-            # between two kernels of ONE stream).  Each context has its own input and output buffers.
-            if args.workload == "cfg3":
-                for b2 in (16, 256):
-                    try:
-                        mds, bufs, sts = [], [], []
-                        for i in range(2):
-                            md2 = P.Modulator(mode=1, device=local_rank, max_frames=b2, chunks_per_frame=args.chunks)
-                            md2.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
-                            st2 = torch.cuda.Stream(device=dev)
-                            with torch.cuda.stream(st2):
-                                bi = torch.randint(0, 256, (b2, 28800), dtype=torch.uint8, device=dev)
-                                bo = torch.empty((b2, 196608), dtype=torch.complex64, device=dev)
-                            mds.append(md2); bufs.append((bi, bo)); sts.append(st2)
-                        stg = P.STAGE_GAIN | P.STAGE_FIR
-                        nrep = 100
-                        for r in range(10):
-                            for i in range(2):
-                                mds[i].chain_dev(bufs[i][0], b2, stg, bufs[i][1], stream=sts[i].cuda_stream)
-                        torch.cuda.synchronize()
-                        t0 = time.perf_counter()
-                        for r in range(nrep):
-                            for i in range(2):
-                                mds[i].chain_dev(bufs[i][0], b2, stg, bufs[i][1], stream=sts[i].cuda_stream)
-                        torch.cuda.synchronize()
-                        dt = time.perf_counter() - t0
-                        fps = 2 * nrep * b2 / dt
-                        gb = ALGO_BYTES["cfg3"] * fps / 1e9
-                        extra["cfg3_B%d_two_streams" % b2] = {"frames_per_s": round(fps, 2), "frames_per_step": b2, "streams": 2,
-                                                              "achieved_GBps": round(gb, 2), "roofline_frac": round(gb / HBM_PEAK_GBPS, 4),
-                                                              "timing": "host clock around %d launches per stream" % nrep}
-                        for md2 in mds:
-                            md2.close()
-                        del bufs
-                    except Exception as ex:
-                        extra["cfg3_B%d_two_streams" % b2] = {"error": str(ex)[:200]}
             line["other_workloads"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)

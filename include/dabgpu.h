@@ -262,6 +262,40 @@ DABGPU_API int dabgpu_symbols_process_dev(dabgpu_ctx *ctx, const void *d_carrier
                                           size_t n_frames, unsigned stage_mask, void *d_iq,
                                           size_t out_cap, size_t *out_bytes, void *stream);
 
+/* Resampler::process -> MemlessPoly::internal_process (cifRes -> cifPoly, src/DabModulator.cpp:403-406) on a native-rate
+ * stream that is already in device memory: the tail of the chain by itself.  stage_mask = DABGPU_STAGE_RESAMPLE and / or
+ * DABGPU_STAGE_POLY; n_samples complex samples in (a whole number of resampler hops), n_samples * L / M out.  Stateful like
+ * the Resampler (the context's halo), asynchronous on `stream`. */
+DABGPU_API int dabgpu_post_process_dev(dabgpu_ctx *ctx, const void *d_native, size_t n_samples, unsigned stage_mask,
+                                       void *d_iq, size_t out_cap, size_t *out_bytes, void *stream);
+
+/* ---- batches in flight inside one context --------------------------------- *
+ * The reference overlaps its stages by handing frame i + 1 to a stage while frame i is still inside it
+ * (PipelinedModCodec, src/ModPlugin.cpp:90-154).  The counterpart here: a chain call on the context's OWN stream
+ * (dabgpu_chain_process_dev / dabgpu_symbols_process_dev with stream == NULL, and the two batches of dabgpu_chain_submit)
+ * goes to one of `lanes` internal HIP streams in turn, each with its own scratch, so that the kernels of consecutive
+ * calls overlap where one launch alone cannot fill the chip (frames are independent units).  Consequences for the caller:
+ *   - outputs of calls on the context's own stream are complete after dabgpu_synchronize (all lanes), or, in stream
+ *     order, for work queued on `stream` after dabgpu_stream_wait_for(ctx, stream);
+ *   - inputs produced on a stream of the caller's are ordered in front with dabgpu_wait_for_stream(ctx, stream);
+ *   - calls that carry stream state (DABGPU_STAGE_RESAMPLE at a ratio other than 1) and batches of more than 2048 frames
+ *     stay on lane 0, in call order;
+ *   - a call with an explicit stream argument is what it always was: asynchronous on that stream, the context's scratch.
+ *     Do not mix the two on one context without a dabgpu_synchronize in between.
+ * dabgpu_set_lanes: 1 ... 4 (default 3: measured best at 1 ... 64 frames per call, tools/exp_r05.py lanes; 1 = every call on the one context stream, in order).  Waits for the context. */
+DABGPU_API int dabgpu_set_lanes(dabgpu_ctx *ctx, int lanes);
+/* everything the context queues from now on starts after what `stream` holds now */
+DABGPU_API int dabgpu_wait_for_stream(dabgpu_ctx *ctx, void *stream);
+/* everything queued on `stream` from now on starts after what the context has queued so far, on every lane */
+DABGPU_API int dabgpu_stream_wait_for(dabgpu_ctx *ctx, void *stream);
+
+/* The hand-over of the native-rate stream from FIRFilter to Resampler (src/DabModulator.cpp:403-406) inside the fused
+ * chain: in pieces of `frames` transmission frames through a two-piece ring (2 x frames x 1.57 MB: sized to stay in
+ * the 256 MiB last-level cache), the producer of piece i + 1 on a second internal stream while the x2 / x4 resampler works on
+ * piece i.  0 = one piece: the whole batch goes through memory between the two kernels.  `frames` is even (TII frame
+ * parity).  Same samples either way (the resampler's state runs through the pieces).  Waits for the context. */
+DABGPU_API int dabgpu_set_handover_frames(dabgpu_ctx *ctx, int frames);
+
 /* Asynchronous host path: the streaming shape of dabgpu_chain_process.  submit() stages the coded
  * bits in pinned memory and queues upload, kernels and -- on a second HIP stream -- the copy back
  * into a pinned buffer owned by the context; up to TWO batches may be in flight, so the copy of
@@ -285,7 +319,7 @@ DABGPU_API int dabgpu_debug_last_variant(dabgpu_ctx *ctx, char *buf, size_t cap)
  * mutex). */
 DABGPU_API int dabgpu_debug_trace(dabgpu_ctx *ctx, int enable);
 
-/* wait for everything queued on the context's own stream */
+/* wait for everything queued on the context's own stream(s): every lane */
 DABGPU_API int dabgpu_synchronize(dabgpu_ctx *ctx);
 
 #ifdef __cplusplus

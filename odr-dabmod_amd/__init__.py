@@ -34,6 +34,8 @@ EXPORTS = [
     "dabgpu_format_size", "dabgpu_format_process", "dabgpu_format_process_dev",
     "dabgpu_set_output_format", "dabgpu_get_num_clipped", "dabgpu_fir_inverse_design",
     "dabgpu_set_fir_boundary_mode", "dabgpu_debug_last_variant", "dabgpu_debug_trace",
+    "dabgpu_set_lanes", "dabgpu_wait_for_stream", "dabgpu_stream_wait_for", "dabgpu_set_handover_frames",
+    "dabgpu_post_process_dev",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -142,6 +144,11 @@ def load_library():
     lib.dabgpu_format_process_dev.argtypes = [vp, vp, sz, C.c_int, vp, sz, szp, vp, vp]
     lib.dabgpu_set_output_format.argtypes = [vp, C.c_int]
     lib.dabgpu_get_num_clipped.argtypes = [vp, szp]
+    lib.dabgpu_set_lanes.argtypes = [vp, C.c_int]
+    lib.dabgpu_set_handover_frames.argtypes = [vp, C.c_int]
+    lib.dabgpu_wait_for_stream.argtypes = [vp, vp]
+    lib.dabgpu_stream_wait_for.argtypes = [vp, vp]
+    lib.dabgpu_post_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
     lib.dabgpu_fir_inverse_design.argtypes = [C.POINTER(C.c_float), sz, C.POINTER(C.c_float), C.POINTER(C.c_double)]
     _lib = lib
     return lib
@@ -408,9 +415,12 @@ class Modulator:
         per_out = self.out_bytes_per_frame(stages) // dt.itemsize
         if out is None:
             out = np.empty(n * per_out, dt)
-        out = out.reshape(-1)
-        if out.dtype != dt or out.size != n * per_out or not out.flags.c_contiguous:
-            raise DabGpuError("chain: output buffer does not match")
+        # (checked BEFORE any reshape: reshaping a non-contiguous array makes a copy, and the caller's buffer would stay empty)
+        if not isinstance(out, np.ndarray) or out.dtype != dt or out.size != n * per_out or not out.flags.c_contiguous:
+            raise DabGpuError("chain: output buffer does not match (dtype %s, %d elements, C-contiguous)" % (dt, n * per_out))
+        flat = out.reshape(-1)
+        assert np.shares_memory(flat, out)
+        out = flat
         ob = C.c_size_t()
         self._chk(self._lib.dabgpu_chain_process(self._h, bits.ctypes.data, n, stages,
                                                  out.ctypes.data, out.nbytes, C.byref(ob)))
@@ -467,4 +477,41 @@ class Modulator:
         return ob.value
 
     def synchronize(self):
+        """Wait for everything the context has queued, on every lane."""
         self._chk(self._lib.dabgpu_synchronize(self._h))
+
+    # ---- batches in flight inside the context (PipelinedModCodec's idiom, src/ModPlugin.cpp:90-154) ----
+    def set_lanes(self, lanes):
+        """Internal HIP streams that calls on the context's own stream rotate over (1 ... 4, default 3)."""
+        self._chk(self._lib.dabgpu_set_lanes(self._h, int(lanes)))
+
+    def set_handover_frames(self, frames):
+        """FIRFilter -> Resampler hand-over in pieces of `frames` frames through a cache-resident ring (0: one piece)."""
+        self._chk(self._lib.dabgpu_set_handover_frames(self._h, int(frames)))
+
+    def wait_for_stream(self, stream):
+        """What the context queues from now on starts after what the HIP stream (handle) holds now."""
+        self._chk(self._lib.dabgpu_wait_for_stream(self._h, stream))
+
+    def stream_wait_for(self, stream):
+        """What is queued on the HIP stream (handle) from now on starts after everything the context has queued."""
+        self._chk(self._lib.dabgpu_stream_wait_for(self._h, stream))
+
+    def chain_dev_queued(self, d_in, n_frames, stages, d_out, from_bits=True):
+        """Device path on the context's OWN stream (the lanes): returns at once; the output is complete after
+        synchronize() or, in stream order, after stream_wait_for()."""
+        ob = C.c_size_t()
+        fn = self._lib.dabgpu_chain_process_dev if from_bits else self._lib.dabgpu_symbols_process_dev
+        self._chk(fn(self._h, d_in.data_ptr(), n_frames, stages, d_out.data_ptr(),
+                     d_out.numel() * d_out.element_size(), C.byref(ob), None))
+        return ob.value
+
+    def post_process_dev(self, d_native, stages, d_out, stream=None):
+        """cifRes -> cifPoly on a native-rate stream in device memory (stages: STAGE_RESAMPLE and / or STAGE_POLY)."""
+        s = self._stream_handle(d_native, stream)
+        ob = C.c_size_t()
+        self._chk(self._lib.dabgpu_post_process_dev(self._h, d_native.data_ptr(), d_native.numel(), stages,
+                                                    d_out.data_ptr(), d_out.numel() * d_out.element_size(), C.byref(ob), s))
+        if not s:
+            self.synchronize()
+        return ob.value

@@ -180,6 +180,28 @@ struct dabgpu_ctx {
     unsigned tii_seg_mask = ~0u;
     int tii_seg_len = 0;
 
+    // Batches in flight inside ONE context (the idiom of PipelinedModCodec, src/ModPlugin.cpp:90-154: the caller hands over
+    // batch i + 1 while batch i is still being worked on).  A chain call on the context's own stream (stream argument NULL)
+    // goes to one of n_lanes internal HIP streams in turn; every lane has its own per-call scratch, so the kernels of
+    // consecutive calls overlap where one launch alone cannot fill the chip.  Lane 0 is `stream` and the scratch members
+    // above; LaneScope swaps another lane's buffers in for the duration of a call.  Calls with the Resampler stay on lane 0
+    // (its state runs from frame to frame).
+    struct Lane {
+        hipStream_t stream = nullptr;
+        hipEvent_t ev = nullptr;
+        DevBuf d_a, d_b, d_fmt, d_clip, d_gain1, d_cfr_counts, d_cfr_mer, d_cfr_papr, d_cfr_tmp;
+    };
+    enum { kMaxLanes = 4, kLaneMaxFrames = 2048 };
+    Lane lane[kMaxLanes];                 // (entry 0: only `ev` is used)
+    int n_lanes = 3;
+    unsigned long long lane_seq = 0;
+    int clip_lane = 0, cfr_last_lane = 0; // whose scratch holds the clip count / the CFR statistics of the most recent call
+    // The native-rate stream between FIRFilter and Resampler (src/DabModulator.cpp:403-406) in pieces of this many frames
+    // through a two-piece ring that stays cache-resident, produced on lane 1's stream while the consumer works on the
+    // piece before (dabgpu_set_handover_frames; 0 = one piece, the whole batch through memory)
+    int handover_frames = 0;
+    hipEvent_t ho_prod[2] = {nullptr, nullptr}, ho_cons[2] = {nullptr, nullptr}, ho_start = nullptr, ho_join = nullptr;
+
     std::mutex mu;
     Settings set;                    // guarded by mu
     Settings cur;                    // snapshot used by the processing thread
@@ -230,6 +252,33 @@ int hip_fail(dabgpu_ctx *c, hipError_t e, const char *what)
         hipError_t e_ = (expr);                                                                \
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr);                                 \
     } while (0)
+
+// the stream of lane i (created on first use; lane 0 is the context's stream)
+int lane_stream(dabgpu_ctx *c, int i, hipStream_t *out)
+{
+    if (i == 0) { *out = c->stream; return DABGPU_OK; }
+    if (!c->lane[i].stream) HIPCHK(c, hipStreamCreateWithFlags(&c->lane[i].stream, hipStreamNonBlocking));
+    *out = c->lane[i].stream;
+    return DABGPU_OK;
+}
+
+// lane i's per-call scratch in place of the context's for the lifetime of the object
+struct LaneScope {
+    dabgpu_ctx *c;
+    int i;
+    LaneScope(dabgpu_ctx *ctx, int lane) : c(ctx), i(lane) { swap(); }
+    ~LaneScope() { swap(); }
+    LaneScope(const LaneScope &) = delete;
+    LaneScope &operator=(const LaneScope &) = delete;
+    void swap()
+    {
+        if (i == 0) return;
+        dabgpu_ctx::Lane &l = c->lane[i];
+        std::swap(c->d_a, l.d_a); std::swap(c->d_b, l.d_b); std::swap(c->d_fmt, l.d_fmt); std::swap(c->d_clip, l.d_clip);
+        std::swap(c->d_gain1, l.d_gain1); std::swap(c->d_cfr_counts, l.d_cfr_counts); std::swap(c->d_cfr_mer, l.d_cfr_mer);
+        std::swap(c->d_cfr_papr, l.d_cfr_papr); std::swap(c->d_cfr_tmp, l.d_cfr_tmp);
+    }
+};
 
 bool mode_geometry(int mode, Geometry *g)
 {
@@ -884,16 +933,19 @@ int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t nativ
     const size_t ext = (mask & DABGPU_STAGE_NOGUARD) ? (size_t)c->g.N
                                                      : (size_t)c->g.null_size + 2 * c->cur.overlap + 8;
     c->tii_seg_len = (int)std::min(native, ext);
+    HIPCHK(c, hipStreamSynchronize(s));   // (once per setting: the segment is read by whichever lane runs the next call)
     c->tii_seg_epoch = 1;
     c->tii_seg_mask = key;
     return DABGPU_OK;
 }
 
 int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask,
-              void *d_out_v, size_t out_cap, size_t *out_bytes, hipStream_t s, bool apply_format = true)
+              void *d_out_v, size_t out_cap, size_t *out_bytes, hipStream_t s, bool apply_format = true, int lane = 0)
 {
     int rc = apply_settings(c);
     if (rc) return rc;
+    LaneScope scratch(c, lane);
+    if (c->cur.cfr_enable && apply_format) c->cfr_last_lane = lane;
     if ((mask & DABGPU_STAGE_NOGUARD) && (mask & (DABGPU_STAGE_FIR | DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY)))
         return fail(c, DABGPU_E_INVALID, "NOGUARD cannot be combined with FIR/RESAMPLE/POLY");
     if ((mask & DABGPU_STAGE_FIR) && c->cur.taps.empty())
@@ -939,6 +991,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
         HIPCHK(c, hipMemsetAsync(c->d_clip.p, 0, 16, s));
         clip = (unsigned long long *)c->d_clip.p;
         c->clip_stream = s;
+        c->clip_lane = lane;
         if (fmt == DABGPU_FMT_S16 && from_bits) {
             // ask the kernels' own predicates (the ones their launchers test), so that the separate convert kernel is taken
             // whenever a variant does not exist in this build
@@ -968,6 +1021,50 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     if (fmt && !fuse_native && !fuse_post) {
         HIPCHK(c, c->d_fmt.reserve(n_frames * per * sizeof(float2)));
         d_out = (float2 *)c->d_fmt.p;
+    }
+
+    // The hand-over FIRFilter -> Resampler in cache-sized pieces (dabgpu_set_handover_frames): x2 / x4 with the predistorter
+    // inside the resampler's store or absent; CFR (per-frame statistics) and TII (per-frame gain, frame parity) keep the
+    // one-piece path.
+    const bool fuse_poly = (mask & DABGPU_STAGE_POLY) && !c->cur.poly_is_lut && resampler_fast_ratio(c);
+    const size_t piece = (size_t)c->handover_frames & ~(size_t)1;
+    if ((mask & DABGPU_STAGE_RESAMPLE) && resampler_fast_ratio(c) && (fuse_poly || !(mask & DABGPU_STAGE_POLY)) &&
+        !c->cur.cfr_enable && !tii && piece >= 2 && n_frames > piece) {
+        HIPCHK(c, c->d_a.reserve(2 * piece * native * sizeof(float2)));
+        hipStream_t prod;
+        if ((rc = lane_stream(c, 1, &prod))) return rc;
+        if (!c->ho_start) {
+            HIPCHK(c, hipEventCreateWithFlags(&c->ho_start, hipEventDisableTiming));
+            for (int i = 0; i < 2; ++i) {
+                HIPCHK(c, hipEventCreateWithFlags(&c->ho_prod[i], hipEventDisableTiming));
+                HIPCHK(c, hipEventCreateWithFlags(&c->ho_cons[i], hipEventDisableTiming));
+            }
+        }
+        // the producer starts after whatever the caller queued on s (the input; the previous call's use of the ring)
+        HIPCHK(c, hipEventRecord(c->ho_start, s));
+        HIPCHK(c, hipStreamWaitEvent(prod, c->ho_start, 0));
+        const size_t in_per = from_bits ? tf_in_bytes(c->g) : (size_t)(c->g.nb_symbols + 1) * (size_t)c->g.K * sizeof(float2);
+        const size_t bps = bytes_per_sample((fuse_post && fmt) ? fmt : 0);
+        size_t f0 = 0;
+        for (int i = 0; f0 < n_frames; ++i, f0 += piece) {
+            const size_t nf = std::min(piece, n_frames - f0);
+            const int slot = i & 1;
+            float2 *ring = (float2 *)c->d_a.p + (size_t)slot * piece * native;
+            if (i >= 2) HIPCHK(c, hipStreamWaitEvent(prod, c->ho_cons[slot], 0));   // the consumer is done with piece i - 2
+            if ((rc = run_native(c, (const char *)d_in + f0 * in_per, from_bits, nf, mask, windowed, ring, native, nullptr,
+                                 prod)))
+                return rc;
+            HIPCHK(c, hipEventRecord(c->ho_prod[slot], prod));
+            HIPCHK(c, hipStreamWaitEvent(s, c->ho_prod[slot], 0));
+            if ((rc = run_resampler(c, ring, nf * native, (float2 *)((char *)d_out + f0 * per * bps), s, fuse_poly,
+                                    fuse_post ? clip : nullptr)))
+                return rc;
+            HIPCHK(c, hipEventRecord(c->ho_cons[slot], s));
+        }
+        if (from_bits && (n_frames & 1)) c->tii_insert = !c->tii_insert;   // (src/TII.cpp:241-242: toggles with TII off as well)
+        if (fmt && !fuse_native && !fuse_post)
+            HIPCHK(c, launch_format((const float *)d_out, 2 * n_frames * per, fmt, d_out_v, clip, s));
+        return DABGPU_OK;
     }
 
     // where the native-rate stream goes
@@ -1125,6 +1222,8 @@ void dabgpu_destroy(dabgpu_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->device);
     if (c->stream) (void)hipStreamSynchronize(c->stream);
+    for (auto &l : c->lane)
+        if (l.stream) (void)hipStreamSynchronize(l.stream);
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh, &c->d_eqg,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
                       &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count, &c->d_fmt, &c->d_clip, &c->d_phase,
@@ -1141,6 +1240,14 @@ void dabgpu_destroy(dabgpu_ctx *c)
     }
     for (void *h : c->h_out)
         if (h) (void)hipHostFree(h);
+    for (auto &l : c->lane) {
+        if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
+        if (l.ev) (void)hipEventDestroy(l.ev);
+        for (DevBuf *b : {&l.d_a, &l.d_b, &l.d_fmt, &l.d_clip, &l.d_gain1, &l.d_cfr_counts, &l.d_cfr_mer, &l.d_cfr_papr, &l.d_cfr_tmp})
+            b->release();
+    }
+    for (hipEvent_t e : {c->ho_prod[0], c->ho_prod[1], c->ho_cons[0], c->ho_cons[1], c->ho_start, c->ho_join})
+        if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     delete c;
@@ -1218,6 +1325,7 @@ int dabgpu_get_cfr_stats(dabgpu_ctx *c, size_t frame, dabgpu_cfr_stats *out)
         return fail(c, DABGPU_E_INVALID, "no CFR statistics for this frame (CFR off, or frame index out of range)");
     const size_t nsym = (size_t)c->g.nb_symbols + 1;
     HIPCHK(c, hipStreamSynchronize(c->cfr_last_stream ? c->cfr_last_stream : c->stream));
+    LaneScope scratch(c, c->cfr_last_lane);
     unsigned counts[2];
     double mer[2];
     std::vector<double> papr(nsym * 4);
@@ -1320,6 +1428,7 @@ int dabgpu_get_num_clipped(dabgpu_ctx *c, size_t *num_clipped)
         *num_clipped = c->collected_clipped;
         return DABGPU_OK;
     }
+    LaneScope scratch(c, c->clip_lane);
     if (!c->d_clip.p || !c->clip_valid) return DABGPU_OK;
     HIPCHK(c, hipStreamSynchronize(c->clip_stream ? c->clip_stream : c->stream));
     unsigned long long v = 0;
@@ -1704,24 +1813,153 @@ size_t dabgpu_chain_out_bytes_per_frame(const dabgpu_ctx *c, unsigned mask)
     return out_samples_per_frame(c, mask, L, M) * bytes_per_sample(fmt);
 }
 
+}  // extern "C"
+
+namespace {
+
+// Which lane a call on the context's own stream goes to: the lanes in turn while a launch alone cannot fill the chip many
+// times over; lane 0 for everything that carries stream state (Resampler) and for large batches (nothing to gain, and
+// the scratch of some chains grows with the batch).
+int pick_lane(dabgpu_ctx *c, size_t n_frames, unsigned mask)
+{
+    bool resample;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        resample = (mask & DABGPU_STAGE_RESAMPLE) && c->set.rs_in != c->set.rs_out;
+    }
+    if (c->n_lanes <= 1 || resample || n_frames > (size_t)dabgpu_ctx::kLaneMaxFrames) return 0;
+    return (int)(c->lane_seq++ % (unsigned long long)c->n_lanes);
+}
+
+int chain_dev(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, void *d_iq, size_t out_cap,
+              size_t *out_bytes, void *stream)
+{
+    int lane = 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) {
+        lane = pick_lane(c, n_frames, mask);
+        const int rc = lane_stream(c, lane, &s);
+        if (rc) return rc;
+    }
+    c->clip_from_collect = false;
+    TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
+    return run_chain(c, d_in, from_bits, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s, true, lane);
+}
+
+}  // namespace
+
+extern "C" {
+
 int dabgpu_chain_process_dev(dabgpu_ctx *c, const void *d_bits, size_t n_frames, unsigned mask,
                              void *d_iq, size_t out_cap, size_t *out_bytes, void *stream)
 {
     CTXCHK(c);
-    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    c->clip_from_collect = false;
-    TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
-    return run_chain(c, d_bits, true, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
+    return chain_dev(c, d_bits, true, n_frames, mask, d_iq, out_cap, out_bytes, stream);
 }
 
 int dabgpu_symbols_process_dev(dabgpu_ctx *c, const void *d_car, size_t n_frames, unsigned mask,
                                void *d_iq, size_t out_cap, size_t *out_bytes, void *stream)
 {
     CTXCHK(c);
+    return chain_dev(c, d_car, false, n_frames, mask, d_iq, out_cap, out_bytes, stream);
+}
+
+// cifRes -> cifPoly on a native-rate stream that is already in device memory: the tail of the chain by itself
+int dabgpu_post_process_dev(dabgpu_ctx *c, const void *d_native, size_t n_samples, unsigned mask, void *d_iq, size_t out_cap,
+                            size_t *out_bytes, void *stream)
+{
+    CTXCHK(c);
+    int rc = apply_settings(c);
+    if (rc) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
-    c->clip_from_collect = false;
+    if (mask & ~(unsigned)(DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY))
+        return fail(c, DABGPU_E_INVALID, "post-processing: DABGPU_STAGE_RESAMPLE and / or DABGPU_STAGE_POLY");
+    if ((mask & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) mask &= ~(unsigned)DABGPU_STAGE_RESAMPLE;
+    size_t n_out = n_samples;
+    if (mask & DABGPU_STAGE_RESAMPLE) {
+        if ((rc = check_resampler(c))) return rc;
+        if (n_samples % ((size_t)c->rs_nin / 2)) return fail(c, DABGPU_E_INVALID, "Resampler::process input size not valid!");
+        n_out = n_samples * c->rs_L / c->rs_M;
+    }
+    if ((rc = check_out(c, n_out * sizeof(float2), out_cap, out_bytes))) return rc;
+    if (n_samples == 0) return DABGPU_OK;
     TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
-    return run_chain(c, d_car, false, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s);
+    const float2 *cur = (const float2 *)d_native;
+    bool poly_done = !(mask & DABGPU_STAGE_POLY);
+    if (mask & DABGPU_STAGE_RESAMPLE) {
+        const bool fuse = (mask & DABGPU_STAGE_POLY) && !c->cur.poly_is_lut && resampler_fast_ratio(c);
+        float2 *dst = (float2 *)d_iq;
+        if (!poly_done && !fuse) {
+            HIPCHK(c, c->d_b.reserve(n_out * sizeof(float2)));
+            dst = (float2 *)c->d_b.p;
+        }
+        if ((rc = run_resampler(c, cur, n_samples, dst, s, fuse))) return rc;
+        cur = dst;
+        poly_done = poly_done || fuse;
+    }
+    if (!poly_done && (rc = run_poly(c, cur, n_out, (float2 *)d_iq, s))) return rc;
+    if (cur == (const float2 *)d_native && poly_done)     // (neither stage: the stream passes through)
+        HIPCHK(c, hipMemcpyAsync(d_iq, d_native, n_samples * sizeof(float2), hipMemcpyDeviceToDevice, s));
+    return DABGPU_OK;
+}
+
+int dabgpu_set_lanes(dabgpu_ctx *c, int lanes)
+{
+    CTXCHK(c);
+    if (lanes < 1 || lanes > (int)dabgpu_ctx::kMaxLanes) return fail(c, DABGPU_E_INVALID, "lanes: 1 ... 4");
+    const int rc = dabgpu_synchronize(c);
+    if (rc) return rc;
+    c->n_lanes = lanes;
+    c->lane_seq = 0;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_handover_frames(dabgpu_ctx *c, int frames)
+{
+    CTXCHK(c);
+    if (frames < 0 || (frames & 1)) return fail(c, DABGPU_E_INVALID, "hand-over piece: an even number of frames, or 0");
+    const int rc = dabgpu_synchronize(c);
+    if (rc) return rc;
+    c->handover_frames = frames;
+    return DABGPU_OK;
+}
+
+// everything the context queues from now on starts after what `stream` holds now
+int dabgpu_wait_for_stream(dabgpu_ctx *c, void *stream)
+{
+    CTXCHK(c);
+    if (!c->lane[0].ev) HIPCHK(c, hipEventCreateWithFlags(&c->lane[0].ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->lane[0].ev, (hipStream_t)stream));
+    for (int i = 0; i < (int)dabgpu_ctx::kMaxLanes; ++i) {
+        hipStream_t ls = i ? c->lane[i].stream : c->stream;
+        if (ls) HIPCHK(c, hipStreamWaitEvent(ls, c->lane[0].ev, 0));
+    }
+    // (a lane whose stream does not exist yet is created later, by a call the host makes after this one: it cannot start
+    // before the host has seen `stream` reach this point only if the caller relies on stream order alone -- so create them)
+    for (int i = 1; i < c->n_lanes; ++i)
+        if (!c->lane[i].stream) {
+            hipStream_t ls;
+            const int rc = lane_stream(c, i, &ls);
+            if (rc) return rc;
+            HIPCHK(c, hipStreamWaitEvent(ls, c->lane[0].ev, 0));
+        }
+    return DABGPU_OK;
+}
+
+// everything queued on `stream` from now on starts after what the context has queued so far (all lanes)
+int dabgpu_stream_wait_for(dabgpu_ctx *c, void *stream)
+{
+    CTXCHK(c);
+    for (int i = 0; i < (int)dabgpu_ctx::kMaxLanes; ++i) {
+        hipStream_t ls = i ? c->lane[i].stream : c->stream;
+        if (!ls) continue;
+        // (lane 0's `ev` is dabgpu_wait_for_stream's: the joins use events 1 ... and one more for lane 0)
+        hipEvent_t &ev = i ? c->lane[i].ev : c->ho_join;
+        if (!ev) HIPCHK(c, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(ev, ls));
+        HIPCHK(c, hipStreamWaitEvent((hipStream_t)stream, ev, 0));
+    }
+    return DABGPU_OK;
 }
 
 int dabgpu_chain_process(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, unsigned mask,
@@ -1764,7 +2002,12 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     if ((m2 & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) m2 &= ~DABGPU_STAGE_RESAMPLE;
     const size_t in_bytes = n_frames * tf_in_bytes(c->g);
     const size_t need = n_frames * out_samples_per_frame(c, m2, c->rs_L, c->rs_M) * bytes_per_sample(c->cur.out_format);
-    dabgpu_ctx::Slot &sl = c->slot[(c->slot_head + c->slot_count) & 1];
+    const int slot_index = (c->slot_head + c->slot_count) & 1;
+    dabgpu_ctx::Slot &sl = c->slot[slot_index];
+    // the two batches in flight run on two lanes where the chain carries no stream state: their kernels overlap
+    const int lane = (c->n_lanes > 1 && !(m2 & DABGPU_STAGE_RESAMPLE)) ? slot_index : 0;
+    hipStream_t ls;
+    if ((rc = lane_stream(c, lane, &ls))) return rc;
     if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
     if (!sl.computed) {
         HIPCHK(c, hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
@@ -1788,20 +2031,21 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     HIPCHK(c, sl.d_in.reserve(std::max<size_t>(in_bytes, 16)));
     HIPCHK(c, sl.d_out.reserve(std::max<size_t>(need, 16)));
     std::memcpy(sl.h_in, bits, in_bytes);                       // 28.8 kB per frame
-    if (in_bytes) HIPCHK(c, hipMemcpyAsync(sl.d_in.p, sl.h_in, in_bytes, hipMemcpyHostToDevice, c->stream));
+    if (in_bytes) HIPCHK(c, hipMemcpyAsync(sl.d_in.p, sl.h_in, in_bytes, hipMemcpyHostToDevice, ls));
     size_t ob = 0;
     {
         TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
-        rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, c->stream);
+        rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, ls, true, lane);
     }
     if (rc) return rc;
     sl.out_format = c->cur.out_format;
     if (sl.out_format) {
-        // the clip counter is one per context and the next submit zeroes it: this batch's count goes to the slot now
+        // the clip counter is one per lane and the next submit on it zeroes it: this batch's count goes to the slot now
         if (!sl.h_clip) HIPCHK(c, hipHostMalloc((void **)&sl.h_clip, 16, hipHostMallocDefault));
-        HIPCHK(c, hipMemcpyAsync(sl.h_clip, c->d_clip.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, c->stream));
+        LaneScope scratch(c, lane);
+        HIPCHK(c, hipMemcpyAsync(sl.h_clip, c->d_clip.p, sizeof(unsigned long long), hipMemcpyDeviceToHost, ls));
     }
-    HIPCHK(c, hipEventRecord(sl.computed, c->stream));
+    HIPCHK(c, hipEventRecord(sl.computed, ls));
     // the copy back runs on its own stream: the next batch's kernels overlap it
     HIPCHK(c, hipStreamWaitEvent(c->copy_stream, sl.computed, 0));
     if (need) HIPCHK(c, hipMemcpyAsync(c->h_out[ho], sl.d_out.p, need, hipMemcpyDeviceToHost, c->copy_stream));
@@ -1835,6 +2079,8 @@ int dabgpu_synchronize(dabgpu_ctx *c)
 {
     CTXCHK(c);
     HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 1; i < (int)dabgpu_ctx::kMaxLanes; ++i)
+        if (c->lane[i].stream) HIPCHK(c, hipStreamSynchronize(c->lane[i].stream));
     return DABGPU_OK;
 }
 

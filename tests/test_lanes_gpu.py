@@ -1,0 +1,316 @@
+"""Batches in flight inside ONE context (the lanes of include/dabgpu.h; idiom: PipelinedModCodec,
+/root/reference/src/ModPlugin.cpp:90-154) and the hand-over FIRFilter -> Resampler in cache-sized pieces
+(order of /root/reference/src/DabModulator.cpp:403-406; arithmetic of /root/reference/src/Resampler.cpp:142-192).
+
+The bar for both is the strictest there is: the same BYTES as the serial, one-piece path -- frames are independent
+units and the resampler's state runs through the pieces, so neither may change a single sample -- and the serial
+path is the one the parity tests hold against the oracle (the first case below checks that directly as well).
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from tests.conftest import load_pkg
+from tests.golden.synth import POLY_AM, POLY_PM, synth_bits
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+def rel_rms(y, ref):
+    return float(np.linalg.norm(y.astype(np.complex128) - ref) / max(np.linalg.norm(ref), 1e-30))
+
+
+def _u32(t):
+    import torch
+    return torch.view_as_real(t).view(torch.int32) if t.is_complex() else t.view(torch.int32)
+
+
+@pytest.mark.parametrize("lanes", [2, 3, 4])
+def test_64_alternating_batches_equal_the_serial_result_frame_for_frame(pkg, lanes):
+    """64 batches of 16 frames handed to ONE context on its own stream, rotating over the lanes, against the same 64
+    batches with one lane (every call in order on one stream): identical bytes, batch for batch; and the first and last
+    batch against the oracle."""
+    import torch
+    nb, B, stages = 64, 16, pkg.STAGE_GAIN | pkg.STAGE_FIR
+    per = O.tf_input_bytes(1)
+    rs = np.random.RandomState(77)
+    bits = np.frombuffer(rs.bytes(nb * B * per), np.uint8).reshape(nb, B, per)
+    d_bits = torch.from_numpy(bits.copy()).cuda()
+    outs = {}
+    for n in (1, lanes):
+        md = pkg.Modulator(mode=1, max_frames=B)
+        try:
+            md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_lanes(n)
+            d_out = torch.zeros((nb, B, 196608), dtype=torch.complex64, device="cuda")
+            torch.cuda.synchronize()
+            for i in range(nb):
+                md.chain_dev_queued(d_bits[i], B, stages, d_out[i])
+            md.synchronize()
+            outs[n] = d_out
+        finally:
+            md.close()
+    assert bool((_u32(outs[1]) == _u32(outs[lanes])).all())
+    ch = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1.0 / 50000.0)
+    for i in (0, nb - 1):
+        ref = ch.process(bits[i])
+        y = outs[lanes][i].cpu().numpy()
+        for f in range(B):
+            assert rel_rms(y[f], ref[f]) < 1e-6
+
+
+def test_lanes_are_ordered_against_a_caller_stream_by_the_two_fences(pkg):
+    """Input written on the caller's stream right before the calls, output read on it right after: correct through
+    dabgpu_wait_for_stream / dabgpu_stream_wait_for alone, without any host synchronisation in between."""
+    import torch
+    B, stages = 8, pkg.STAGE_GAIN | pkg.STAGE_FIR
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=3100 + i) for i in range(4 * B)]).reshape(4, B, per)
+    md = pkg.Modulator(mode=1, max_frames=B)
+    try:
+        md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        st = torch.cuda.Stream()
+        src = torch.from_numpy(bits).cuda()
+        torch.cuda.synchronize()
+        with torch.cuda.stream(st):
+            d_bits = torch.zeros_like(src)
+            d_out = torch.zeros((4, B, 196608), dtype=torch.complex64, device="cuda")
+            acc = torch.zeros((4, B), dtype=torch.float32, device="cuda")
+            for rep in range(3):
+                # (a long-running filler in front, so that an unordered lane would certainly overtake it)
+                big = torch.empty(1 << 28, dtype=torch.float32, device="cuda")
+                for _ in range(3):
+                    big.fill_(1.0)
+                d_bits.copy_(src if rep == 2 else src.flip(0), non_blocking=True)
+                md.wait_for_stream(st.cuda_stream)
+                for i in range(4):
+                    md.chain_dev_queued(d_bits[i], B, stages, d_out[i])
+                md.stream_wait_for(st.cuda_stream)
+                acc.copy_(d_out.abs().sum(dim=-1))
+            got = d_out.clone()
+        st.synchronize()
+        y = got.cpu().numpy()
+        ch = O.Chain(mode=1, stages=3, gain_mode=2, normalise=1.0 / 50000.0)
+        for i in range(4):
+            ref = ch.process(bits[i])
+            for f in range(B):
+                assert rel_rms(y[i, f], ref[f]) < 1e-6
+        assert np.allclose(acc.cpu().numpy(), np.abs(y).sum(axis=-1), rtol=1e-4)
+    finally:
+        md.close()
+
+
+def test_lane_scratch_is_per_lane_for_the_chains_that_need_some(pkg):
+    """Chains with per-call scratch (s16 through the separate FormatConverter kernel, TII with per-frame gains, CFR
+    statistics, the windowed guard interval): rotating over four lanes gives the bytes of one lane, and the clip count /
+    CFR statistics asked for afterwards are those of the LAST call."""
+    import torch
+    B = 4
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=3300 + i) for i in range(6 * B)]).reshape(6, B, per)
+    d_bits = torch.from_numpy(bits).cuda()
+
+    def run(lanes, setup, fmt=None):
+        md = pkg.Modulator(mode=1, max_frames=B)
+        try:
+            md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 if fmt else 1.0 / 50000.0, 4.0)
+            setup(md)
+            md.set_output_format(fmt)
+            md.set_lanes(lanes)
+            stages = pkg.STAGE_GAIN | pkg.STAGE_FIR
+            ns = md.out_samples_per_frame(stages)
+            d_out = torch.zeros((6, B, ns), dtype=torch.complex64 if fmt is None else torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for i in range(6):
+                md.chain_dev_queued(d_bits[i], B, stages, d_out[i])
+            md.synchronize()
+            extra = md.num_clipped() if fmt else None
+            return d_out, extra
+        finally:
+            md.close()
+
+    cases = {
+        "s16 + windowed guard (FormatConverter kernel, d_fmt + d_b)": (lambda md: md.set_window_overlap(24), "s16"),
+        "TII + max gain (per-frame gain of symbol 1)": (lambda md: (md.set_tii(True, 3, 5), md.set_gain(1, 1.0, 1.0, 4.0)), None),
+        "long filter (IFFT kernel -> guard_fir_kernel through d_b)": (lambda md: md.set_fir_taps(np.hanning(201).astype(np.float32) / 100), None),
+    }
+    for name, (setup, fmt) in cases.items():
+        a, ca = run(1, setup, fmt)
+        b, cb = run(4, setup, fmt)
+        assert bool((_u32(a) == _u32(b)).all()), name
+        assert ca == cb, name
+
+    # CFR: the statistics of the most recent call, whichever lane ran it
+    def cfr_stats(lanes):
+        md = pkg.Modulator(mode=1, max_frames=B)
+        try:
+            md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_cfr(True, 50.0, 0.1)
+            md.set_lanes(lanes)
+            d_out = torch.zeros((6, B, 196608), dtype=torch.complex64, device="cuda")
+            for i in range(6):
+                md.chain_dev_queued(d_bits[i], B, 3, d_out[i])
+            st = [md.cfr_stats(f) for f in range(B)]
+            md.synchronize()
+            return d_out, st
+        finally:
+            md.close()
+    a, sa = cfr_stats(1)
+    b, sb = cfr_stats(3)
+    assert bool((_u32(a) == _u32(b)).all())
+    for x, y in zip(sa, sb):
+        assert x["num_clip"] == y["num_clip"] and x["num_error_clip"] == y["num_error_clip"] and x["mer_symbol"] == y["mer_symbol"]
+        assert np.array_equal(x["papr_after"], y["papr_after"])
+
+
+def test_submit_collect_on_two_lanes_equals_the_synchronous_call(pkg):
+    """The asynchronous host path keeps its two batches on two lanes now: same bytes as dabgpu_chain_process, in order."""
+    B = 6
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=3500 + i) for i in range(5 * B)]).reshape(5, B, per)
+    md = pkg.Modulator(mode=1, max_frames=B)
+    try:
+        md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        want = [md.chain(bits[i], 3).copy() for i in range(5)]
+        got = []
+        md.submit(bits[0], 3)
+        for i in range(1, 5):
+            md.submit(bits[i], 3)
+            got.append(md.collect())
+        got.append(md.collect())
+        for i in range(5):
+            assert np.array_equal(got[i].view(np.uint32).ravel(), want[i].view(np.uint32).ravel()), i
+    finally:
+        md.close()
+
+
+@pytest.mark.parametrize("fmt", [None, "s16"])
+@pytest.mark.parametrize("piece", [2, 6, 10])
+def test_cfg4_handover_in_pieces_equals_one_piece_byte_for_byte(pkg, piece, fmt):
+    """cfg 4 (FIRFilter -> Resampler x4 -> MemlessPoly) with the native-rate stream handed over in pieces of 2 / 6 / 10
+    frames through the two-piece ring, against the one-piece path: 23 frames (ragged last piece), two consecutive calls
+    (the resampler's state crosses pieces AND calls) -- the same bytes; and the one-piece path against the oracle."""
+    import torch
+    B = 23
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=3700 + i) for i in range(2 * B)]).reshape(2, B, per)
+    d_bits = torch.from_numpy(bits).cuda()
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY
+    res = {}
+    for p in (0, piece):
+        md = pkg.Modulator(mode=1, max_frames=B)
+        try:
+            md.set_gain(pkg.GAIN_VAR, 1.0, 0.6 if fmt else 1.0 / 50000.0, 4.0)
+            md.set_resampler(2048000, 8192000)
+            md.set_poly(POLY_AM, POLY_PM)
+            md.set_output_format(fmt)
+            md.set_handover_frames(p)
+            ns = md.out_samples_per_frame(stages)
+            d_out = torch.zeros((2, B, ns), dtype=torch.complex64 if fmt is None else torch.int32, device="cuda")
+            md.trace(True)
+            for i in range(2):
+                md.chain_dev(d_bits[i], B, stages, d_out[i])
+            torch.cuda.synchronize()
+            kernels = md.last_variant()
+            res[p] = (d_out, md.num_clipped() if fmt else None, kernels)
+        finally:
+            md.close()
+    assert bool((_u32(res[0][0]) == _u32(res[piece][0])).all())
+    assert res[0][1] == res[piece][1]
+    # the pieces really ran: one frame kernel + one resampler per piece
+    npieces = -(-B // piece)
+    assert sum(k.startswith("tf_kernel") for k in res[piece][2]) == npieces
+    assert sum(k.startswith("resampler16_kernel") for k in res[piece][2]) == npieces
+    assert sum(k.startswith("tf_kernel") for k in res[0][2]) == 1
+    if fmt is None:
+        ch = O.Chain(mode=1, stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000, am=POLY_AM, pm=POLY_PM)
+        y = res[piece][0].cpu().numpy()
+        for i in range(2):
+            ref = ch.process(bits[i])
+            for f in (0, 1, piece, B - 1):
+                assert rel_rms(y[i, f], ref[f]) < 1e-6
+
+
+def test_handover_pieces_from_carriers_and_x2(pkg):
+    """The same through the carriers entry point (SignalMultiplexer output) and the x2 ratio without predistorter."""
+    import torch
+    B = 9
+    md0 = pkg.Modulator(mode=1, max_frames=B)
+    K = md0.geometry["carriers"]
+    md0.close()
+    rs = np.random.RandomState(5)
+    q = rs.randint(0, 4, size=(B, 77 * K))
+    car = np.exp(1j * (2 * q + 1) * np.pi / 4).astype(np.complex64)
+    car[:, :K] = 0
+    d_car = torch.from_numpy(car).cuda()
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE
+    res = {}
+    for p in (0, 4):
+        md = pkg.Modulator(mode=1, max_frames=B)
+        try:
+            md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_resampler(2048000, 4096000)
+            md.set_handover_frames(p)
+            d_out = torch.zeros((B, 2 * 196608), dtype=torch.complex64, device="cuda")
+            md.symbols_dev(d_car, B, stages, d_out)
+            torch.cuda.synchronize()
+            res[p] = d_out
+        finally:
+            md.close()
+    assert bool((_u32(res[0]) == _u32(res[4])).all())
+
+
+def test_post_process_dev_is_the_tail_of_the_chain(pkg):
+    """dabgpu_post_process_dev (cifRes -> cifPoly on a device-resident native-rate stream) after the native chain ==
+    the fused chain with the same stages, byte for byte, state carried across two calls; bad arguments are refused."""
+    import torch
+    B = 3
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=3900 + i) for i in range(2 * B)]).reshape(2, B, per)
+    d_bits = torch.from_numpy(bits).cuda()
+    full = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY
+
+    def make():
+        md = pkg.Modulator(mode=1, max_frames=B)
+        md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        md.set_resampler(2048000, 8192000)
+        md.set_poly(POLY_AM, POLY_PM)
+        return md
+    a, b = make(), make()
+    try:
+        for i in range(2):
+            want = torch.zeros((B, 4 * 196608), dtype=torch.complex64, device="cuda")
+            a.chain_dev(d_bits[i], B, full, want)
+            native = torch.zeros((B, 196608), dtype=torch.complex64, device="cuda")
+            b.chain_dev(d_bits[i], B, pkg.STAGE_GAIN | pkg.STAGE_FIR, native)
+            got = torch.zeros_like(want)
+            b.post_process_dev(native, pkg.STAGE_RESAMPLE | pkg.STAGE_POLY, got)
+            torch.cuda.synchronize()
+            assert bool((_u32(want) == _u32(got)).all()), i
+        with pytest.raises(pkg.DabGpuError, match="post-processing"):
+            b.post_process_dev(native, pkg.STAGE_FIR, got)
+        with pytest.raises(pkg.DabGpuError, match="input size not valid"):
+            b.post_process_dev(native.reshape(-1)[:1000], pkg.STAGE_RESAMPLE, got)
+    finally:
+        a.close()
+        b.close()
+
+
+def test_set_lanes_and_handover_arguments(pkg):
+    md = pkg.Modulator(mode=1, max_frames=1)
+    try:
+        for bad in (0, 5, -1):
+            with pytest.raises(pkg.DabGpuError, match="lanes"):
+                md.set_lanes(bad)
+        for bad in (-2, 3):
+            with pytest.raises(pkg.DabGpuError, match="hand-over"):
+                md.set_handover_frames(bad)
+        md.set_lanes(4)
+        md.set_handover_frames(64)
+    finally:
+        md.close()
