@@ -419,7 +419,7 @@ class Modulator:
         if not isinstance(out, np.ndarray) or out.dtype != dt or out.size != n * per_out or not out.flags.c_contiguous:
             raise DabGpuError("chain: output buffer does not match (dtype %s, %d elements, C-contiguous)" % (dt, n * per_out))
         flat = out.reshape(-1)
-        assert np.shares_memory(flat, out)
+        assert flat.size == 0 or np.shares_memory(flat, out)
         out = flat
         ob = C.c_size_t()
         self._chk(self._lib.dabgpu_chain_process(self._h, bits.ctypes.data, n, stages,

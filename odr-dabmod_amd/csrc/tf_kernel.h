@@ -266,7 +266,13 @@ void tf_kernel(const TfArgs a)
     // microbenchmark prices a third cheaper per byte, were tried too: neighbouring lanes swap half of their samples by DPP and
     // store pairs -- parity green, -2 % with either policy: the 40 instructions of the swap and two 512-byte halves per store.)  The chains from carriers (cfg 2, the
     // IFFT + FIR stage) ARE bandwidth-bound, at the nominal clock with power to spare, and lose 0 ... 1.5 %: they keep plain stores.
+    // (tool builds only, tools/exp_store_policy.sh: -DDABGPU_STORE_AUX=n forces the policy bits of every variant's stores --
+    // 0 plain, 1 sc0, 2 nt, 16 sc1 and their sums -- so that the A/B behind the figures above can be re-run from the tree)
+#ifdef DABGPU_STORE_AUX
+    constexpr int kStoreAux = DABGPU_STORE_AUX;
+#else
     constexpr int kStoreAux = FROM_BITS ? 2 : 0;
+#endif
     auto put = [&](int soff, int voff, cf y) __attribute__((always_inline)) {
         if (OFMT == 1) {
             __builtin_amdgcn_raw_buffer_store_b32(s16_pack(y, nclip), orsrc, voff * 4, soff * 4, kStoreAux);

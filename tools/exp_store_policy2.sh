@@ -9,7 +9,8 @@ d="$ROOT/tools/_variants/src_ntall"
 rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"
 cp -r "$ROOT/odr-dabmod_amd/csrc" "$d/odr-dabmod_amd/csrc"; cp "$ROOT/include/"*.h "$d/include/"
 rm -f "$d/odr-dabmod_amd/csrc/"*.o "$d/odr-dabmod_amd/csrc/libdabgpu.so"
-sed -i "s/orsrc, voff \* 8, soff \* 8, 0);/orsrc, voff * 8, soff * 8, 2);/; s/orsrc, voff \* 4, soff \* 4, 0);/orsrc, voff * 4, soff * 4, 2);/" "$d/odr-dabmod_amd/csrc/tf_kernel.h"
+# (the frame kernel: every variant's stores non-temporal through the tool-only flag, tf_kernel.h: kStoreAux)
+grep -q "DABGPU_STORE_AUX" "$d/odr-dabmod_amd/csrc/tf_kernel.h" || { echo "tf_kernel.h no longer reads DABGPU_STORE_AUX" >&2; exit 1; }
 python3 - "$d/odr-dabmod_amd/csrc/resampler.hip" <<'PY'
 import sys
 p = sys.argv[1]
@@ -23,6 +24,6 @@ assert old in s
 s = s.replace(old, new, 1)
 open(p, "w").write(s)
 PY
-make -s -C "$d/odr-dabmod_amd/csrc" -j8 > "$ROOT/tools/_variants/ntall.log" 2>&1
+make -s -C "$d/odr-dabmod_amd/csrc" -j8 NOSLP="-fno-slp-vectorize -DDABGPU_STORE_AUX=2" > "$ROOT/tools/_variants/ntall.log" 2>&1
 cp "$d/odr-dabmod_amd/csrc/libdabgpu.so" "$ROOT/tools/_variants/libdabgpu_ntall.so"
 echo built ntall

@@ -81,16 +81,27 @@ class PowerProbe:
 
 
 def sample_load(step, seconds, ms_per_step, stream, device_index=0, probe=None):
-    """Queue about `seconds` of step() launches on `stream` (a torch stream) and sample the card meanwhile."""
-    import torch
+    """About `seconds` of step() launches on `stream` (a torch stream) with the card sampled meanwhile.  The sampler runs on
+    its own thread from before the first launch: queueing tens of thousands of small launches blocks the host once the
+    runtime's queue is full, and a sampler that starts after the queueing would see only the tail of the load."""
+    import threading
     probe = probe or PowerProbe(device_index)
     n = max(8, int(seconds / (ms_per_step * 1e-3)))
-    done = torch.cuda.Event()
-    for _ in range(n):
-        step()
-    done.record(stream)
-    pw = probe.measure(lambda: not done.query())
-    stream.synchronize()
+    running = [True]
+    out = [None]
+
+    def sampler():
+        out[0] = probe.measure(lambda: running[0])
+    t = threading.Thread(target=sampler)
+    t.start()
+    try:
+        for _ in range(n):
+            step()
+        stream.synchronize()
+    finally:
+        running[0] = False
+        t.join()
+    pw = out[0]
     if pw and "error" not in pw:
         pw["launches_sampled"] = n
     return pw
