@@ -431,6 +431,9 @@ def _split_gain_scalar(y, ref, mode, bits=None, gain_mode=None, normalise=1.0, h
     return da, res, dex
 
 
+VAR_TOTAL_LIMIT = 8e-7   # chains with GainControl in mode var: total max-abs / |out|_inf against the reference (measured <= 6.3e-7)
+
+
 def _hold_gain_bars(tag, y, ref, mode, bits, gain_mode, normalise, residual_limit, total_limit, head=0, tail=0):
     """The bars of a native-rate chain with GainControl, one per stage.  residual_limit: the bar of the stages besides the
     scalar -- chains with FIRFilter: a9's 5e-7 plus the two roundings of the gain multiply itself (device and reference
@@ -446,7 +449,14 @@ def _hold_gain_bars(tag, y, ref, mode, bits, gain_mode, normalise, residual_limi
     else:
         ok &= record_bound("a7 gain scalar (mode %s) against the reference's, rel, " % gain_mode + tag, da, 3.5e-7)
     ok &= record_bound("max-abs / |out|_inf after the gain scalar (symbol interiors), " + tag, res, residual_limit)
-    return ok and np.abs(y - ref).max() / np.abs(ref).max() <= total_limit
+    # The chain's TOTAL against the reference, recorded like every other bar.  Without var gain: the round-3 limits (5e-7 for
+    # the windowed chain, 7e-7 once FIRFilter is in it), unchanged.  With var gain the total is dominated by the difference of
+    # the two gain SCALARS -- the documented deviation of the fused chain ("Known deviations from the
+    # reference": exact variance here, an fp32 recurrence up to 6e-7 away from it there) -- and is held to that scalar's own
+    # reference-relative bar, VAR_TOTAL_LIMIT.  No limit in this file changes without a line in that section.
+    ok &= record_bound("chain total max-abs / |out|_inf against the reference (gain mode %s), " % gain_mode + tag,
+                       np.abs(y - ref).max() / np.abs(ref).max(), VAR_TOTAL_LIMIT if gain_mode == 2 else total_limit)
+    return ok
 
 
 @pytest.mark.parametrize("mode", [1, 2, 3, 4])
@@ -469,7 +479,7 @@ def test_chain_cfg3_gain_var_fir(pkg, mode, chunks):
     # within 2e-7 of the reference's -- and a9 -- 5e-7 * |in|_inf of the filter on what is left once that scalar is taken
     # out (the IFFT's own rounding, rel-RMS 1e-7, is inside it).  Their sum (7e-7 of the largest sample) bounds the total.
     assert _hold_gain_bars("a6+a9 fused chain cfg3, mode %d chunks %d" % (mode, chunks), y, ref, mode,
-                           _chain_case_bits(mode, 3), 2, 1.0 / 50000.0, 6.2e-7, 1e-6, tail=44)
+                           _chain_case_bits(mode, 3), 2, 1.0 / 50000.0, 6.2e-7, 7e-7, tail=44)
 
 
 @pytest.mark.parametrize("gain", [(2, 1.0 / 50000.0), (0, 1.0), (None, 0)])
@@ -635,7 +645,7 @@ def test_chain_windowed_guard_without_fir_is_windowed_by_the_frame_kernel(pkg, m
         assert record_bound("a6+a8 windowed chain max-abs / |out|_inf, " + tag, np.abs(y - ref).max() / np.abs(ref).max(), 3e-7)
     else:
         assert _hold_gain_bars("a6+a8 windowed chain, " + tag, y, ref, mode, _chain_case_bits(mode, 2), gain_mode,
-                               1.0 / 50000.0 if gain_mode == 2 else 1.0, 3e-7, 8e-7, head=overlap, tail=overlap)
+                               1.0 / 50000.0 if gain_mode == 2 else 1.0, 3e-7, 5e-7, head=overlap, tail=overlap)
 
 
 @pytest.mark.parametrize("mode,overlap", [(1, 10), (1, 1), (1, 128), (2, 10), (2, 80), (3, 7), (3, 19), (4, 10)])
@@ -662,7 +672,7 @@ def test_chain_windowed_guard_with_fir_is_one_kernel_too(pkg, mode, overlap, chu
                             np.abs(y - ref).max() / np.abs(ref).max(), 5e-7)
     else:
         assert _hold_gain_bars("a6+a8+a9 windowed chain with FIR, " + tag, y, ref, mode, _chain_case_bits(mode, 2), gain_mode,
-                               1.0 / 50000.0 if gain_mode == 2 else 1.0, 6.2e-7, 1e-6, head=overlap, tail=overlap + 44)
+                               1.0 / 50000.0 if gain_mode == 2 else 1.0, 6.2e-7, 7e-7, head=overlap, tail=overlap + 44)
 
 
 def test_chain_windowed_guard_with_a_short_and_a_long_filter(pkg):
