@@ -193,7 +193,8 @@ def launch_ranks(n, argv, dry_run):
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DABGPU_BENCH_CHILD="1")
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), DABGPU_BENCH_CHILD="1",
+                   DABGPU_BENCH_PARENT=str(os.getpid()))
         env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + argv, env=env,
                                       stdout=None if r == 0 else sys.stderr))
@@ -221,6 +222,8 @@ def launch_ranks(n, argv, dry_run):
 def dry_run(args, streams):
     """--dry-run: the launcher, the process group (gloo when there is no GPU), the barrier-bracketed timing and the
     one-line contract with a sleep standing in for the kernels -- what the CPU tests exercise at N = 2."""
+    if os.environ.get("DABGPU_BENCH_FAIL_RANK") is not None and os.environ.get("DABGPU_BENCH_FAIL_RANK") == os.environ.get("RANK"):
+        raise SystemExit(3)        # (tests: a rank that dies before the rendezvous -- the launcher must end the others)
     grp = streams.StreamGroup(backend=os.environ.get("DABGPU_DIST_BACKEND", "gloo"))
     B = args.frames
     wall = grp.timed(lambda: time.sleep(0.01 * (1 + grp.rank)), args.steps, lambda: None)
@@ -322,10 +325,12 @@ def main():
         ns = md.out_samples_per_frame(stages)
         stream = torch.cuda.Stream(device=dev)
         with torch.cuda.stream(stream):
-            # synthetic hot-path input: uniform random bytes, resident in HBM
-            rs = np.random.RandomState(grp.stream_seed(42))
-            bits = np.frombuffer(rs.bytes(B * 28800), dtype=np.uint8).reshape(B, 28800)
-            d_bits = torch.from_numpy(bits.copy()).to(dev)
+            # synthetic hot-path input: uniform random bytes, a different stream per rank, generated ON the
+            # device -- eight ranks of 32768 frames would otherwise each draw 0.94 GB through numpy and stage it through
+            # pageable host memory (2 GB of host RAM and ~3 s per rank before the first launch)
+            gen = torch.Generator(device=dev)
+            gen.manual_seed(grp.stream_seed(42))
+            d_bits = torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device=dev, generator=gen)
             if from_bits:
                 d_in = d_bits
             else:

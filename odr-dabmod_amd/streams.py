@@ -93,8 +93,13 @@ class StreamGroup:
         cplx = t.is_complex()
         if cplx:
             t = torch.view_as_real(t)            # (RCCL has no complex element type: the same bytes as float pairs)
+        dev = t.device
+        if self.backend == "gloo" and dev.type != "cpu":
+            t = t.cpu()                          # (gloo gathers host tensors only: ranks that share a GPU in the tests)
         out = [torch.empty_like(t) for _ in range(self.world)] if self.rank == root else None
         dist.gather(t.contiguous(), out, dst=root)
+        if out is not None and out[0].device != dev:
+            out = [o.to(dev) for o in out]
         if out is not None and cplx:
             out = [torch.view_as_complex(o) for o in out]
         return out

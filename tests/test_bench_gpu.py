@@ -83,6 +83,25 @@ def test_bench_gpus_2_on_the_full_chain_of_config_5():
     assert abs(d["value"] - 2 * 128 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
 
 
+def test_bench_gpus_2_with_the_iq_gather_at_world_size_2():
+    """The optional final IQ gather (north_star; StreamGroup.gather_to_root) at world size 2 UNDER THE LAUNCHER: two ranks
+    on the one leased GPU, gloo (which gathers host tensors: the harness stages them), 8 frames per rank to rank 0 -- the
+    line carries iq_gather with ranks = 2 and the bytes of one rank's piece."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DABGPU_BENCH_DEVICES="0,0", DABGPU_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1",
+                        "--frames", "64", "--gather", "8", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0
+    g = d["iq_gather"]
+    assert g["ranks"] == 2 and g["frames_per_rank"] == 8 and g["bytes_per_rank"] == 8 * 196608 * 8
+    assert g["ms"] > 0 and g["GBps_into_rank0"] > 0
+
+
 def test_bench_gpus_beyond_the_node_fails_loudly():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DABGPU_BENCH_DEVICES")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,

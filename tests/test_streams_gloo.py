@@ -131,6 +131,60 @@ def test_bench_launches_n_ranks_itself_dry_run():
     assert d["config"]["devices"] == [0, 1]
 
 
+def _ranks_of_launcher(pid):
+    """Live processes that a bench.py launcher with this pid started (it marks its ranks' environment)."""
+    import psutil
+    found = []
+    for q in psutil.process_iter(["pid"]):
+        try:
+            if q.environ().get("DABGPU_BENCH_PARENT") == str(pid) and q.status() != psutil.STATUS_ZOMBIE:
+                found.append(q.pid)
+        except (psutil.Error, OSError):
+            pass
+    return found
+
+
+def test_bench_launches_eight_ranks_dry_run():
+    """The shape of the driver's largest scan point: `python bench.py --gpus 8` as its own launcher -- eight children, one
+    rendezvous port, ONE line (n_gpus = 8, value = eight ranks' frames over the slowest rank's time), every child gone
+    afterwards.  (--dry-run: the launcher, the gloo process group and the timing harness without a kernel; rank r sleeps
+    10 (1 + r) ms per step.)"""
+    import json
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    t0 = time.time()
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--dry-run", "--steps", "2",
+                          "--warmup", "1", "--frames", "32768"], env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out, err = p.communicate(timeout=600)
+    assert p.returncode == 0, err[-2000:]
+    lines = [l for l in out.splitlines() if l.strip()]
+    assert len(lines) == 1, out
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 2 and d["scaling"] == "weak"
+    assert d["config"]["devices"] == list(range(8)) and d["config"]["frames_per_step_per_gpu"] == 32768
+    # the slowest rank (rank 7) sleeps 80 ms per step
+    assert 0.08 * 2 <= d["ms_per_step"] * 2e-3 < 2.0
+    assert abs(d["value"] - 8 * 32768 * 2 / (d["ms_per_step"] * 2e-3)) / d["value"] < 1e-3
+    # teardown: no child of ours is left (the launcher reaps all eight before it returns)
+    assert not _ranks_of_launcher(p.pid)
+    assert time.time() - t0 < 300
+
+
+def test_bench_launcher_ends_the_other_ranks_when_one_fails():
+    """A rank that dies must not leave seven others waiting in a barrier: the launcher terminates them and returns the
+    failing status (DABGPU_BENCH_FAIL_RANK makes one dry-run rank exit before the rendezvous)."""
+    import time
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env["DABGPU_BENCH_FAIL_RANK"] = "3"
+    t0 = time.time()
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--dry-run", "--steps", "2"], env=env,
+                         stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out, err = p.communicate(timeout=300)
+    assert p.returncode != 0 and not out.strip()
+    assert time.time() - t0 < 120
+    assert not _ranks_of_launcher(p.pid)
+
+
 def test_bench_refuses_a_world_size_that_contradicts_gpus():
     env = dict(os.environ, WORLD_SIZE="4", RANK="0", LOCAL_RANK="0")
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--dry-run"], env=env,
