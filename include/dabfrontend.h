@@ -33,6 +33,12 @@ DABFE_API int dabfe_time_interleave(const uint8_t *in, size_t framesize, size_t 
  * frame (Mode I: 28 800 bytes = the hot path's input); returns the number of blocks */
 DABFE_API int dabfe_eti_frontend(const uint8_t *eti, size_t nframes, unsigned mode, uint8_t *out, size_t out_cap);
 
+/* A raw ETI(NI) byte stream through ONE EtiReader in pieces of `piece` bytes (the reader accepts input cut anywhere,
+ * src/EtiReader.cpp:93-284): the frame counters (FCT) of the headers it parsed, in order, into fct_out; *n_errors = calls that
+ * threw (a refused header), *n_short = calls that consumed less than they were given.  Returns the number of headers. */
+DABFE_API int dabfe_eti_reader_stream(const uint8_t *bytes, size_t n, size_t piece, unsigned *fct_out, size_t fct_cap,
+                                      size_t *n_errors, size_t *n_short);
+
 #ifdef __cplusplus
 }
 #endif

@@ -9,7 +9,7 @@ import numpy as np
 _HOST = os.path.join(os.path.dirname(os.path.abspath(__file__)), "host")
 LIB_PATH = os.path.join(_HOST, "libdabfrontend.so")
 EXPORTS = ["dabfe_prbs", "dabfe_conv_encode", "dabfe_subchannel_profile", "dabfe_puncture",
-           "dabfe_time_interleave", "dabfe_eti_frontend"]
+           "dabfe_time_interleave", "dabfe_eti_frontend", "dabfe_eti_reader_stream"]
 _U8P = C.POINTER(C.c_uint8)
 _lib = None
 
@@ -30,6 +30,9 @@ def bind(lib, prefix):
     g("puncture").argtypes = [_U8P, C.c_size_t, C.c_uint, C.c_uint, C.c_int, C.c_uint, _U8P]
     g("time_interleave").argtypes = [_U8P, C.c_size_t, C.c_size_t, _U8P]
     g("eti_frontend").argtypes = [_U8P, C.c_size_t, C.c_uint, _U8P, C.c_size_t]
+    if hasattr(lib, prefix + "eti_reader_stream"):          # (the product library; the reference harness has no such view)
+        g("eti_reader_stream").argtypes = [_U8P, C.c_size_t, C.c_size_t, C.POINTER(C.c_uint), C.c_size_t,
+                                           C.POINTER(C.c_size_t), C.POINTER(C.c_size_t)]
     return lib
 
 
@@ -100,6 +103,18 @@ class Frontend:
         if self._f("time_interleave")(fp, f.shape[1], f.shape[0], out.ctypes.data_as(_U8P)) < 0:
             raise ValueError("TimeInterleaver failed")
         return out
+
+    def eti_reader_stream(self, data, piece):
+        """A raw ETI byte stream through one EtiReader, `piece` bytes per call -> (frame counters of the headers it parsed,
+        calls that threw, calls that consumed less than they were given)."""
+        d, dp = self._u8(data)
+        d = d.reshape(-1)
+        fct = (C.c_uint * (d.size // 6144 + 8))()
+        ne, ns = C.c_size_t(), C.c_size_t()
+        n = self._f("eti_reader_stream")(dp, d.size, piece, fct, len(fct), C.byref(ne), C.byref(ns))
+        if n < 0:
+            raise ValueError("EtiReader stream failed")
+        return [int(fct[i]) for i in range(min(n, len(fct)))], int(ne.value), int(ns.value)
 
     def eti_to_bits(self, eti, mode=1):
         """eti: (nframes, 6144) uint8 -> (n_tf, block) uint8 hot-path input blocks."""

@@ -359,20 +359,33 @@ int EtiReader::loadEtiData(const Buffer &dataIn)
     while (left > 0) {
         switch (m_state) {
             case State::Sync:                                  // ERR + FSYNC
-                if (left < 4) return static_cast<int>(dataIn.getLength() - left);
                 if (m_resync) {
-                    // after a refused frame the stream position is no longer known to be a frame start (a caller that
-                    // feeds pieces not aligned to frames): look for ERR = 0xFF followed by one of the two FSYNC words
-                    // (src/Eti.h:50-61, doc/README-Fileinput) instead of taking the next four bytes on trust
-                    const bool sync = in[0] == 0xFF && ((in[1] == 0x07 && in[2] == 0x3A && in[3] == 0xB6) ||
-                                                         (in[1] == 0xF8 && in[2] == 0xC5 && in[3] == 0x49));
-                    if (!sync) {
+                    // After a refused frame whose end could not be located (below), the stream position is not known to
+                    // be a frame start: look for one of the two FSYNC words (src/Eti.h:50-61, doc/README-Fileinput)
+                    // instead of taking the next four bytes on trust.  The ERR byte in front of it is NOT tested -- a
+                    // multiplexer may mark its frames with an error level other than 0xFF, and such a stream must lock
+                    // again --, and a candidate is confirmed, whenever this buffer reaches that far, by the OTHER FSYNC
+                    // word 6144 bytes later (the two alternate): four payload bytes that happen to spell FSYNC do not
+                    // lock the reader onto payload.  Bytes that cannot start a frame are consumed, including a tail
+                    // shorter than a sync word: a caller that treats "consumed < length" as a read error sees none.
+                    auto fsync = [](const uint8_t *p) {
+                        return (p[1] == 0x07 && p[2] == 0x3A && p[3] == 0xB6) ? 1 : (p[1] == 0xF8 && p[2] == 0xC5 && p[3] == 0x49) ? 2 : 0;
+                    };
+                    if (left < 4) { in += left; left = 0; break; }
+                    const int k = fsync(in);
+                    bool lock = k != 0;
+                    if (lock && left >= 6144 + 4) {
+                        const int k2 = fsync(in + 6144);
+                        lock = k2 != 0 && k2 != k;
+                    }
+                    if (!lock) {
                         ++in;
                         --left;
                         break;
                     }
                     m_resync = false;
                 }
+                if (left < 4) return static_cast<int>(dataIn.getLength() - left);
                 m_remaining = 6144;
                 take(4);
                 m_state = State::Fc;
@@ -417,9 +430,15 @@ int EtiReader::loadEtiData(const Buffer &dataIn)
                         // beyond it (a caller feeding a byte stream in pieces) is skipped as padding, so that the
                         // next frame start is a real one and its payload is never parsed as FC / STC.
                         const size_t beyond = m_remaining > left ? m_remaining - left : 0;
+                        // Is the NEXT call's first byte a frame start?  Yes when the offending frame ends inside this buffer
+                        // and what follows it here is a whole number of frames -- the frame-aligned caller (one frame, or n
+                        // frames, per call: the reference's own loop, src/DabMod.cpp:605-724), who keeps the reference's
+                        // behaviour of taking frame starts on trust.  Otherwise alignment is lost (the tail of this buffer
+                        // is dropped in mid-frame) and the next frame start is searched for.
+                        const bool aligned = beyond == 0 && (left - m_remaining) % 6144 == 0;
                         m_remaining = beyond;
                         m_state = beyond ? State::Pad : State::Sync;
-                        m_resync = true;                       // (the next frame start is searched for, not assumed)
+                        m_resync = !aligned;
                         m_stc.clear();
                         mySources.clear();
                         throw std::runtime_error("EtiReader: stream characterisation exceeds the 6144-byte ETI frame");

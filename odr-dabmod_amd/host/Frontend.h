@@ -157,7 +157,7 @@ private:
     enum class State { Sync, Fc, Nst, Eoh, Fic, Subch, Eof, Tist, Pad };
     State m_state = State::Sync;
     size_t m_remaining = 0;                    // bytes of the 6144-byte frame not yet consumed
-    bool m_resync = false;                     // after a refused frame: State::Sync searches for ERR + FSYNC
+    bool m_resync = false;                     // after a refused frame that lost the alignment: State::Sync searches for FSYNC
     bool m_fc_valid = false;
     unsigned m_fct = 0, m_ficf = 0, m_nst = 0, m_fp = 0, m_mid = 0;
     std::vector<uint8_t> m_stc;                // raw STC words of the current layout

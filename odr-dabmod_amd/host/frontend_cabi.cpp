@@ -104,4 +104,40 @@ int dabfe_eti_frontend(const uint8_t *eti, size_t nframes, unsigned mode, uint8_
     } catch (const std::exception &) { return -1; }
 }
 
+int dabfe_eti_reader_stream(const uint8_t *bytes, size_t n, size_t piece, unsigned *fct_out, size_t fct_cap,
+                            size_t *n_errors, size_t *n_short)
+{
+    // ONE EtiReader fed `piece` bytes at a time; after every call the frame counter of the header parsed last is noted
+    // whenever it changed: the sequence of frames the reader locked onto
+    if (!bytes || !piece) return -1;
+    double off = 0.0;
+    EtiReader rd(off);
+    size_t nf = 0, errors = 0, shorts = 0;
+    int last = -1;
+    for (size_t pos = 0; pos < n;) {
+        const size_t len = std::min(piece, n - pos);
+        int used;
+        try {
+            used = rd.loadEtiData(Buffer(len, bytes + pos));
+        } catch (const std::exception &) {
+            ++errors;
+            pos += len;                      // (the exception drops the rest of this buffer)
+            continue;
+        }
+        if ((size_t)used != len) ++shorts;
+        pos += used > 0 ? (size_t)used : len;
+        try {
+            const int fct = (int)rd.getFct();
+            if (fct != last) {
+                if (nf < fct_cap && fct_out) fct_out[nf] = (unsigned)fct;
+                ++nf;
+                last = fct;
+            }
+        } catch (const std::exception &) {}
+    }
+    if (n_errors) *n_errors = errors;
+    if (n_short) *n_short = shorts;
+    return (int)nf;
+}
+
 }  // extern "C"

@@ -114,6 +114,50 @@ def test_frontend_refuses_a_header_whose_subchannels_overrun_the_frame(fe_mod):
     assert fe.eti_to_bits(synth_eti(8, subchannels=((0, 48, 0x22), (100, 48, 0x22))), 1).shape[0] == 2
 
 
+def _bad_header(eti, which):
+    """Make frame `which` claim 2 x 3840 bytes of sub-channel data (more than a 6144-byte frame holds)."""
+    f = eti[which]
+    for i in range(2):
+        f[8 + 4 * i + 2] = (0x22 << 2) | (480 >> 8)
+        f[8 + 4 * i + 3] = 480 & 0xFF
+
+
+def test_eti_reader_relocks_after_a_refused_frame(fe_mod):
+    """What happens AFTER the reader refuses a header (advisor, round 4).  (i) A frame-aligned caller -- one frame per
+    call, the reference's own loop -- loses exactly the bad frame, also when the stream's ERR byte is not 0xFF (frame
+    starts are taken on trust, like the reference).  (ii) A caller that feeds pieces which do not line up with frames
+    loses its alignment with the dropped buffer: the reader then searches for FSYNC whatever ERR says, is not fooled by four
+    payload bytes that spell a sync word (the candidate is confirmed by the OTHER sync word 6144 bytes on), consumes
+    every byte it is given while it searches, and is back on the stream within two frames."""
+    fe = fe_mod.Frontend()
+    sub = ((0, 48, 0x22), (100, 48, 0x22))
+    for err_byte in (0xFF, 0x00):
+        eti = synth_eti(12, subchannels=sub)
+        eti[:, 0] = err_byte                                         # ERR: error level marking of the multiplexer
+        _bad_header(eti, 4)
+        # (i) frame-aligned, one and three frames per call
+        for piece in (6144, 3 * 6144):
+            fct, errors, short = fe.eti_reader_stream(eti, piece)
+            assert errors == 1 and short == 0
+            # (the view notes the header parsed LAST in every call that returned; the call that threw is dropped whole)
+            assert fct == ([0, 1, 2, 3, 5, 6, 7, 8, 9, 10, 11] if piece == 6144 else [2, 8, 11]), (piece, fct)
+        # (ii) pieces of 20000 bytes: the piece [20000, 40000) holds the whole bad frame, the exception drops its tail, and
+        # the next call starts in the middle of frame 6 -- with a false sync word planted in what is left of frame 6 (its
+        # partner 6144 bytes on, in frame 7, is payload: rejected).  The reader finds frame 7 and reads on: the last headers
+        # of the four calls are frames 3, (dropped), 9, 11.
+        eti[6, 4000:4004] = (err_byte, 0x07, 0x3A, 0xB6)
+        fct, errors, short = fe.eti_reader_stream(eti, 20000)
+        assert errors == 1 and fct == [3, 9, 11], fct
+        # pieces of 1000 bytes: the bad frame's end is known (it lies beyond the piece that threw), nothing but frame 4 is lost
+        fct, errors, short = fe.eti_reader_stream(eti, 1000)
+        assert errors == 1 and fct == list(range(12)), fct           # (frame 4's header is parsed before its layout is refused)
+    # a clean stream in awkward pieces: nothing is lost, nothing is left unconsumed except across field boundaries
+    clean = synth_eti(10, subchannels=sub)
+    for piece in (1000, 6143, 6145, 10000):          # (a piece must hold the largest field: 768 bytes of sub-channel data)
+        fct, errors, short = fe.eti_reader_stream(clean, piece)
+        assert fct == list(range(10)) and errors == 0
+
+
 def test_frontend_mode_zero_is_rejected_like_dabmodulator_setmode(fe_mod):
     """DabModulator::process builds the flowgraph with setMode(dabMode), which throws for 0
     (src/DabModulator.cpp:131-133, :119-121)."""
