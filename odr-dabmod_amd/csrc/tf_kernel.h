@@ -144,7 +144,7 @@ void tf_kernel(const TfArgs a)
     float *g_l = reinterpret_cast<float *>(eq_d + 48);
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : (FIR && !WIN) ? 4 * KB : ((WIN && !FIR) ? 7 * kWinMax : 0)));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
-    constexpr int kBitStride = kBitWords + 1;     // + one dummy slot per half
+    constexpr int kBitStride = kBitWords + 2;     // + one dummy slot per half (and one more: the halves stay 8-byte aligned)
     // small read-only tables copied to LDS once: read through global memory they compile to
     // vector loads (the output stores may alias them), and every such load drags an
     // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
@@ -229,6 +229,7 @@ void tf_kernel(const TfArgs a)
         for (int m = 0; m < 8; ++m) hk8[m] = a.t.fir_h[tt + T * m];
     }
     int bitpos[6];
+    unsigned bsh[6] = {0u, 0u, 0u, 0u, 0u, 0u};   // bitpos ^ 7: the symbol loop's form of it (see advance)
     // differential state of the lane's carriers, without the
     // "+1 eighth" every data block adds to every carrier: phase of symbol s = 2 q_c + s - 1 eighths.
     // Kept as six 4-bit fields of ONE register, in quarter turns (every increment is an even number of eighths): the
@@ -244,6 +245,7 @@ void tf_kernel(const TfArgs a)
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
             bitpos[c] = a.t.src_carrier[kpos[c]];
+            bsh[c] = (unsigned)bitpos[c] ^ 7u;
             P |= ((unsigned)a.t.phase_q[kpos[c]] & 3u) << fpos[c];
         }
     }
@@ -282,22 +284,24 @@ void tf_kernel(const TfArgs a)
         }
     };
 
-    // advance the differential state over one data block (K/4 bytes: I bits, then Q bits)
-    // held in LDS or in global memory; the 12 byte reads are issued together
-    auto advance = [&](const uint8_t *blk) __attribute__((always_inline)) {
-        unsigned ib[6], qb[6];
+    // advance the differential state over one data block (K/4 bytes: I bits, then Q bits) staged in LDS.
+    // The block is staged DWORD-INTERLEAVED (round 5): dword j of the I half at slot 2 j, dword j of the Q half at slot
+    // 2 j + 1 (the lane that fetched a dword simply parks it at another address: bit_slot), so the I and the Q bit of a
+    // carrier arrive in ONE 8-byte read -- six ds_read_b64 per lane and symbol where the byte layout took twelve
+    // ds_read_u8, whose 2 x 32-lane groups hit two dwords of one bank in almost every instruction (the 48 dwords of a
+    // half block over 32 banks; 11 % of the LDS cycles of the cfg 3 kernel were bank conflicts, all of them here).  Bit of
+    // carrier n inside its dword: byte (n >> 3) & 3, bit 7 - (n & 7) of it = (n & 31) ^ 7 -- v_bfe_u32 reads the low five
+    // bits of its offset operand, so n ^ 7 (bsh) serves as it is, and bits 5 ... of it are the dword index.
+    auto advance = [&](const uint32_t *blk) __attribute__((always_inline)) {
+        uint2 w[6];
 #pragma unroll
-        for (int c = 0; c < 6; ++c) {
-            const int bp = bitpos[c];
-            ib[c] = blk[bp >> 3];
-            qb[c] = blk[(K >> 3) + (bp >> 3)];
-        }
+        for (int c = 0; c < 6; ++c)
+            w[c] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(blk) + (__builtin_amdgcn_ubfe(bsh[c], 5u, 6u) << 3));
         unsigned I = 0u, Q = 0u;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            const unsigned sh = 7u - ((unsigned)bitpos[c] & 7u);
-            I |= __builtin_amdgcn_ubfe(ib[c], sh, 1u) << fpos[c];
-            Q |= __builtin_amdgcn_ubfe(qb[c], sh, 1u) << fpos[c];
+            I |= __builtin_amdgcn_ubfe(w[c].x, bsh[c], 1u) << fpos[c];
+            Q |= __builtin_amdgcn_ubfe(w[c].y, bsh[c], 1u) << fpos[c];
         }
         // (I, Q) = 00 -> 0, 10 -> 1, 11 -> 2, 01 -> 3 quarter turns, in every field at once; the guard bits absorb the carry
         P = (P + ((I ^ Q) | (Q << 1))) & 0x333333u;
@@ -311,7 +315,8 @@ void tf_kernel(const TfArgs a)
         const int dd = min(max(d, 0), G::nb_symbols - 2);
         return reinterpret_cast<const uint32_t *>(fbits + (size_t)dd * (size_t)(K / 4))[t < kBitWords ? t : 0];
     };
-    const int bit_slot = t < kBitWords ? t : kBitWords;   // kBitWords = dummy slot
+    // (I dword j -> slot 2 j, Q dword j -> slot 2 j + 1; kBitWords = dummy slot)
+    const int bit_slot = t < kBitWords / 2 ? 2 * t : (t < kBitWords ? 2 * (t - kBitWords / 2) + 1 : kBitWords);
 
     // the lane's 6 active carriers of symbol s
     // MAG_IN_GAIN (the equalised-boundary variant with GainControl: every sample of the symbol is scaled by g after the
@@ -787,7 +792,7 @@ void tf_kernel(const TfArgs a)
         uint32_t pf = 0u;
         if (FROM_BITS) {
             lds_barrier();                    // bitbuf[bb] written (prologue / previous iteration)
-            if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
+            if (s >= 2) advance(bitbuf + bb * kBitStride);
             pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
             load_active(s, val);
             if (GAIN && !CFR && a.gain.mode == 2) {

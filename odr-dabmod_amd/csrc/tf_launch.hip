@@ -25,7 +25,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     const bool wf = (flags & TF_WINDOW) && (flags & TF_FIR);
     if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter
     else if ((flags & TF_FIR) && !wf) b += 4 * (nt ? nt - 1 : kBnd) * sizeof(float2);  // 2 x [tail | next head]
-    if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 1) * sizeof(uint32_t);  // staged coded bits
+    if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 2) * sizeof(uint32_t);  // staged coded bits (kBitStride)
     b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
     b += 56 * sizeof(float2);                                      // twiddles of the stride-8 stage
     if (flags & TF_CFR) b += 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red

@@ -217,6 +217,40 @@ def parts(argv):
     md.close()
 
 
+def cfg3power(argv):
+    """cfg 3 (or cfg3 + option) at B frames per launch with board power: one arm of an A/B over libraries
+    (DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/exp_r05.py cfg3power [B] [cfr|nofir|window] [tag])."""
+    B = int(argv[0]) if argv else 32768
+    option = argv[1] if len(argv) > 1 and argv[1] != "-" else None
+    tag = argv[2] if len(argv) > 2 else os.path.basename(os.environ.get("DABGPU_LIB", "product"))
+    st = torch.cuda.Stream(device=dev)
+    probe = PowerProbe(0)
+    md = P.Modulator(mode=1, device=0, max_frames=B)
+    md.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+    if option == "cfr":
+        md.set_cfr(True, 50.0, 0.1)
+    elif option == "window":
+        md.set_window_overlap(10)
+    stages = P.STAGE_GAIN | (0 if option == "nofir" else P.STAGE_FIR)
+    with torch.cuda.stream(st):
+        bits = torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device=dev)
+        out = torch.empty((B, 196608), dtype=torch.complex64, device=dev)
+    step = lambda: md.chain_dev(bits, B, stages, out, stream=st.cuda_stream)
+    for _ in range(5):
+        step()
+    st.synchronize()
+    for rep in range(2):
+        ms = min(event_time(st, step, 10) for _ in range(2))
+        fps = B / (ms * 1e-3)
+        pw = sample_load(step, 3.0, ms, st, probe=probe)
+        rec = dict(exp="cfg3power", lib=tag, option=option, frames_per_call=B, ms_per_call=round(ms, 4), frames_per_s=round(fps, 1),
+                   roofline_frac=round(ALGO3 * fps / 8e12, 4))
+        if pw and "watts_avg" in pw:
+            rec.update(watts=pw["watts_avg"], sclk_MHz=pw["sclk_MHz_avg"], mJ_per_frame=round(1e3 * pw["watts_avg"] / fps, 4))
+        emit(**rec)
+    md.close()
+
+
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "lanes"
-    {"lanes": lanes, "handover": handover, "rsonly": rsonly, "tfonly": tfonly, "parts": parts}[what](sys.argv[2:])
+    {"lanes": lanes, "handover": handover, "rsonly": rsonly, "tfonly": tfonly, "parts": parts, "cfg3power": cfg3power}[what](sys.argv[2:])
