@@ -461,6 +461,38 @@ def main():
         torch.cuda.empty_cache()
         return res
 
+    def other_mode(mode, b, steps):
+        """The cfg 3 chain (coded bits -> ... -> GainControl(var) -> guard -> FIRFilter) in transmission mode II / III / IV
+        (src/DabModulator.cpp:84-122): these run the generic frame kernels (radix-8 stages + a radix-4/2 tail for N = 512 /
+        256 / 1024), not the Mode I specialisations.  Frames per second of THAT mode's frames (24 / 24 / 48 ms of air time),
+        and its own algorithmic bytes per frame."""
+        md = P.Modulator(mode=mode, device=local_rank, max_frames=b, chunks_per_frame=args.chunks)
+        md.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        stages = P.STAGE_GAIN | P.STAGE_FIR
+        nin, ns = md.geometry["tf_input_bytes"], md.out_samples_per_frame(stages)
+        st = torch.cuda.Stream(device=dev)
+        with torch.cuda.stream(st):
+            d_bits = torch.randint(0, 256, (b, nin), dtype=torch.uint8, device=dev)
+            d_out = torch.empty((b, ns), dtype=torch.complex64, device=dev)
+            for _ in range(3):
+                md.chain_dev(d_bits, b, stages, d_out, stream=st.cuda_stream)
+            st.synchronize()
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record(st)
+            for _ in range(steps):
+                md.chain_dev(d_bits, b, stages, d_out, stream=st.cuda_stream)
+            e1.record(st)
+            st.synchronize()
+        ms = e0.elapsed_time(e1) / steps
+        md.close()
+        del d_bits, d_out
+        torch.cuda.empty_cache()
+        algo_b = nin + 8 * ns
+        fps = b / (ms * 1e-3)
+        return {"frames_per_s": round(fps, 2), "frames_per_step": b, "algorithmic_bytes_per_frame": algo_b,
+                "achieved_GBps": round(algo_b * fps / 1e9, 2), "roofline_frac": round(algo_b * fps / 1e9 / HBM_PEAK_GBPS, 4),
+                "frame_ms_of_air_time": {2: 24, 3: 24, 4: 48}[mode], "kernel": "generic tf_kernel<logn=%d>" % {2: 9, 3: 8, 4: 10}[mode]}
+
     B = args.frames
     gather_info = {}
     wall, kern_ms = run_workload(args.workload, B, args.steps, args.warmup,
@@ -717,6 +749,13 @@ def main():
                                 extra[wl]["counters_source"] = "live collection failed (%s)" % why4
                 except Exception as ex:  # secondary numbers must never break the contract line
                     extra[wl] = {"error": str(ex)[:200]}
+            if args.workload == "cfg3":
+                for mode in (2, 3, 4):
+                    try:
+                        # (the same 51.5 GB of IQ per step as the Mode I headline: frames are a quarter / a half as long)
+                        extra["cfg3_mode%d" % mode] = other_mode(mode, min(B, 16384) * (2 if mode == 4 else 4), max(3, args.steps // 4))
+                    except Exception as ex:
+                        extra["cfg3_mode%d" % mode] = {"error": str(ex)[:200]}
             line["other_workloads"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)

@@ -314,3 +314,24 @@ def test_set_lanes_and_handover_arguments(pkg):
         md.set_handover_frames(64)
     finally:
         md.close()
+
+
+def test_chain_out_buffer_must_be_the_callers_memory(pkg):
+    """Modulator.chain(out=...): a non-contiguous or mistyped reuse buffer is refused BEFORE any reshape could silently copy
+    it (advisor, round 4: the result used to land in the copy and the caller's buffer stayed empty)."""
+    md = pkg.Modulator(mode=2, max_frames=2)
+    try:
+        md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=4100 + i) for i in range(2)])
+        ns = md.out_samples_per_frame(3)
+        good = np.zeros((2, ns), np.complex64)
+        y = md.chain(bits, 3, out=good)
+        assert np.shares_memory(y, good) and np.abs(good).max() > 0
+        wide = np.zeros((2, 2 * ns), np.complex64)
+        for bad in (wide[:, ::2], np.zeros((2, ns), np.complex128), np.zeros((2, ns + 1), np.complex64)):
+            with pytest.raises(pkg.DabGpuError, match="output buffer does not match"):
+                md.chain(bits, 3, out=bad)
+        assert np.abs(wide).max() == 0
+    finally:
+        md.close()
