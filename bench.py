@@ -701,12 +701,14 @@ def main():
                 try:
                     base = wl.split("_B")[0].replace("_s16", "").replace("_cfr", "").replace("_window", "").replace("_nofir", "")
                     option = wl.rsplit("_", 1)[1] if wl.endswith(("_cfr", "_window", "_nofir")) else None
-                    k = max(3, args.steps // 4) if b2 > 256 else (400 if b2 <= 16 else 100)
+                    # (small batches: regions of 30 ... 80 ms -- a region of a few milliseconds right after a synchronisation
+                    #  is spent in the clock's ramp from idle and under-reports by a third)
+                    k = max(3, args.steps // 4) if b2 > 256 else (3000 if b2 <= 16 else 800)
                     # B = 1 / 16 / 256: ONE context, its own stream, the library's lanes (SMALL_BATCH_LANES); "_one_lane":
                     # the same calls in order on one stream (what rounds 1-4 reported under these names)
                     small = "_B" in wl
                     nl = 0 if not small else (1 if wl.endswith("_one_lane") else SMALL_BATCH_LANES)
-                    w2, k2 = run_workload(base, b2, k, 2 * k if small else 1, fmt="s16" if wl.endswith("_s16") else None,
+                    w2, k2 = run_workload(base, b2, k, k if small else 1, fmt="s16" if wl.endswith("_s16") else None,
                                           option=option, power_seconds=3.0 if wl in ("cfg4", "cfg2", "cfg3_nofir") else 0.0,
                                           lanes=nl, repeats=5 if small else 1)
                     algo2 = ALGO_BYTES[base] if not wl.endswith("_s16") else \
@@ -718,7 +720,7 @@ def main():
                         extra[wl].update({"contexts": 1, "lanes": nl, "us_per_call": round(k2 * 1e3, 2),
                                           "timing": "HIP events on the caller's stream around %d calls on the context's own "
                                                     "stream, ordered by dabgpu_wait_for_stream / dabgpu_stream_wait_for; "
-                                                    "median of 5 such regions after %d warm-up calls" % (k, 2 * k + PREWARM)})
+                                                    "median of 5 such regions after %d warm-up calls" % (k, k + PREWARM)})
                     pw2 = power_of.get((base, option, "s16" if wl.endswith("_s16") else None, b2)) \
                         if wl in ("cfg4", "cfg2", "cfg3_nofir") else None
                     if pw2:
