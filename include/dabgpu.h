@@ -284,6 +284,13 @@ DABGPU_API int dabgpu_post_process_dev(dabgpu_ctx *ctx, const void *d_native, si
  *     Do not mix the two on one context without a dabgpu_synchronize in between.
  * dabgpu_set_lanes: 1 ... 4 (default 3: measured best at 1 ... 64 frames per call, tools/exp_r05.py lanes; 1 = every call on the one context stream, in order).  Waits for the context. */
 DABGPU_API int dabgpu_set_lanes(dabgpu_ctx *ctx, int lanes);
+/* Diagnostic: how many lanes exist so far (lane 0 = the context's stream, the others are created on first use), and in
+ * *own_queue_mask, bit i: lane i was found a hardware queue of its own.  (The HIP runtime multiplexes streams onto a few
+ * hardware queues, four by default -- GPU_MAX_HW_QUEUES --, and streams that share one run in order; which queue a new
+ * stream joins depends on the process's history, so a lane's stream is probed against the lanes before it and replaced
+ * until it overlaps with all of them.  A process that keeps more busy streams of its own than the device has hardware
+ * queues left cannot be given that.) */
+DABGPU_API int dabgpu_debug_lanes(dabgpu_ctx *ctx, int *own_queue_mask);
 /* everything the context queues from now on starts after what `stream` holds now */
 DABGPU_API int dabgpu_wait_for_stream(dabgpu_ctx *ctx, void *stream);
 /* everything queued on `stream` from now on starts after what the context has queued so far, on every lane */

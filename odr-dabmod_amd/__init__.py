@@ -35,7 +35,7 @@ EXPORTS = [
     "dabgpu_set_output_format", "dabgpu_get_num_clipped", "dabgpu_fir_inverse_design",
     "dabgpu_set_fir_boundary_mode", "dabgpu_debug_last_variant", "dabgpu_debug_trace",
     "dabgpu_set_lanes", "dabgpu_wait_for_stream", "dabgpu_stream_wait_for", "dabgpu_set_handover_frames",
-    "dabgpu_post_process_dev",
+    "dabgpu_post_process_dev", "dabgpu_debug_lanes",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -146,6 +146,7 @@ def load_library():
     lib.dabgpu_get_num_clipped.argtypes = [vp, szp]
     lib.dabgpu_set_lanes.argtypes = [vp, C.c_int]
     lib.dabgpu_set_handover_frames.argtypes = [vp, C.c_int]
+    lib.dabgpu_debug_lanes.argtypes = [vp, C.POINTER(C.c_int)]
     lib.dabgpu_wait_for_stream.argtypes = [vp, vp]
     lib.dabgpu_stream_wait_for.argtypes = [vp, vp]
     lib.dabgpu_post_process_dev.argtypes = [vp, vp, sz, u, vp, sz, szp, vp]
@@ -484,6 +485,14 @@ class Modulator:
     def set_lanes(self, lanes):
         """Internal HIP streams that calls on the context's own stream rotate over (1 ... 4, default 3)."""
         self._chk(self._lib.dabgpu_set_lanes(self._h, int(lanes)))
+
+    def lanes_info(self):
+        """(lanes created so far, [lane i has a hardware queue of its own])."""
+        m = C.c_int()
+        n = self._lib.dabgpu_debug_lanes(self._h, C.byref(m))
+        if n < 0:
+            raise DabGpuError(self._lib.dabgpu_last_error(self._h).decode())
+        return n, [bool(m.value >> i & 1) for i in range(n)]
 
     def set_handover_frames(self, frames):
         """FIRFilter -> Resampler hand-over in pieces of `frames` frames through a cache-resident ring (0: one piece)."""

@@ -193,6 +193,7 @@ struct dabgpu_ctx {
     };
     enum { kMaxLanes = 4, kLaneMaxFrames = 2048 };
     Lane lane[kMaxLanes];                 // (entry 0: only `ev` is used)
+    bool lane_own_queue[kMaxLanes] = {true, false, false, false};   // the probe found the lane a hardware queue of its own
     int n_lanes = 3;
     unsigned long long lane_seq = 0;
     int clip_lane = 0, cfr_last_lane = 0; // whose scratch holds the clip count / the CFR statistics of the most recent call
@@ -253,11 +254,67 @@ int hip_fail(dabgpu_ctx *c, hipError_t e, const char *what)
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr);                                 \
     } while (0)
 
-// the stream of lane i (created on first use; lane 0 is the context's stream)
+// Lanes must sit on DIFFERENT hardware queues to overlap at all.  The HIP runtime multiplexes its streams onto a few
+// hardware queues (four by default), a new stream joining the queue that has the fewest at that moment -- so whether
+// three streams created in a row end up on three queues depends on every stream the process has created and destroyed
+// before (measured: 16-frame calls on three lanes take 8.9 us each when they do and 13.5 us when two of them share a
+// queue, which is in-order; tools/_variants history in profiles/r05_lane_queues.txt).  Nothing in the API tells which
+// queue a stream is on, but it shows: a 200 us spin on one stream delays a no-op on the other exactly when they share
+// one.  A lane's stream is therefore PROBED against the lanes before it when it is created, and candidates that share
+// a queue with one of them are set aside (kept alive until the lane is settled, so that the next candidate goes
+// elsewhere) and destroyed afterwards.  Once per lane and context, ~0.3 ms per probe.
+__global__ void lane_probe_spin(unsigned long long ticks)
+{
+    const unsigned long long t0 = wall_clock64();                 // (constant-rate counter, 100 MHz)
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void lane_probe_nop() {}
+
+// do kernels on a and b overlap?  (false also on any error: the caller then simply keeps what it has)
+bool streams_overlap(hipStream_t a, hipStream_t b)
+{
+    hipEvent_t ea = nullptr, eb = nullptr;
+    bool overlap = false;
+    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess &&
+        hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess &&
+        hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess) {
+        hipLaunchKernelGGL(lane_probe_spin, dim3(1), dim3(64), 0, a, 20000ull);      // 200 us
+        (void)hipEventRecord(ea, a);
+        hipLaunchKernelGGL(lane_probe_nop, dim3(1), dim3(64), 0, b);
+        (void)hipEventRecord(eb, b);
+        if (hipEventSynchronize(eb) == hipSuccess) overlap = hipEventQuery(ea) == hipErrorNotReady;
+        (void)hipEventSynchronize(ea);
+        (void)hipGetLastError();
+    }
+    if (ea) (void)hipEventDestroy(ea);
+    if (eb) (void)hipEventDestroy(eb);
+    return overlap;
+}
+
+// the stream of lane i (created on first use, lanes 1 .. i in order; lane 0 is the context's stream)
 int lane_stream(dabgpu_ctx *c, int i, hipStream_t *out)
 {
     if (i == 0) { *out = c->stream; return DABGPU_OK; }
-    if (!c->lane[i].stream) HIPCHK(c, hipStreamCreateWithFlags(&c->lane[i].stream, hipStreamNonBlocking));
+    for (int k = 1; k <= i; ++k) {
+        if (c->lane[k].stream) continue;
+        std::vector<hipStream_t> aside;
+        hipStream_t pick = nullptr;
+        bool own = false;
+        for (int tries = 0; tries < 12 && !pick; ++tries) {
+            hipStream_t cand = nullptr;
+            HIPCHK(c, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
+            bool ok = true;
+            for (int j = 0; j < k && ok; ++j) ok = streams_overlap(j ? c->lane[j].stream : c->stream, cand);
+            if (ok) { pick = cand; own = true; } else aside.push_back(cand);
+        }
+        if (!pick) {                              // no queue to itself (fewer hardware queues than lanes): any stream will do
+            pick = aside.back();
+            aside.pop_back();
+        }
+        for (hipStream_t st : aside) (void)hipStreamDestroy(st);
+        c->lane[k].stream = pick;
+        c->lane_own_queue[k] = own;
+    }
     *out = c->lane[i].stream;
     return DABGPU_OK;
 }
@@ -1912,6 +1969,16 @@ int dabgpu_set_lanes(dabgpu_ctx *c, int lanes)
     c->n_lanes = lanes;
     c->lane_seq = 0;
     return DABGPU_OK;
+}
+
+int dabgpu_debug_lanes(dabgpu_ctx *c, int *own_queue_mask)
+{
+    CTXCHK(c);
+    int n = 1, mask = 1;
+    for (int i = 1; i < (int)dabgpu_ctx::kMaxLanes; ++i)
+        if (c->lane[i].stream) { ++n; if (c->lane_own_queue[i]) mask |= 1 << i; }
+    if (own_queue_mask) *own_queue_mask = mask;
+    return n;
 }
 
 int dabgpu_set_handover_frames(dabgpu_ctx *c, int frames)

@@ -335,3 +335,27 @@ def test_chain_out_buffer_must_be_the_callers_memory(pkg):
         assert np.abs(wide).max() == 0
     finally:
         md.close()
+
+
+def test_lanes_get_hardware_queues_of_their_own_whatever_came_before(pkg):
+    """The HIP runtime puts a new stream on whichever of its (four) hardware queues holds the fewest, so three streams created
+    in a row share queues or not depending on the process's history -- and lanes that share one run in order.  Lane streams
+    are probed and replaced until they overlap with one another: after contexts have come and gone in uneven numbers, a
+    fresh context still reports a queue of its own for each of its three lanes."""
+    import torch
+    junk = [torch.cuda.Stream() for _ in range(5)]                    # an uneven number of other streams in the process
+    for n in (1, 2, 3, 2):
+        md = pkg.Modulator(mode=1, max_frames=2)
+        try:
+            md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_lanes(3)
+            d_bits = torch.zeros((2, 28800), dtype=torch.uint8, device="cuda")
+            d_out = torch.zeros((2, 196608), dtype=torch.complex64, device="cuda")
+            for _ in range(2 * n):
+                md.chain_dev_queued(d_bits, 2, 3, d_out)
+            md.synchronize()
+            count, own = md.lanes_info()
+            assert count == min(3, 2 * n) and all(own), (n, count, own)
+        finally:
+            md.close()
+    del junk
