@@ -98,14 +98,19 @@ def handover(argv):
     for p in pieces:
         md = _cfg4(B)
         md.set_handover_frames(p)
-        step = lambda: md.chain_dev(bits, B, stages, out, stream=st.cuda_stream)
+        # on the context's OWN stream: the consumer is lane 0, the producer lane 1, which the library has probed onto
+        # different hardware queues (on a caller's stream the two may share one and run in order: profiles/r05_lane_queues.txt)
+        def step():
+            md.wait_for_stream(st.cuda_stream)
+            md.chain_dev_queued(bits, B, stages, out)
+            md.stream_wait_for(st.cuda_stream)
         for _ in range(3):
             step()
         st.synchronize()
         ms = min(event_time(st, step, 5) for _ in range(2))
         fps = B / (ms * 1e-3)
         pw = sample_load(step, 3.0, ms, st, probe=probe)
-        rec = dict(exp="handover", piece_frames=p, frames_per_call=B, ms_per_call=round(ms, 3), frames_per_s=round(fps, 1),
+        rec = dict(exp="handover", piece_frames=p, lanes=md.lanes_info(), frames_per_call=B, ms_per_call=round(ms, 3), frames_per_s=round(fps, 1),
                    roofline_frac=round(ALGO4 * fps / 8e12, 4), power=pw)
         if pw and "watts_avg" in pw:
             rec["mJ_per_frame"] = round(1e3 * pw["watts_avg"] / fps, 4)
