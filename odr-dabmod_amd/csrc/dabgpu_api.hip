@@ -291,29 +291,43 @@ bool streams_overlap(hipStream_t a, hipStream_t b)
     return overlap;
 }
 
+// a new stream that overlaps with every stream of `others` (see above); *own: the probe found one
+int create_stream_apart(dabgpu_ctx *c, const std::vector<hipStream_t> &others, hipStream_t *out, bool *own)
+{
+    std::vector<hipStream_t> aside;
+    hipStream_t pick = nullptr;
+    *own = false;
+    for (int tries = 0; tries < 12 && !pick; ++tries) {
+        hipStream_t cand = nullptr;
+        hipError_t e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            for (hipStream_t st : aside) (void)hipStreamDestroy(st);
+            return hip_fail(c, e, "hipStreamCreate");
+        }
+        bool ok = true;
+        for (size_t j = 0; j < others.size() && ok; ++j) ok = streams_overlap(others[j], cand);
+        if (ok) { pick = cand; *own = true; } else aside.push_back(cand);
+    }
+    if (!pick) {                              // no queue to itself (fewer hardware queues than streams to keep apart): any will do
+        pick = aside.back();
+        aside.pop_back();
+    }
+    for (hipStream_t st : aside) (void)hipStreamDestroy(st);
+    *out = pick;
+    return DABGPU_OK;
+}
+
 // the stream of lane i (created on first use, lanes 1 .. i in order; lane 0 is the context's stream)
 int lane_stream(dabgpu_ctx *c, int i, hipStream_t *out)
 {
     if (i == 0) { *out = c->stream; return DABGPU_OK; }
     for (int k = 1; k <= i; ++k) {
         if (c->lane[k].stream) continue;
-        std::vector<hipStream_t> aside;
-        hipStream_t pick = nullptr;
-        bool own = false;
-        for (int tries = 0; tries < 12 && !pick; ++tries) {
-            hipStream_t cand = nullptr;
-            HIPCHK(c, hipStreamCreateWithFlags(&cand, hipStreamNonBlocking));
-            bool ok = true;
-            for (int j = 0; j < k && ok; ++j) ok = streams_overlap(j ? c->lane[j].stream : c->stream, cand);
-            if (ok) { pick = cand; own = true; } else aside.push_back(cand);
-        }
-        if (!pick) {                              // no queue to itself (fewer hardware queues than lanes): any stream will do
-            pick = aside.back();
-            aside.pop_back();
-        }
-        for (hipStream_t st : aside) (void)hipStreamDestroy(st);
-        c->lane[k].stream = pick;
-        c->lane_own_queue[k] = own;
+        std::vector<hipStream_t> others{c->stream};
+        for (int j = 1; j < k; ++j) others.push_back(c->lane[j].stream);
+        if (c->copy_stream) others.push_back(c->copy_stream);
+        const int rc = create_stream_apart(c, others, &c->lane[k].stream, &c->lane_own_queue[k]);
+        if (rc) return rc;
     }
     *out = c->lane[i].stream;
     return DABGPU_OK;
@@ -2075,7 +2089,15 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     const int lane = (c->n_lanes > 1 && !(m2 & DABGPU_STAGE_RESAMPLE)) ? slot_index : 0;
     hipStream_t ls;
     if ((rc = lane_stream(c, lane, &ls))) return rc;
-    if (!c->copy_stream) HIPCHK(c, hipStreamCreateWithFlags(&c->copy_stream, hipStreamNonBlocking));
+    if (!c->copy_stream) {
+        // the copy back must overlap with the kernels of BOTH batches in flight: apart from lanes 0 and 1
+        hipStream_t l1 = nullptr;
+        bool own = false;
+        if (c->n_lanes > 1 && (rc = lane_stream(c, 1, &l1))) return rc;
+        std::vector<hipStream_t> others{c->stream};
+        if (l1) others.push_back(l1);
+        if ((rc = create_stream_apart(c, others, &c->copy_stream, &own))) return rc;
+    }
     if (!sl.computed) {
         HIPCHK(c, hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));
         HIPCHK(c, hipEventCreateWithFlags(&sl.copied, hipEventDisableTiming));
