@@ -5,7 +5,7 @@ guard interval (copy / raised-cosine window) x crest-factor reduction x TII x ou
 the RULE BOOK -- written from the documentation, not from the launcher -- and every cell of the
 matrix (i) asks the library which kernels it actually launched (dabgpu_debug_last_variant) and compares, (ii) checks the
 frames against the oracle.  The table of all cells goes to gpurun_out/dispatch_matrix.txt (committed as
-profiles/r04_dispatch_matrix.txt); README's "which kernels run for which configuration" is generated from it
+profiles/r05_dispatch_matrix.txt); README's "which kernels run for which configuration" is generated from it
 (tools/readme_dispatch.py).
 
 Throughput shape: one workgroup per frame (chunks_per_frame = 1), two frames per call, the second call of a configuration is
