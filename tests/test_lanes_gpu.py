@@ -359,3 +359,52 @@ def test_lanes_get_hardware_queues_of_their_own_whatever_came_before(pkg):
         finally:
             md.close()
     del junk
+
+
+def test_setters_from_another_thread_while_batches_are_in_flight_on_the_lanes(pkg):
+    """The remote-control contract with the lanes: a thread toggles digital gain and the taps (a table that
+    is rewritten on the device) while the processing thread keeps three batches in flight.  Every frame must come out under ONE
+    consistent snapshot -- scale 1, 1/2 or 1/4 of the base frame, never a mixture -- which also proves that a table is only
+    rewritten once every lane has drained."""
+    import threading
+    import torch
+    md = pkg.Modulator(mode=2, max_frames=2)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=4300), synth_bits(per, seed=4301)])
+        taps = O.fir_default_taps()
+        base = O.Chain(mode=2, stages=3, gain_mode=2, normalise=1.0 / 50000.0).process(bits)
+        ns = md.out_samples_per_frame(3)
+        d_bits = torch.from_numpy(bits).cuda()
+        outs = [torch.zeros((2, ns), dtype=torch.complex64, device="cuda") for _ in range(6)]
+        stop = threading.Event()
+
+        def rc_thread():
+            i = 0
+            while not stop.is_set():
+                md.set_gain(2, 1.0 if i & 1 else 0.5, 1.0 / 50000.0, 4.0)
+                md.set_fir_taps(taps if i & 2 else taps * np.float32(0.5))
+                i += 1
+
+        t = threading.Thread(target=rc_thread)
+        t.start()
+        seen = set()
+        try:
+            for _ in range(60):
+                for o in outs:
+                    md.chain_dev_queued(d_bits, 2, 3, o)
+                md.synchronize()
+                for o in outs:
+                    y = o.cpu().numpy()
+                    for f in range(2):
+                        k = float(np.vdot(base[f], y[f]).real / np.vdot(base[f], base[f]).real)
+                        scale = min((1.0, 0.5, 0.25), key=lambda c: abs(c - k))
+                        assert rel_rms(y[f], base[f] * np.float32(scale)) < 2e-6, k
+                        seen.add(scale)
+        finally:
+            stop.set()
+            t.join()
+        assert len(seen) >= 2
+    finally:
+        md.close()
