@@ -195,6 +195,7 @@ struct dabgpu_ctx {
     Lane lane[kMaxLanes];                 // (entry 0: only `ev` is used)
     bool lane_own_queue[kMaxLanes] = {true, false, false, false};   // the probe found the lane a hardware queue of its own
     int n_lanes = 3;
+    int call_lanes = 1;                   // lanes the CURRENT chain call rotates over (1: an explicit stream, lane 0 only)
     unsigned long long lane_seq = 0;
     int clip_lane = 0, cfr_last_lane = 0; // whose scratch holds the clip count / the CFR statistics of the most recent call
     // The native-rate stream between FIRFilter and Resampler (src/DabModulator.cpp:403-406) in pieces of this many frames
@@ -721,9 +722,14 @@ int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
     // the depth) and, with FIR, one look-ahead transform.  Measured optimum, Mode I (tools/sweep_chunks.py, round 3):
     // 1024 / B runs down to B = 32, two symbols per run for 14 ... 31 frames, single symbols below (latency, not
     // efficiency, counts there: 10 us per Mode-I frame).
+    // With the call rotating over L lanes (section 4.5 of DESIGN.md), L launches are in flight and the chip is filled by
+    // FEWER, LONGER runs per launch -- and every run saved is a prologue and a look-ahead transform saved: measured optimum
+    // with three lanes (tools/exp_r05.py chunks, profiles/r05_exp_chunks.jsonl) 26 runs per frame at 16 frames (416 workgroups;
+    // +10 % over 624), 6 ... 8 at 64 (+14 % over 1024), 2 at 256 (+4 %): about 1280 / L workgroups per launch.
     const int nsym = c->g.nb_symbols + 1;
     const size_t n = n_frames;
-    const int want = std::max(1, std::min(n >= 1024 ? 1 : (int)((1024 + n - 1) / n), nsym));
+    const size_t target = c->call_lanes > 1 ? std::max<size_t>(256, 1280 / (size_t)c->call_lanes) : 1024;
+    const int want = std::max(1, std::min(n >= target ? 1 : (int)((target + n - 1) / n), nsym));
     // no empty runs: the callers give every run ceil(nsym / chunks) symbols, so ask for exactly as many runs as that
     // run length needs (74 wanted -> 2 symbols per run -> 39 runs, not 74 workgroups of which 35 return after the prologue)
     const int per_run = (nsym + want - 1) / want;
@@ -1891,14 +1897,16 @@ namespace {
 // Which lane a call on the context's own stream goes to: the lanes in turn while a launch alone cannot fill the chip many
 // times over; lane 0 for everything that carries stream state (Resampler) and for large batches (nothing to gain, and
 // the scratch of some chains grows with the batch).
-int pick_lane(dabgpu_ctx *c, size_t n_frames, unsigned mask)
+int pick_lane(dabgpu_ctx *c, size_t n_frames, unsigned mask, bool *rotating)
 {
+    *rotating = false;
     bool resample;
     {
         std::lock_guard<std::mutex> lk(c->mu);
         resample = (mask & DABGPU_STAGE_RESAMPLE) && c->set.rs_in != c->set.rs_out;
     }
     if (c->n_lanes <= 1 || resample || n_frames > (size_t)dabgpu_ctx::kLaneMaxFrames) return 0;
+    *rotating = true;
     return (int)(c->lane_seq++ % (unsigned long long)c->n_lanes);
 }
 
@@ -1907,14 +1915,19 @@ int chain_dev(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
 {
     int lane = 0;
     hipStream_t s = (hipStream_t)stream;
+    c->call_lanes = 1;
     if (!s) {
-        lane = pick_lane(c, n_frames, mask);
+        bool rotating = false;
+        lane = pick_lane(c, n_frames, mask, &rotating);
         const int rc = lane_stream(c, lane, &s);
         if (rc) return rc;
+        if (rotating) c->call_lanes = c->n_lanes;
     }
     c->clip_from_collect = false;
     TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
-    return run_chain(c, d_in, from_bits, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s, true, lane);
+    const int rc = run_chain(c, d_in, from_bits, n_frames, mask, (float2 *)d_iq, out_cap, out_bytes, s, true, lane);
+    c->call_lanes = 1;
+    return rc;
 }
 
 }  // namespace
@@ -2124,7 +2137,9 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     size_t ob = 0;
     {
         TraceScope trace(c->trace_enabled ? &c->last_variant : nullptr);
+        c->call_lanes = (c->n_lanes > 1 && !(m2 & DABGPU_STAGE_RESAMPLE)) ? 2 : 1;     // (the two batches in flight)
         rc = run_chain(c, sl.d_in.p, true, n_frames, mask, (float2 *)sl.d_out.p, need, &ob, ls, true, lane);
+        c->call_lanes = 1;
     }
     if (rc) return rc;
     sl.out_format = c->cur.out_format;

@@ -8,6 +8,10 @@
   rsonly     the x4 resampler + predistorter ALONE (dabgpu_post_process_dev) in calls of 128 frames whose input comes
              from a ring of R frames: R = 128 (201 MB, fits the 256 MiB last-level cache) against R = 4096 (6.4 GB):
              the same launches, only the addresses differ -- the energy of reading the native-rate stream from memory
+  tfonly     the frame kernel alone, 128 frames per call, output to a ring of R frames: the WRITE side of the same question
+  parts      cfg 4's two kernels one at a time and the chain: time, power, joules per frame
+  cfg3power  cfg 3 (or + cfr / nofir / window) at B frames with board power: one arm of an A/B over DABGPU_LIB builds
+  chunks     cfg 3 on three lanes: runs of symbols per frame against the batch size
 """
 import importlib
 import json
@@ -222,6 +226,44 @@ def parts(argv):
     md.close()
 
 
+def chunks(argv):
+    """cfg 3 on three lanes: workgroups (runs of symbols) per frame against the batch size -- with three launches in flight
+    the chip is filled by FEWER, LONGER runs per launch than auto_chunks' 1024 workgroups, and every run costs a prologue and
+    one look-ahead transform."""
+    batches = [int(x) for x in argv] or [4, 16, 64, 256]
+    stages = P.STAGE_GAIN | P.STAGE_FIR
+    st = torch.cuda.Stream(device=dev)
+    for B in batches:
+        with torch.cuda.stream(st):
+            bits = [torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device=dev) for _ in range(4)]
+            outs = [torch.empty((B, 196608), dtype=torch.complex64, device=dev) for _ in range(4)]
+        st.synchronize()
+        for ch in (0, 77, 39, 26, 20, 16, 13, 11, 8, 6, 4, 3, 2, 1):
+            if ch and B * ch > 4096:
+                continue
+            md = P.Modulator(mode=1, device=0, max_frames=B, chunks_per_frame=ch)
+            md.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+            calls = max(40, min(400, 8192 // B))
+            k = [0]
+
+            def body():
+                md.wait_for_stream(st.cuda_stream)
+                for _ in range(calls):
+                    i = k[0] & 3
+                    k[0] += 1
+                    md.chain_dev_queued(bits[i], B, stages, outs[i])
+                md.stream_wait_for(st.cuda_stream)
+            body()
+            st.synchronize()
+            best = min(event_time(st, body, 3) for _ in range(3)) / calls
+            fps = B / (best * 1e-3)
+            emit(exp="chunks", frames_per_call=B, chunks_per_frame=ch, workgroups_per_call=(B * ch if ch else None),
+                 us_per_call=round(best * 1e3, 2), frames_per_s=round(fps, 1), roofline_frac=round(ALGO3 * fps / 8e12, 4))
+            md.close()
+        del bits, outs
+        torch.cuda.empty_cache()
+
+
 def cfg3power(argv):
     """cfg 3 (or cfg3 + option) at B frames per launch with board power: one arm of an A/B over libraries
     (DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/exp_r05.py cfg3power [B] [cfr|nofir|window] [tag])."""
@@ -258,4 +300,4 @@ def cfg3power(argv):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "lanes"
-    {"lanes": lanes, "handover": handover, "rsonly": rsonly, "tfonly": tfonly, "parts": parts, "cfg3power": cfg3power}[what](sys.argv[2:])
+    {"lanes": lanes, "handover": handover, "rsonly": rsonly, "tfonly": tfonly, "parts": parts, "cfg3power": cfg3power, "chunks": chunks}[what](sys.argv[2:])
