@@ -255,69 +255,6 @@ int hip_fail(dabgpu_ctx *c, hipError_t e, const char *what)
         if (e_ != hipSuccess) return hip_fail(ctx, e_, #expr);                                 \
     } while (0)
 
-// Lanes must sit on DIFFERENT hardware queues to overlap at all.  The HIP runtime multiplexes its streams onto a few
-// hardware queues (four by default), a new stream joining the queue that has the fewest at that moment -- so whether
-// three streams created in a row end up on three queues depends on every stream the process has created and destroyed
-// before (measured: 16-frame calls on three lanes take 8.9 us each when they do and 13.5 us when two of them share a
-// queue, which is in-order; tools/_variants history in profiles/r05_lane_queues.txt).  Nothing in the API tells which
-// queue a stream is on, but it shows: a 200 us spin on one stream delays a no-op on the other exactly when they share
-// one.  A lane's stream is therefore PROBED against the lanes before it when it is created, and candidates that share
-// a queue with one of them are set aside (kept alive until the lane is settled, so that the next candidate goes
-// elsewhere) and destroyed afterwards.  Once per lane and context, ~0.3 ms per probe.
-__global__ void lane_probe_spin(unsigned long long ticks)
-{
-    const unsigned long long t0 = wall_clock64();                 // (constant-rate counter, 100 MHz)
-    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(16);
-}
-__global__ void lane_probe_nop() {}
-
-// do kernels on a and b overlap?  (false also on any error: the caller then simply keeps what it has)
-bool streams_overlap(hipStream_t a, hipStream_t b)
-{
-    hipEvent_t ea = nullptr, eb = nullptr;
-    bool overlap = false;
-    if (hipEventCreateWithFlags(&ea, hipEventDisableTiming) == hipSuccess &&
-        hipEventCreateWithFlags(&eb, hipEventDisableTiming) == hipSuccess &&
-        hipStreamSynchronize(a) == hipSuccess && hipStreamSynchronize(b) == hipSuccess) {
-        hipLaunchKernelGGL(lane_probe_spin, dim3(1), dim3(64), 0, a, 20000ull);      // 200 us
-        (void)hipEventRecord(ea, a);
-        hipLaunchKernelGGL(lane_probe_nop, dim3(1), dim3(64), 0, b);
-        (void)hipEventRecord(eb, b);
-        if (hipEventSynchronize(eb) == hipSuccess) overlap = hipEventQuery(ea) == hipErrorNotReady;
-        (void)hipEventSynchronize(ea);
-        (void)hipGetLastError();
-    }
-    if (ea) (void)hipEventDestroy(ea);
-    if (eb) (void)hipEventDestroy(eb);
-    return overlap;
-}
-
-// a new stream that overlaps with every stream of `others` (see above); *own: the probe found one
-int create_stream_apart(dabgpu_ctx *c, const std::vector<hipStream_t> &others, hipStream_t *out, bool *own)
-{
-    std::vector<hipStream_t> aside;
-    hipStream_t pick = nullptr;
-    *own = false;
-    for (int tries = 0; tries < 12 && !pick; ++tries) {
-        hipStream_t cand = nullptr;
-        hipError_t e = hipStreamCreateWithFlags(&cand, hipStreamNonBlocking);
-        if (e != hipSuccess) {
-            for (hipStream_t st : aside) (void)hipStreamDestroy(st);
-            return hip_fail(c, e, "hipStreamCreate");
-        }
-        bool ok = true;
-        for (size_t j = 0; j < others.size() && ok; ++j) ok = streams_overlap(others[j], cand);
-        if (ok) { pick = cand; *own = true; } else aside.push_back(cand);
-    }
-    if (!pick) {                              // no queue to itself (fewer hardware queues than streams to keep apart): any will do
-        pick = aside.back();
-        aside.pop_back();
-    }
-    for (hipStream_t st : aside) (void)hipStreamDestroy(st);
-    *out = pick;
-    return DABGPU_OK;
-}
-
 // the stream of lane i (created on first use, lanes 1 .. i in order; lane 0 is the context's stream)
 int lane_stream(dabgpu_ctx *c, int i, hipStream_t *out)
 {
@@ -327,8 +264,7 @@ int lane_stream(dabgpu_ctx *c, int i, hipStream_t *out)
         std::vector<hipStream_t> others{c->stream};
         for (int j = 1; j < k; ++j) others.push_back(c->lane[j].stream);
         if (c->copy_stream) others.push_back(c->copy_stream);
-        const int rc = create_stream_apart(c, others, &c->lane[k].stream, &c->lane_own_queue[k]);
-        if (rc) return rc;
+        HIPCHK(c, create_stream_apart(others.data(), (int)others.size(), &c->lane[k].stream, &c->lane_own_queue[k]));
     }
     *out = c->lane[i].stream;
     return DABGPU_OK;
@@ -2109,7 +2045,7 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
         if (c->n_lanes > 1 && (rc = lane_stream(c, 1, &l1))) return rc;
         std::vector<hipStream_t> others{c->stream};
         if (l1) others.push_back(l1);
-        if ((rc = create_stream_apart(c, others, &c->copy_stream, &own))) return rc;
+        HIPCHK(c, create_stream_apart(others.data(), (int)others.size(), &c->copy_stream, &own));
     }
     if (!sl.computed) {
         HIPCHK(c, hipEventCreateWithFlags(&sl.computed, hipEventDisableTiming));

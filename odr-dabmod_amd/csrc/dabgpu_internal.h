@@ -47,6 +47,10 @@ void trace_launch(const char *what);
         hipLaunchKernelGGL(kernel, __VA_ARGS__);                        \
     } while (0)
 
+// stream_probe.hip: streams on hardware queues of their own (the lanes of a context; the async host path's copy stream)
+bool streams_overlap(hipStream_t a, hipStream_t b);
+hipError_t create_stream_apart(const hipStream_t *others, int n, hipStream_t *out, bool *own);
+
 struct GainParams {
     int mode;            // 0 fix, 1 max, 2 var
     float constant;      // normalise * digital  (reference src/GainControl.cpp:118)
