@@ -789,7 +789,8 @@ int fused_ntaps(const dabgpu_ctx *c)
 
 int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,
                float2 *native_out, size_t native, float *gain1, hipStream_t s, bool keep_stats = true,
-               unsigned long long *s16_clipped = nullptr, const float2 *tii_seg = nullptr, bool *tii_done = nullptr)
+               unsigned long long *s16_clipped = nullptr, const float2 *tii_seg = nullptr, bool *tii_done = nullptr,
+               int fused_fmt = DABGPU_FMT_S16)
 {
     if (tii_done) *tii_done = false;
     TfArgs a{};
@@ -843,7 +844,7 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
     if (!windowed) {
         if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
         if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
-        if (s16_clipped) flags |= TF_OUT_S16;
+        if (s16_clipped) flags |= tf_ofmt_flag(fused_fmt);        // (the frame kernel stores the integers itself)
         if (!(flags & TF_CFR)) a.ntaps = fused_ntaps(c);     // (the CFR variants loop over the run-time tap count)
         // cfg 3 chain: the filtered transform alone with equalised boundaries (dabgpu_set_fir_boundary_mode(ctx, 1): the packed
         // dual transform)
@@ -1005,7 +1006,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
         clip = (unsigned long long *)c->d_clip.p;
         c->clip_stream = s;
         c->clip_lane = lane;
-        if (fmt == DABGPU_FMT_S16 && from_bits) {
+        if (from_bits) {
             // ask the kernels' own predicates (the ones their launchers test), so that the separate convert kernel is taken
             // whenever a variant does not exist in this build
             const bool poly_ok = !(mask & DABGPU_STAGE_POLY) || (!c->cur.poly_is_lut && (mask & DABGPU_STAGE_RESAMPLE));
@@ -1020,14 +1021,16 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
                               ((mask & DABGPU_STAGE_NOGUARD) ? 0 : TF_GUARD) | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0) |
                               (c->cur.cfr_enable ? TF_CFR : 0);
             if (c->use_eq && tf_has_eq(ta, tflags)) tflags |= TF_EQ;
-            // (a windowed guard interval has variants without the s16 store only, and TII is added to the native-rate complexf
-            // stream afterwards unless the frame kernel adds it itself: the frame kernel's own s16 store is out then, the
-            // resampler's is not)
-            fuse_native = !post && !windowed && (!tii || tf_has_tii(ta, tflags)) && tf_has_s16(ta, tflags);
+            // (a windowed guard interval has variants without the integer store only, and TII is added to the native-rate
+            // complexf stream afterwards unless the frame kernel adds it itself: the frame kernel's own store is out then, the
+            // resampler's is not.  u8 / s8: the frame kernel's equalised-boundary and no-FIRFilter variants; s16: those, the
+            // pruned dual transform and the x2 / x4 resampler.)
+            fuse_native = !post && !windowed && (!tii || tf_has_tii(ta, tflags)) && tf_has_fmt(ta, tflags | tf_ofmt_flag(fmt));
             ResamplerArgs ra{};
             ra.nin = c->rs_nin;
             ra.nout = c->rs_nout;
-            fuse_post = (mask & DABGPU_STAGE_RESAMPLE) && resampler_fast_ratio(c) && resampler_has_s16(ra) && poly_ok;
+            fuse_post = fmt == DABGPU_FMT_S16 && (mask & DABGPU_STAGE_RESAMPLE) && resampler_fast_ratio(c) &&
+                        resampler_has_s16(ra) && poly_ok;
         }
     }
     float2 *d_out = (float2 *)d_out_v;
@@ -1097,7 +1100,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     }
     bool tii_done = false;
     if ((rc = run_native(c, d_in, from_bits, n_frames, mask, windowed, native_out, native, gain1, s, true,
-                         fuse_native ? clip : nullptr, tii ? (const float2 *)c->d_tii_frame.p : nullptr, &tii_done)))
+                         fuse_native ? clip : nullptr, tii ? (const float2 *)c->d_tii_frame.p : nullptr, &tii_done, fmt)))
         return rc;
     if (tii && !tii_done) {
         if (fuse_native) return fail(c, DABGPU_E_DEVICE, "s16 stored by the frame kernel, TII still to be added");

@@ -86,7 +86,7 @@ struct TfArgs {
     unsigned *cfr_counts;     // [frame][2]: clipped samples, clipped errors (pre-zeroed)
     double *cfr_mer;          // [frame][2]: sum |before|^2, sum |after - before|^2 of the MER symbol (pre-zeroed)
     double *cfr_papr;         // [frame][nb_symbols+1][4]: peak, mean of |x|^2 before / after CFR (pre-zeroed)
-    // TF_OUT_S16: `out` holds 4-byte s16 pairs; the number of clipped components is ADDED to *clipped
+    // TF_OUT_S16 / _U8 / _S8: `out` holds 4-byte s16 pairs / 2-byte u8 or s8 pairs; the number of clipped components is ADDED to *clipped
     unsigned long long *clipped;
     // TF_WINDOW: raised-cosine overlap of the guard interval (t.window holds the 2 * overlap factors)
     int overlap;
@@ -96,14 +96,17 @@ struct TfArgs {
 };
 
 enum TfFlags { TF_FROM_BITS = 1, TF_GAIN = 2, TF_GUARD = 4, TF_FIR = 8, TF_CFR = 16, TF_GVAR = 32 /* internal */,
-               TF_OUT_S16 = 64, TF_WINDOW = 256, TF_EQ = 512 };
+               TF_OUT_S16 = 64, TF_WINDOW = 256, TF_EQ = 512, TF_OUT_U8 = 1024, TF_OUT_S8 = 2048 };
+// the integer format the frame kernel is asked to store itself: 0 = none (complexf), else DABGPU_FMT_S16 / _U8 / _S8 (1 / 2 / 3)
+inline int tf_ofmt(unsigned flags) { return (flags & TF_OUT_S16) ? 1 : (flags & TF_OUT_U8) ? 2 : (flags & TF_OUT_S8) ? 3 : 0; }
+inline unsigned tf_ofmt_flag(int fmt) { return fmt == 1 ? TF_OUT_S16 : fmt == 2 ? TF_OUT_U8 : fmt == 3 ? TF_OUT_S8 : 0u; }
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0, int overlap = 0, int ntaps = 0);
 int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
 bool tf_has_eq(const TfArgs &a, unsigned flags);     // the equalised-boundary variant exists for this chain (TF_EQ; needs t.eq_g)
 bool tf_has_window(const TfArgs &a, unsigned flags); // a frame-kernel variant windows the guard interval itself (TF_WINDOW)
-bool tf_has_s16(const TfArgs &a, unsigned flags);   // a frame-kernel variant stores s16 itself (TF_OUT_S16)
+bool tf_has_fmt(const TfArgs &a, unsigned flags);   // a frame-kernel variant stores the format of flags' TF_OUT_* bit itself
 bool tf_has_tii(const TfArgs &a, unsigned flags);   // the variant these flags select adds the TII null symbol itself (a.tii_seg)
 
 // Stand-alone stage kernels (per-stage drop-ins and the non-fused fallbacks).

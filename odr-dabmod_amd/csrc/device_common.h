@@ -869,6 +869,28 @@ DEV int cvt_i32_sat(float x)
     asm("v_cvt_i32_f32 %0, %1" : "=v"(r) : "v"(x));     // (a C cast of an out-of-range float is undefined; the instruction is not)
     return r;
 }
+// FormatConverter on one component, any format (src/FormatConverter.cpp:111-170): FMT 1 = s16, 2 = u8 (x + 128), 3 = s8;
+// range test in float, count, else truncate toward zero.  (format_kernel; the fused u8 / s8 stores below)
+template <int FMT> DEV int format_one(float x, unsigned &clipped)
+{
+    constexpr float lo = FMT == 1 ? -32768.0f : (FMT == 2 ? 0.0f : -128.0f);
+    constexpr float hi = FMT == 1 ? 32767.0f : (FMT == 2 ? 255.0f : 127.0f);
+    // (u8: the reference adds 128 to the ROUNDED float sample.  In a kernel's store epilogue the compiler would contract the
+    // sum into the multiply that produced x -- 35.999992 + 128 is 164.0 in fp32, 163 after truncation when fused -- so x is made
+    // opaque first: an empty asm, no instruction.)
+    if (FMT == 2) asm("" : "+v"(x));
+    const float v = FMT == 2 ? x + 128.0f : x;
+    if (v < lo) { ++clipped; return (int)lo; }
+    if (v > hi) { ++clipped; return (int)hi; }
+    return (int)v;                       // v_cvt_i32_f32: toward zero, NaN -> 0
+}
+// u8 / s8 fused into the chain's last store: one 2-byte word per complex sample, the components as format_kernel forms them
+template <int FMT> DEV unsigned short b8_pack(cf y, unsigned &clipped)
+{
+    static_assert(FMT == 2 || FMT == 3, "u8 or s8");
+    const int re = format_one<FMT>(y.x, clipped), im = format_one<FMT>(y.y, clipped);
+    return (unsigned short)((unsigned)(re & 0xff) | ((unsigned)(im & 0xff) << 8));
+}
 DEV uint32_t s16_pack(cf y, unsigned &clipped)
 {
     clipped += (__builtin_fabsf(y.x + 0.5f) > 32767.5f ? 1u : 0u) + (__builtin_fabsf(y.y + 0.5f) > 32767.5f ? 1u : 0u);

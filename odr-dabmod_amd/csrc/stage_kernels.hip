@@ -552,16 +552,7 @@ __global__ void tii_add_kernel(cf *__restrict__ out, size_t stride, const cf *__
 // truncation toward zero; u8 adds 128.0f first.  FMT: 1 = s16, 2 = u8, 3 = s8.
 // HBM-bound elementwise: 8 floats per lane (two 16-byte loads, one 16- or 8-byte store), the
 // clip count reduced per wave and added to a device counter.
-template <int FMT> DEV int format_one(float x, unsigned &clipped)
-{
-    constexpr float lo = FMT == 1 ? -32768.0f : (FMT == 2 ? 0.0f : -128.0f);
-    constexpr float hi = FMT == 1 ? 32767.0f : (FMT == 2 ? 255.0f : 127.0f);
-    const float v = FMT == 2 ? x + 128.0f : x;
-    if (v < lo) { ++clipped; return (int)lo; }
-    if (v > hi) { ++clipped; return (int)hi; }
-    return (int)v;                       // v_cvt_i32_f32: toward zero, NaN -> 0
-}
-
+// (format_one: device_common.h)
 template <int FMT> __global__ __launch_bounds__(256)
 void format_kernel(const float *__restrict__ in, size_t n, void *__restrict__ out,
                    unsigned long long *__restrict__ clipped_total)

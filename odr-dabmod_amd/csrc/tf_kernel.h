@@ -68,7 +68,8 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // ZONLY (Mode I with the fused FIR and no gain statistics over the time domain: the coded-bits path with gain fix / var,
 // the carriers path with gain var or none): the unfiltered transform is formed only where
 // the boundary FIR reads it (Fft::run_dual_zonly).
-// OFMT = 1: the output is s16 (4 bytes per sample, FormatConverter semantics) instead of cf32 -- instantiated for the
+// OFMT = 1: the output is s16 (4 bytes per sample, FormatConverter semantics) instead of cf32; OFMT = 2 / 3 (round 5): u8 / s8, 2
+// bytes per sample, on the equalised-boundary and the no-FIRFilter variants -- instantiated for the
 // production variants only (Mode I coded-bits chain, default filter); everything else converts in format_kernel.
 // WIN (coded-bits chain with guard interval, no FIR): the guard interval is windowed (ofdmwindowing > 0, f-4,
 // src/GuardIntervalInserter.cpp:149-300).  Every sample outside the 2W-wide seams is the copy it is without a window;
@@ -255,7 +256,7 @@ void tf_kernel(const TfArgs a)
     // (buffer_store ... offen).  Flat 64-bit addresses cost a register pair and a 64-bit add per store, and were
     // what the register allocator spilled first.  soff: wave-uniform sample index inside the frame (>= 0), voff: the
     // lane's; out-of-range lanes are exec-masked by the callers (the hardware would drop them as well).
-    constexpr int kOutBytes = OFMT == 1 ? 4 : 8;
+    constexpr int kOutBytes = OFMT == 0 ? 8 : (OFMT == 1 ? 4 : 2);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
         reinterpret_cast<char *>(a.out) + (size_t)frame * a.out_stride * kOutBytes, 0, (int)(a.out_stride * kOutBytes), 0x00020000);
     unsigned nclip = 0;
@@ -276,8 +277,10 @@ void tf_kernel(const TfArgs a)
     constexpr int kStoreAux = FROM_BITS ? 2 : 0;
 #endif
     auto put = [&](int soff, int voff, cf y) __attribute__((always_inline)) {
-        if (OFMT == 1) {
+        if constexpr (OFMT == 1) {
             __builtin_amdgcn_raw_buffer_store_b32(s16_pack(y, nclip), orsrc, voff * 4, soff * 4, kStoreAux);
+        } else if constexpr (OFMT == 2 || OFMT == 3) {
+            __builtin_amdgcn_raw_buffer_store_b16(b8_pack<(OFMT == 3 ? 3 : 2)>(y, nclip), orsrc, voff * 2, soff * 2, kStoreAux);
         } else {
             const v2u_ d = {__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.y)};
             __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, voff * 8, soff * 8, kStoreAux);
@@ -1133,7 +1136,7 @@ void tf_kernel(const TfArgs a)
         lds_barrier();
         boundary(bnd + cur * 2 * KB);
     }
-    if (OFMT == 1) s16_flush_count(nclip, a.clipped);
+    if (OFMT != 0) s16_flush_count(nclip, a.clipped);
     pt.flush(a.phase_cycles, pt_iterations);
 }
 
@@ -1171,7 +1174,8 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     const bool fb = flags & TF_FROM_BITS, gn = flags & TF_GAIN, gd = flags & TF_GUARD,
                fr = flags & TF_FIR;
     if (fr && !gd) return hipErrorInvalidValue;
-    if ((flags & TF_OUT_S16) && !tf_has_s16(a, flags)) return hipErrorInvalidValue;
+    const int of = tf_ofmt(flags);                           // 0 complexf, else the DABGPU_FMT_* the kernel stores itself
+    if (of && (!tf_has_fmt(a, flags) || !a.clipped)) return hipErrorInvalidValue;
     if ((flags & TF_WINDOW) && !tf_has_window(a, flags)) return hipErrorInvalidValue;
     if ((flags & TF_EQ) && !tf_has_eq(a, flags)) return hipErrorInvalidValue;
     if (flags & TF_CFR) {
@@ -1227,17 +1231,21 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     if constexpr (LOGN == 11 && NT == 45) if (fb && fr && gd && (!gn || a.gain.mode != 1)) {
         if (flags & TF_EQ) {
             // ... or the one that runs the filtered transform alone and equalises the boundary (needs the taps' inverse)
-            if (!a.t.eq_g || ((flags & TF_OUT_S16) && !a.clipped)) return hipErrorInvalidValue;
+            if (!a.t.eq_g) return hipErrorInvalidValue;
 #define TF_LAUNCH_EQ(GN, OF) \
             tf_go<11, true, GN, true, true, 45, false, false, false, OF, false, true>(grid, block, lds, s, a)
-            if (flags & TF_OUT_S16) { if (gn) TF_LAUNCH_EQ(true, 1); else TF_LAUNCH_EQ(false, 1); }
-            else                    { if (gn) TF_LAUNCH_EQ(true, 0); else TF_LAUNCH_EQ(false, 0); }
+            switch (of) {
+                case 1: if (gn) TF_LAUNCH_EQ(true, 1); else TF_LAUNCH_EQ(false, 1); break;
+                case 2: if (gn) TF_LAUNCH_EQ(true, 2); else TF_LAUNCH_EQ(false, 2); break;
+                case 3: if (gn) TF_LAUNCH_EQ(true, 3); else TF_LAUNCH_EQ(false, 3); break;
+                default: if (gn) TF_LAUNCH_EQ(true, 0); else TF_LAUNCH_EQ(false, 0);
+            }
 #undef TF_LAUNCH_EQ
             return hipGetLastError();
         }
         // Mode I, default filter length, gain fix / var (or none): the variant that prunes the unfiltered transform
-        if (flags & TF_OUT_S16) {
-            if (!a.clipped) return hipErrorInvalidValue;
+        if (of > 1) return hipErrorInvalidValue;           // (u8 / s8 are stored by the equalised and the no-FIRFilter variants)
+        if (of == 1) {
             if (gn) tf_go<11, true, true, true, true, 45, false, false, true, 1>(grid, block, lds, s, a);
             else tf_go<11, true, false, true, true, 45, false, false, true, 1>(grid, block, lds, s, a);
             return hipGetLastError();
@@ -1246,12 +1254,17 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         else tf_go<11, true, false, true, true, 45, false, false, true>(grid, block, lds, s, a);
         return hipGetLastError();
     }
-    if (flags & TF_OUT_S16) {
-        // the reference's default chain (no FIRFilter) with s16 output, Mode I: any gain mode
-        if (LOGN != 11 || NT != 0 || !fb || !gd || fr || !a.clipped) return hipErrorInvalidValue;   // (callers ask tf_has_s16 first)
+    if (of) {
+        // the reference's default chain (no FIRFilter) with integer output, Mode I: any gain mode
+        if (LOGN != 11 || NT != 0 || !fb || !gd || fr) return hipErrorInvalidValue;   // (callers ask tf_has_fmt first)
         if constexpr (LOGN == 11 && NT == 0) {
-            if (gn) tf_go<11, true, true, true, false, 0, false, false, false, 1>(grid, block, lds, s, a);
-            else tf_go<11, true, false, true, false, 0, false, false, false, 1>(grid, block, lds, s, a);
+#define TF_LAUNCH_NOFIR(GN, OF) tf_go<11, true, GN, true, false, 0, false, false, false, OF>(grid, block, lds, s, a)
+            switch (of) {
+                case 1: if (gn) TF_LAUNCH_NOFIR(true, 1); else TF_LAUNCH_NOFIR(false, 1); break;
+                case 2: if (gn) TF_LAUNCH_NOFIR(true, 2); else TF_LAUNCH_NOFIR(false, 2); break;
+                default: if (gn) TF_LAUNCH_NOFIR(true, 3); else TF_LAUNCH_NOFIR(false, 3);
+            }
+#undef TF_LAUNCH_NOFIR
         }
         return hipGetLastError();
     }

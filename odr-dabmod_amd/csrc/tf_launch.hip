@@ -43,7 +43,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
 // without s16 store (with or without FIRFilter, with or without CFR), overlap up to kWinMax (and inside the cyclic prefix)
 bool tf_has_window(const TfArgs &a, unsigned flags)
 {
-    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_OUT_S16;
+    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_OUT_S16 | TF_OUT_U8 | TF_OUT_S8;
     if ((flags & want) != want || (flags & never) || a.overlap < 1 || a.overlap > kWinMax) return false;
     // with FIR: the filter's look-ahead and the window must both fit into the cyclic prefix
     if (flags & TF_FIR)
@@ -72,14 +72,17 @@ bool tf_has_tii(const TfArgs &a, unsigned flags)
     return (flags & TF_EQ) ? tf_has_eq(a, flags) : !(flags & TF_FIR);
 }
 
-// the frame-kernel variants that store s16 themselves: Mode I coded-bits chain, guard + default-length filter,
-// gain none / fix / var, no CFR
-bool tf_has_s16(const TfArgs &a, unsigned flags)
+// the frame-kernel variants that store an integer format (flags' TF_OUT_* bit) themselves: the Mode I coded-bits chain with the
+// guard interval, without FIRFilter (any gain mode) or with the default-length filter (gain none / fix / var) -- s16 on both
+// forms of the latter, u8 / s8 on its equalised-boundary form (TF_EQ set by the caller) only
+bool tf_has_fmt(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
-    if (a.g.logN != 11 || (flags & (TF_CFR | TF_WINDOW))) return false;
+    const int of = tf_ofmt(flags);
+    if (!of || a.g.logN != 11 || (flags & (TF_CFR | TF_WINDOW))) return false;
     // without FIRFilter (the reference's default): every gain mode
     if ((flags & want) == (TF_FROM_BITS | TF_GUARD)) return true;
+    if (of > 1 && !(flags & TF_EQ)) return false;
     return a.ntaps == 45 && (flags & want) == want && (!(flags & TF_GAIN) || a.gain.mode != 1);
 }
 

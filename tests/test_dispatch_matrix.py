@@ -50,8 +50,12 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
         default_len = mode == 1 and F and ntaps == 45 and not cfr and gain != 1      # (gain max needs the unfiltered samples)
         eq = default_len and fir != "notch"              # boundary outputs through the taps' inverse
         tii_inside = tii and not cfr and (eq or not F)
-        s16_inside = fmt == "s16" and mode == 1 and not cfr and (not F or default_len) and (not tii or tii_inside)
-        of = int(s16_inside)
+        # integer output stored by the frame kernel itself: s16 on the no-FIRFilter and both default-length variants, u8 / s8
+        # (round 5) on the no-FIRFilter and the equalised-boundary variants
+        fmt_inside = (fmt is not None and mode == 1 and not cfr and (not tii or tii_inside) and
+                      ((not F or default_len) if fmt == "s16" else (not F or eq)))
+        s16_inside = fmt_inside
+        of = FMT_CODE[fmt] if fmt_inside else 0
         if cfr:
             out.append(tf(logn, G, 1, F, nt if F else 0, cfr=1))
         elif default_len:

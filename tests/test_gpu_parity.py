@@ -1568,7 +1568,7 @@ def test_async_host_path_zero_copy_buffer_lifetime(pkg):
 
 
 # --------------------------------------------------------------------------- f-2 fused into the chain
-def _chain_formats_case(pkg, mode, stages, fmt, setup, n_frames=2, seed=1900):
+def _chain_formats_case(pkg, mode, stages, fmt, setup, n_frames=2, seed=1900, seen=None):
     """The chain with an integer output format against FormatConverter applied to the chain's own complexf output:
     the conversion is integer work on identical floats, so the bytes and the clip count must be equal."""
     md = pkg.Modulator(mode=mode, max_frames=n_frames)
@@ -1581,6 +1581,8 @@ def _chain_formats_case(pkg, mode, stages, fmt, setup, n_frames=2, seed=1900):
         md.set_resampler(2048000, 2048000 if not (stages & pkg.STAGE_RESAMPLE) else md._rs_out)   # fresh resampler state
         md.set_output_format(fmt)
         yi = md.chain(bits, stages)
+        if seen is not None:
+            seen["kernels"] = md.last_variant()           # (with md.trace(True) in setup: the kernels of the integer-output call)
         assert yi.dtype == want.dtype and yi.size == want.size
         assert np.array_equal(yi.reshape(-1), want)
         assert md.num_clipped() == clipped
@@ -1615,6 +1617,32 @@ def test_chain_s16_stored_by_the_frame_kernel_without_firfilter(pkg, gain):
         assert clipped > 0
 
 
+@pytest.mark.parametrize("fmt", ["u8", "s8"])
+@pytest.mark.parametrize("fir", [True, False])
+@pytest.mark.parametrize("gain", [(2, 1.0 / 256.0), (2, 1.0 / 64.0), (1, 1.0 / 300.0), (0, 1.0 / 400.0), (None, 0)])
+def test_chain_u8_s8_stored_by_the_frame_kernel(pkg, fmt, fir, gain):
+    """u8 / s8 output (round 5): the equalised-boundary variant (cfg 3) and the no-FIRFilter variant store the two bytes of a
+    sample themselves -- tf_kernel<..., OFMT = 2 / 3>, ONE kernel, a quarter of the bytes written -- with the bytes and the clip
+    count of FormatConverter on the chain's own complexf output (src/FormatConverter.cpp:144-170); gain mode max with
+    FIRFilter (no equalised variant: its statistic needs the unfiltered samples) still converts in format_kernel."""
+    def setup(md):
+        md._rs_out = 2048000
+        if gain[0] is not None:
+            md.set_gain(gain[0], 1.0, gain[1], 4.0)
+        md.trace(True)
+    stages = (pkg.STAGE_FIR if fir else 0) | (pkg.STAGE_GAIN if gain[0] is not None else 0)
+    seen = {}
+    clipped = _chain_formats_case(pkg, 1, stages, fmt, setup, seen=seen)
+    code = {"u8": 2, "s8": 3}[fmt]
+    fused = not (fir and gain[0] == 1)
+    if fused:
+        assert len(seen["kernels"]) == 1 and "ofmt=%d" % code in seen["kernels"][0], seen
+    else:
+        assert seen["kernels"][-1] == "format_kernel<%d>" % code, seen
+    if gain in ((2, 1.0 / 64.0), (None, 0)):
+        assert clipped > 0                                # the clip counter is exercised
+
+
 @pytest.mark.parametrize("out_rate,poly", [(8192000, True), (8192000, False), (4096000, True)])
 def test_chain_s16_stored_by_the_resampler(pkg, out_rate, poly):
     """cfg 4 with s16 output: the x2 / x4 resampler converts in its store (polynomial predistorter before it)."""
@@ -1645,18 +1673,18 @@ def test_chain_s16_stored_by_the_resampler_behind_tii_and_windowing(pkg, case):
     _chain_formats_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY, "s16", setup)
 
 
-@pytest.mark.parametrize("case", ["mode2", "u8", "s8", "tii", "windowed", "rational", "nofir"])
+@pytest.mark.parametrize("case", ["mode2", "u8", "s8", "u8_windowed", "s8_mode4", "tii", "windowed", "rational", "nofir"])
 def test_chain_output_format_on_every_other_path(pkg, case):
     """Where no kernel variant stores the format itself the chain converts in format_kernel: same bytes."""
-    mode = 2 if case == "mode2" else 1
-    fmt = case if case in ("u8", "s8") else "s16"
+    mode = 2 if case == "mode2" else (4 if case == "s8_mode4" else 1)
+    fmt = case[:2] if case[:2] in ("u8", "s8") else "s16"
 
     def setup(md):
         md._rs_out = 2048000
         md.set_gain(2, 1.0, 1.0 if fmt == "s16" else 1.0 / 256.0, 4.0)
         if case == "tii":
             md.set_tii(True, 3, 5)
-        if case == "windowed":
+        if case in ("windowed", "u8_windowed"):
             md.set_window_overlap(10)
         if case == "rational":
             md._rs_out = 3072000

@@ -62,6 +62,8 @@ run("resample 8192000, no poly", mask=7, setup=lambda m: m.set_resampler(2048000
 run("poly only (native rate)", mask=7, setup=poly, B=1024)
 run("LUT only (native rate)", mask=7, setup=lambda m: m.set_lut(1.0 / 32768, np.linspace(1.0, 1.2, 32).astype(np.float32)), B=1024)
 run("no FIR -> s16", mask=1, fmt="s16")
+run("no FIR -> u8", mask=1, fmt="u8")
+run("no FIR -> s8", mask=1, fmt="s8")
 run("CFR + window 10", setup=lambda m: (m.set_cfr(True, 50.0, 0.1), m.set_window_overlap(10)))
 run("CFR + window 10, no FIR", mask=1, setup=lambda m: (m.set_cfr(True, 50.0, 0.1), m.set_window_overlap(10)))
 run("window 10", setup=lambda m: m.set_window_overlap(10))
