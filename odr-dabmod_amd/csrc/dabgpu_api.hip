@@ -158,6 +158,7 @@ struct dabgpu_ctx {
     // resampler
     DevBuf d_rs_window, d_rs_tw_in, d_rs_tw_out, d_rs_halo, d_rs_tw_s, d_rs_tw_l;
     int rs_nin = 0, rs_nout = 0;
+    int rs_halo_cur = 0;                  // which of the two halo buffers holds the state the next call reads
     size_t rs_L = 1, rs_M = 1;
     float rs_factor = 1.f;
     // scratch
@@ -597,8 +598,9 @@ int apply_settings_groups(dabgpu_ctx *c)
             }
             HIPCHK(c, upload(c->d_rs_tw_s, tsv, s));
             HIPCHK(c, upload(c->d_rs_tw_l, tlv, s));
-            HIPCHK(c, c->d_rs_halo.reserve(nin * sizeof(float2)));
-            HIPCHK(c, hipMemsetAsync(c->d_rs_halo.p, 0, nin * sizeof(float2), s));
+            HIPCHK(c, c->d_rs_halo.reserve(2 * nin * sizeof(float2)));          // two buffers: read this call's, write the next's
+            HIPCHK(c, hipMemsetAsync(c->d_rs_halo.p, 0, 2 * nin * sizeof(float2), s));
+            c->rs_halo_cur = 0;
         }
     }
     // everything above went through the context's own stream; the caller may launch on another one
@@ -732,7 +734,9 @@ int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out
     a.window = (const float *)c->d_rs_window.p;
     a.tw_in = (const float2 *)c->d_rs_tw_in.p;
     a.tw_out = (const float2 *)c->d_rs_tw_out.p;
-    a.in = d_in; a.halo = (const float2 *)c->d_rs_halo.p;
+    float2 *halo = (float2 *)c->d_rs_halo.p + (size_t)c->rs_halo_cur * (size_t)c->rs_nin;
+    float2 *halo_next = (float2 *)c->d_rs_halo.p + (size_t)(c->rs_halo_cur ^ 1) * (size_t)c->rs_nin;
+    a.in = d_in; a.halo = halo;
     a.out = d_out; a.nhops = nhops;
     a.poly = (fuse_poly && resampler_fast_ratio(c)) ? (const float *)c->d_coef.p : nullptr;
     a.clipped = s16_clipped;
@@ -740,9 +744,15 @@ int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out
     a.M = (int)c->rs_M;
     a.tw_s = (const float2 *)c->d_rs_tw_s.p;
     a.tw_l = (const float2 *)c->d_rs_tw_l.p;
+    // new halo = last two hops of the concatenation [halo | in]: the x2 / x4 kernel of Mode I writes it itself, into the
+    // other buffer (launches of one stream are in order: the next call reads what this one wrote)
+    if (resampler_writes_halo(a)) {
+        a.halo_out = halo_next;
+        HIPCHK(c, launch_resampler(a, s));
+        c->rs_halo_cur ^= 1;
+        return DABGPU_OK;
+    }
     HIPCHK(c, launch_resampler(a, s));
-    // new halo = last two hops of the concatenation [halo | in]
-    float2 *halo = (float2 *)c->d_rs_halo.p;
     if (nhops >= 2) {
         HIPCHK(c, hipMemcpyAsync(halo, d_in + (nhops - 2) * hin, 2 * hin * sizeof(float2),
                                  hipMemcpyDeviceToDevice, s));

@@ -152,6 +152,8 @@ struct ResamplerArgs {
     const float2 *tw_out;   // nout entries
     const float2 *in;       // nhops * nin/2 samples (one stream)
     const float2 *halo;     // nin samples: the two hops before `in` (zeros at stream start)
+    float2 *halo_out;       // non-null (the x2 / x4 kernel at nin = 4096 only, see resampler_writes_halo): the kernel leaves the
+                            // last two hops of [halo | in] there -- the next call's halo -- instead of a copy launched behind it
     float2 *out;            // nhops * nout/2
     const float *poly;      // nullptr, or am[5] at [0..4] and pm[5] at [8..12]: MemlessPoly fused into the store
     unsigned long long *clipped;   // non-null: store s16 pairs (FormatConverter fused, x2 / x4 kernels with nin = 4096)
@@ -163,5 +165,6 @@ struct ResamplerArgs {
 };
 hipError_t launch_resampler(const ResamplerArgs &a, hipStream_t s);
 bool resampler_has_s16(const ResamplerArgs &a);
+bool resampler_writes_halo(const ResamplerArgs &a);   // the kernel this geometry runs honours halo_out
 
 }  // namespace dabgpu

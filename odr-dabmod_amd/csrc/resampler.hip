@@ -535,6 +535,17 @@ void resampler16_kernel(const ResamplerArgs a, int hops_per_run)
 #pragma unroll
         for (int m = 0; m < 8; ++m) { in2[m] = in1[m]; in1[m] = in0[m]; in0[m] = nxt[m]; }
     }
+    // The stream's state for the next call -- the last two input hops of [halo | in] -- is in the registers of the workgroup
+    // that ran the last hop (in2 = c_{last-1}, in1 = c_last after the rotation above): it leaves them in the OTHER halo buffer
+    // (the readers of this launch use a.halo), where a device-to-device copy launched behind the kernel used to put them --
+    // one launch less per call, 25 -> 18 us for a single frame of cfg 4.
+    if (a.halo_out != nullptr && h1 == (long)a.nhops) {
+#pragma unroll
+        for (int m = 0; m < 8; ++m) {
+            a.halo_out[t + T * m] = in2[m];
+            a.halo_out[HIN + t + T * m] = in1[m];
+        }
+    }
     if (S16) s16_flush_count(nclip, a.clipped);
 }
 
@@ -590,6 +601,12 @@ template <int LOGNIN> hipError_t launch_resampler_n(const ResamplerArgs &a, hipS
 }
 
 }  // namespace
+
+// the kernel that leaves the next call's halo behind itself (resampler16_kernel): x2 and x4 at nin = 4096 (Mode I)
+bool resampler_writes_halo(const ResamplerArgs &a)
+{
+    return a.nin == 4096 && a.nout % a.nin == 0 && (a.nout / a.nin == 2 || a.nout / a.nin == 4);
+}
 
 // the kernels that store s16 themselves: x2 and x4 at nin = 4096 (Mode I)
 bool resampler_has_s16(const ResamplerArgs &a)

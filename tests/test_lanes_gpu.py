@@ -408,3 +408,53 @@ def test_setters_from_another_thread_while_batches_are_in_flight_on_the_lanes(pk
         assert len(seen) >= 2
     finally:
         md.close()
+
+
+@pytest.mark.parametrize("case", ["cfg4", "cfg4_s16", "x2_lut", "tii_cfr", "rational"])
+def test_resampler_chains_on_the_contexts_own_stream_are_one_stream(pkg, case):
+    """A chain with the Resampler on the context's own stream stays on lane 0, in call order (its state runs from call to call)
+    -- whatever dabgpu_set_lanes says.  Twelve calls of five frames as ONE stream (the halo crosses every call; the x2 / x4
+    kernel writes it itself, into the other of two buffers) with three lanes set against one: the same bytes, for cfg 4, its
+    s16 form, x2 with the LUT predistorter (a separate kernel behind the resampler), TII + CFR in front, and a rational ratio
+    (the general kernel, halo copied behind it); cfg 4 also against the oracle's stream."""
+    import torch
+    B, calls = 5, 12
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=4500 + i) for i in range(B * calls)]).reshape(calls, B, per)
+    d_bits = torch.from_numpy(bits).cuda()
+    stages = pkg.STAGE_GAIN | pkg.STAGE_FIR | pkg.STAGE_RESAMPLE | pkg.STAGE_POLY
+    fmt = "s16" if case == "cfg4_s16" else None
+    outs, extra = {}, {}
+    for lanes in (1, 3):
+        md = pkg.Modulator(mode=1, max_frames=B)
+        try:
+            md.set_gain(pkg.GAIN_VAR, 1.0, 0.6 if fmt else 1.0 / 50000.0, 4.0)
+            rate = {"x2_lut": 4096000, "rational": 3072000}.get(case, 8192000)
+            md.set_resampler(2048000, rate)
+            if case == "x2_lut":
+                md.set_lut(1.0 / 32768, np.linspace(1.0, 1.2, 32).astype(np.float32))
+            else:
+                md.set_poly(POLY_AM, POLY_PM)
+            if case == "tii_cfr":
+                md.set_tii(True, 3, 5)
+                md.set_cfr(True, 50.0, 0.1)
+            md.set_output_format(fmt)
+            md.set_lanes(lanes)
+            ns = md.out_samples_per_frame(stages)
+            d_out = torch.zeros((calls, B, ns), dtype=torch.complex64 if fmt is None else torch.int32, device="cuda")
+            torch.cuda.synchronize()
+            for i in range(calls):
+                md.chain_dev_queued(d_bits[i], B, stages, d_out[i])
+            md.synchronize()
+            outs[lanes] = d_out
+            extra[lanes] = (md.num_clipped() if fmt else None, md.cfr_stats(B - 1)["num_clip"] if case == "tii_cfr" else None)
+        finally:
+            md.close()
+    assert bool((_u32(outs[1]) == _u32(outs[3])).all())
+    assert extra[1] == extra[3]
+    if case == "cfg4":
+        ch = O.Chain(mode=1, stages=15, gain_mode=2, normalise=1.0 / 50000.0, out_rate=8192000, am=POLY_AM, pm=POLY_PM)
+        ref = ch.process(bits.reshape(calls * B, per))
+        y = outs[3].cpu().numpy().reshape(calls * B, -1)
+        for f in (0, 1, B, 3 * B + 2, calls * B - 1):
+            assert rel_rms(y[f], ref[f]) < 1e-6, f

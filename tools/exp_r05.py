@@ -12,6 +12,8 @@
   parts      cfg 4's two kernels one at a time and the chain: time, power, joules per frame
   cfg3power  cfg 3 (or + cfr / nofir / window) at B frames with board power: one arm of an A/B over DABGPU_LIB builds
   chunks     cfg 3 on three lanes: runs of symbols per frame against the batch size
+  cfg4small  cfg 4 at small batches on one stream: the chain, the frame kernel alone, the resampler alone
+  cfg4lanes  cfg 4 on the context's own stream, 1 ... 4 lanes (the chain pipelined across calls)
 """
 import importlib
 import json
@@ -264,6 +266,69 @@ def chunks(argv):
         torch.cuda.empty_cache()
 
 
+def cfg4small(argv):
+    """cfg 4 (frame kernel -> x4 resampler + predistorter) at small batches, one context: microseconds per call of the chain,
+    of the frame kernel alone and of the resampler alone -- what pipelining the two ACROSS calls could hide."""
+    st = torch.cuda.Stream(device=dev)
+    h = st.cuda_stream
+    for B in [int(x) for x in argv] or [1, 4, 16, 64, 256]:
+        md = _cfg4(B)
+        with torch.cuda.stream(st):
+            bits = torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device=dev)
+            native = torch.empty((B, 196608), dtype=torch.complex64, device=dev)
+            out = torch.empty((B, 4 * 196608), dtype=torch.complex64, device=dev)
+        steps = {"chain": lambda: md.chain_dev(bits, B, 15, out, stream=h),
+                 "frame_kernel": lambda: md.chain_dev(bits, B, 3, native, stream=h),
+                 "resampler_poly": lambda: md.post_process_dev(native, P.STAGE_RESAMPLE | P.STAGE_POLY, out, stream=h)}
+        rec = dict(exp="cfg4small", frames_per_call=B)
+        calls = max(20, min(300, 4096 // B))
+        for name, step in steps.items():
+            def body():
+                for _ in range(calls):
+                    step()
+            body()
+            st.synchronize()
+            rec[name + "_us"] = round(min(event_time(st, body, 2) for _ in range(3)) / calls * 1e3, 2)
+        rec["frames_per_s"] = round(B / (rec["chain_us"] * 1e-6), 1)
+        rec["roofline_frac"] = round(ALGO4 * rec["frames_per_s"] / 8e12, 4)
+        emit(**rec)
+        md.close()
+
+
+def cfg4lanes(argv):
+    """cfg 4 on the context's own stream, 1 ... 4 lanes: the native-rate part of call i + 1 on a lane of its own while lane 0
+    runs the resampler of call i (the chain pipelined across calls)."""
+    st = torch.cuda.Stream(device=dev)
+    stages = 15
+    for B in [int(x) for x in argv] or [1, 4, 16, 64, 256]:
+        with torch.cuda.stream(st):
+            bits = [torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device=dev) for _ in range(4)]
+            outs = [torch.empty((B, 4 * 196608), dtype=torch.complex64, device=dev) for _ in range(4)]
+        st.synchronize()
+        for n in (1, 2, 3, 4):
+            md = _cfg4(B)
+            md.set_lanes(n)
+            calls = max(20, min(300, 4096 // B))
+            k = [0]
+
+            def body():
+                md.wait_for_stream(st.cuda_stream)
+                for _ in range(calls):
+                    i = k[0] & 3
+                    k[0] += 1
+                    md.chain_dev_queued(bits[i], B, stages, outs[i])
+                md.stream_wait_for(st.cuda_stream)
+            body()
+            st.synchronize()
+            best = min(event_time(st, body, 2) for _ in range(3)) / calls
+            fps = B / (best * 1e-3)
+            emit(exp="cfg4lanes", frames_per_call=B, lanes=n, us_per_call=round(best * 1e3, 2), frames_per_s=round(fps, 1),
+                 roofline_frac=round(ALGO4 * fps / 8e12, 4))
+            md.close()
+        del bits, outs
+        torch.cuda.empty_cache()
+
+
 def cfg3power(argv):
     """cfg 3 (or cfg3 + option) at B frames per launch with board power: one arm of an A/B over libraries
     (DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/exp_r05.py cfg3power [B] [cfr|nofir|window] [tag])."""
@@ -300,4 +365,4 @@ def cfg3power(argv):
 
 if __name__ == "__main__":
     what = sys.argv[1] if len(sys.argv) > 1 else "lanes"
-    {"lanes": lanes, "handover": handover, "rsonly": rsonly, "tfonly": tfonly, "parts": parts, "cfg3power": cfg3power, "chunks": chunks}[what](sys.argv[2:])
+    {"lanes": lanes, "handover": handover, "rsonly": rsonly, "tfonly": tfonly, "parts": parts, "cfg3power": cfg3power, "chunks": chunks, "cfg4small": cfg4small, "cfg4lanes": cfg4lanes}[what](sys.argv[2:])
