@@ -16,14 +16,14 @@ import sys
 p = sys.argv[1]
 s = open(p).read()
 old = '''            lds_barrier();                    // bitbuf[bb] written (prologue / previous iteration)
-            if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
+            if (s >= 2) advance(bitbuf + bb * kBitStride);
             pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)'''
 new = '''            if (EQ) {
                 P = pf_prev;                      // EXPERIMENT: the phases arrive as one dword per lane and symbol
                 pf = reinterpret_cast<const uint32_t *>(fbits)[(size_t)(min(s, 74)) * (K / 16) + (t % (K / 16))];
             } else {
             lds_barrier();                    // bitbuf[bb] written (prologue / previous iteration)
-            if (s >= 2) advance(reinterpret_cast<const uint8_t *>(bitbuf + bb * kBitStride));
+            if (s >= 2) advance(bitbuf + bb * kBitStride);
             pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
             }'''
 assert old in s
