@@ -126,3 +126,43 @@ def test_counter_math_and_the_static_mix_belong_to_the_committed_sources():
         assert m["valu_instructions"] > 100 and 0.0 <= m["packed_fraction_of_valu"] <= 1.0
         t = m["issue_model_simd_ticks"]
         assert abs(t["valu"] + t["lds"] + t["vmem"] - t["total"]) < 0.5
+
+
+def test_power_probe_picks_the_devices_own_card_or_refuses(tmp_path, monkeypatch):
+    """tools/power_probe.py (advisor, round 4): without a PCI mapping the probe falls back to "the card whose power rises" --
+    idle reading taken when the probe is created -- and REFUSES when a second card rises by more than half as much (another
+    tenant's load), instead of reporting that card's watts as the kernel's."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import power_probe as pp
+    cards = []
+    for i in range(3):
+        d = tmp_path / ("card%d" % i)
+        d.mkdir()
+        (d / "power1_input").write_text("250000000")
+        (d / "freq1_input").write_text("2400000000")
+        (d / "power1_cap").write_text("1400000000")
+        cards.append(str(d))
+    monkeypatch.setattr(pp, "_hwmon_of_device", lambda i: None)
+    monkeypatch.setattr(pp.glob, "glob", lambda pat: list(cards))
+    probe = pp.PowerProbe(0)
+    assert probe.by == "largest rise" and len(probe.cards) == 3
+    state = {"n": 0}
+
+    def busy(load):
+        def f():
+            state["n"] += 1
+            for d, w in zip(cards, load):
+                open(os.path.join(d, "power1_input"), "w").write(str(int(w * 1e6)))
+            return state["n"] % 13 != 0
+        return f
+    r = probe.measure(busy((1350, 260, 255)), interval=0.0)
+    assert r["watts_avg"] == 1350.0 and r["watts_before"] == 250.0 and r["watts_cap"] == 1400.0 and "largest rise" in r["card"]
+    r = probe.measure(busy((1350, 900, 255)), interval=0.0)
+    assert "error" in r and "ambiguous" in r["error"]
+    # with the PCI mapping there is exactly one card and nothing to guess
+    monkeypatch.setattr(pp, "_hwmon_of_device", lambda i: cards[1])
+    probe = pp.PowerProbe(0)
+    assert probe.cards == [cards[1]] and probe.by == "pci"
+    r = probe.measure(busy((1350, 900, 255)), interval=0.0)
+    assert r["watts_avg"] == 900.0
