@@ -1,0 +1,165 @@
+"""Randomised configurations of the fused chain against the oracle.
+
+tests/test_dispatch_matrix.py walks a fixed grid of (mode x gain x filter class x window x CFR x TII x format) with one
+workgroup per frame and the host entry point.  This file draws, from a fixed seed, combinations that grid does not reach:
+any filter length, any window width that fits, resampling ratios with and without the predistorter, every output format,
+several runs of symbols per frame, one to five frames per call, two consecutive calls of one stream (resampler state, TII
+frame parity, the CFR statistics' rotating symbol), and the three ways in: host buffers, a caller's stream, the context's own
+stream on three lanes -- with the native-rate hand-over in pieces where it applies.  Same bars as everywhere: complexf
+rel-RMS < 1e-6 per frame against the oracle; integers at most one step apart, rarely.
+
+Semantics of the stages: /root/reference/src/DabModulator.cpp:385-419 (wiring) and the files each stage cites in include/dabgpu.h.
+"""
+import numpy as np
+import pytest
+
+import oracle as O
+from tests.conftest import load_pkg
+from tests.golden.synth import POLY_AM, POLY_PM
+
+pytestmark = pytest.mark.gpu
+
+CP = {1: 504, 2: 126, 3: 63, 4: 252}
+import os
+
+N_CASES = int(os.environ.get("DABGPU_FUZZ_CASES", "256"))     # (a one-off hunt: DABGPU_FUZZ_CASES=2000 python -m pytest tests/test_fuzz_gpu.py -m gpu)
+
+
+def _draw(rs):
+    mode = int(rs.choice([1, 1, 1, 1, 2, 3, 4]))
+    cp = CP[mode]
+    c = {"mode": mode}
+    c["gain"] = rs.choice([None, 0, 1, 2, 2, 2])
+    c["gain"] = None if c["gain"] is None else int(c["gain"])
+    kind = rs.choice(["none", "default", "short", "long"], p=[0.25, 0.35, 0.3, 0.1])
+    if kind == "none":
+        c["taps"] = None
+    elif kind == "default":
+        c["taps"] = O.fir_default_taps()
+    else:
+        n = int(rs.randint(1, 61)) if kind == "short" else int(rs.choice([101, 200, 300]))
+        k = np.arange(n) - (n - 1) / 2.0
+        h = 0.79 * np.sinc(0.79 * k) * np.hamming(n) if n > 1 else np.ones(1)
+        c["taps"] = (h / h.sum()).astype(np.float32)
+    c["overlap"] = 0 if rs.rand() < 0.6 else int(rs.randint(1, min(128, cp) + 1))
+    c["cfr"] = bool(rs.rand() < 0.2)
+    c["tii"] = bool(mode in (1, 2) and rs.rand() < 0.25)
+    c["fmt"] = rs.choice([None, None, None, "s16", "u8", "s8"])
+    c["fmt"] = None if c["fmt"] is None else str(c["fmt"])
+    # resampling (and the predistorter, which needs |x| < 1: var gain at the SDR normalisation, complexf out)
+    c["rate"] = 2048000
+    c["poly"] = False
+    if rs.rand() < 0.3:
+        c["rate"] = int(rs.choice([4096000, 8192000, 8192000, 3072000, 1024000]))
+        if c["gain"] == 2 and c["fmt"] is None and rs.rand() < 0.6:
+            c["poly"] = True
+    c["chunks"] = int(rs.choice([0, 0, 1, 3, 7]))
+    c["frames"] = int(rs.choice([1, 2, 3, 5]))
+    c["entry"] = str(rs.choice(["host", "stream", "lanes"]))
+    c["pieces"] = int(rs.choice([0, 2]))
+    c["seed"] = int(rs.randint(1 << 30))
+    return c
+
+
+def _normalise(c):
+    if c["poly"]:
+        return 1.0 / 50000.0
+    if c["fmt"] is None:
+        return 1.0 / 50000.0 if c["gain"] == 2 else 1.0
+    full = 32767.0 if c["fmt"] == "s16" else 127.0
+    return {None: 1.0, 0: full / 2.0e5, 1: full / 50000.0, 2: full / 50000.0}[c["gain"]]
+
+
+def _cases():
+    rs = np.random.RandomState(20250930)
+    return [_draw(rs) for _ in range(N_CASES)]
+
+
+def _id(c):
+    t = "none" if c["taps"] is None else str(len(c["taps"]))
+    return "m%d-g%s-t%s-w%d-c%d-i%d-%s-r%d%s-k%d-f%d-%s-p%d" % (
+        c["mode"], c["gain"], t, c["overlap"], c["cfr"], c["tii"], c["fmt"] or "cf32", c["rate"] // 1000,
+        "p" if c["poly"] else "", c["chunks"], c["frames"], c["entry"], c["pieces"])
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    return load_pkg()
+
+
+@pytest.mark.parametrize("c", _cases(), ids=_id)
+def test_random_configuration_against_the_oracle(pkg, c):
+    import torch
+    mode, nf = c["mode"], c["frames"]
+    md = pkg.Modulator(mode=mode, max_frames=nf, chunks_per_frame=c["chunks"])
+    try:
+        K = md.geometry["carriers"]
+        norm = _normalise(c)
+        clip = float(np.float32(50.0 * np.sqrt(K / 1536.0)))
+        stages = 0
+        kw = dict(mode=mode, window_overlap=c["overlap"])
+        if c["gain"] is not None:
+            stages |= pkg.STAGE_GAIN
+            md.set_gain(c["gain"], 1.0, norm, 4.0)
+            kw.update(gain_mode=c["gain"], normalise=norm)
+        if c["taps"] is not None:
+            stages |= pkg.STAGE_FIR
+            md.set_fir_taps(c["taps"])
+            kw.update(taps=c["taps"])
+        md.set_window_overlap(c["overlap"])
+        if c["cfr"]:
+            md.set_cfr(True, clip, 0.1)
+            kw.update(cfr=(clip, 0.1))
+        if c["tii"]:
+            md.set_tii(True, 3, 5, False)
+            kw.update(tii=(3, 5, False))
+        if c["rate"] != 2048000:
+            stages |= pkg.STAGE_RESAMPLE
+            md.set_resampler(2048000, c["rate"])
+            kw.update(out_rate=c["rate"])
+        if c["poly"]:
+            stages |= pkg.STAGE_POLY
+            md.set_poly(POLY_AM, POLY_PM)
+            kw.update(am=POLY_AM, pm=POLY_PM)
+        md.set_output_format(c["fmt"])
+        md.set_handover_frames(c["pieces"])
+        kw.update(stages=stages)
+        per = md.geometry["tf_input_bytes"]
+        rs = np.random.RandomState(c["seed"])
+        bits = np.frombuffer(rs.bytes(2 * nf * per), np.uint8).reshape(2, nf, per)
+        ns = md.out_samples_per_frame(stages)
+        dt = np.dtype(getattr(md, "_out_dtype", np.complex64))
+        got = []
+        if c["entry"] == "host":
+            for i in range(2):
+                got.append(md.chain(bits[i], stages).copy())
+        else:
+            d_bits = torch.from_numpy(bits.copy()).cuda()
+            tdt = torch.complex64 if c["fmt"] is None else {"s16": torch.int32, "u8": torch.int16, "s8": torch.int16}[c["fmt"]]
+            d_out = torch.zeros((2, nf, ns), dtype=tdt, device="cuda")
+            torch.cuda.synchronize()
+            if c["entry"] == "stream":
+                st = torch.cuda.Stream()
+                for i in range(2):
+                    md.chain_dev(d_bits[i], nf, stages, d_out[i], stream=st.cuda_stream)
+                st.synchronize()
+            else:
+                for i in range(2):
+                    md.chain_dev_queued(d_bits[i], nf, stages, d_out[i])
+                md.synchronize()
+            raw = d_out.cpu().numpy()
+            for i in range(2):
+                got.append(raw[i].view(dt).reshape(nf, -1))
+        ref = O.Chain(**kw).process(bits.reshape(2 * nf, per)).reshape(2, nf, -1)
+        for i in range(2):
+            if c["fmt"] is None:
+                for f in range(nf):
+                    err = np.linalg.norm(got[i][f].astype(np.complex128) - ref[i][f]) / max(np.linalg.norm(ref[i][f]), 1e-30)
+                    assert err < 1e-6, "call %d frame %d: rel-RMS %.3g" % (i, f, err)
+            else:
+                want, _ = O.format_convert(ref[i], c["fmt"])
+                d = np.abs(got[i].reshape(-1).astype(np.int32) - want.reshape(-1).astype(np.int32))
+                assert d.max() <= 1 and float((d != 0).mean()) < 2e-2, "call %d: max step %d, %.2g of the components off" % (
+                    i, d.max(), float((d != 0).mean()))
+    finally:
+        md.close()
