@@ -458,3 +458,45 @@ def test_resampler_chains_on_the_contexts_own_stream_are_one_stream(pkg, case):
         y = outs[3].cpu().numpy().reshape(calls * B, -1)
         for f in (0, 1, B, 3 * B + 2, calls * B - 1):
             assert rel_rms(y[f], ref[f]) < 1e-6, f
+
+
+def test_three_threads_three_contexts_each_on_its_own_lanes(pkg):
+    """A head-end with several multiplexes: three host threads, one context each, every context with three lanes (nine internal
+    streams probed for hardware queues while the other threads are already launching), different settings per context, twenty
+    calls of four frames each on the context's own stream -- every frame against the oracle."""
+    import threading
+    import torch
+    per = O.tf_input_bytes(1)
+    B, calls = 4, 20
+    kws = [dict(gain_mode=2, normalise=1.0 / 50000.0), dict(gain_mode=1, normalise=1.0), dict(gain_mode=0, normalise=1.0 / 4000.0)]
+    bits = [np.stack([synth_bits(per, seed=4700 + 100 * k + i) for i in range(B)]) for k in range(3)]
+    refs = [O.Chain(mode=1, stages=3, **kws[k]).process(bits[k]) for k in range(3)]
+    results, errors = [None] * 3, []
+
+    def run(k):
+        try:
+            md = pkg.Modulator(mode=1, max_frames=B)
+            md.set_gain(kws[k]["gain_mode"], 1.0, kws[k]["normalise"], 4.0)
+            d_bits = torch.from_numpy(bits[k]).cuda()
+            outs = [torch.zeros((B, 196608), dtype=torch.complex64, device="cuda") for _ in range(4)]
+            torch.cuda.synchronize()
+            for i in range(calls):
+                md.chain_dev_queued(d_bits, B, 3, outs[i & 3])
+            md.synchronize()
+            results[k] = ([o.cpu().numpy() for o in outs], md.lanes_info())
+            md.close()
+        except Exception as e:          # surfaced in the main thread below
+            errors.append(repr(e))
+
+    threads = [threading.Thread(target=run, args=(k,)) for k in range(3)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    for k in range(3):
+        outs, (n, own) = results[k]
+        assert n == 3
+        for o in outs:
+            for f in range(B):
+                assert rel_rms(o[f], refs[k][f]) < 1e-6, (k, f)
