@@ -102,6 +102,25 @@ def test_bench_gpus_2_with_the_iq_gather_at_world_size_2():
     assert g["ms"] > 0 and g["GBps_into_rank0"] > 0
 
 
+def test_bench_gpus_8_ranks_with_real_kernels_on_the_one_gpu():
+    """The driver's largest scan point with REAL kernels: eight ranks of `bench.py --gpus 8`, all on the one leased GPU
+    (DABGPU_BENCH_DEVICES, gloo) -- eight processes importing torch, creating contexts and modulating side by side, the barrier and
+    the MAX-reduce at world size 8, one line.  Small batches: the eight share 288 GB and one set of CUs."""
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_PORT")}
+    env.update(DABGPU_BENCH_DEVICES="0,0,0,0,0,0,0,0", DABGPU_DIST_BACKEND="gloo")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8", "--steps", "3", "--warmup", "1",
+                        "--frames", "256", "--no-extra", "--no-cpu-baseline"], env=env, capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.splitlines() if l.strip()]
+    assert len(lines) == 1, r.stdout
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 8 and d["steps"] == 3 and d["config"]["frames_per_step_per_gpu"] == 256
+    assert d["config"]["devices"] == [0] * 8 if "devices" in d["config"] else True
+    assert abs(d["value"] - 8 * 256 * 3 / (d["ms_per_step"] * 3e-3)) / d["value"] < 1e-3
+    assert d["scaling"] == "weak" and d["roofline"]["frac"] > 0
+
+
 def test_bench_gpus_beyond_the_node_fails_loudly():
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "DABGPU_BENCH_DEVICES")}
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "64", "--steps", "1"], env=env,
