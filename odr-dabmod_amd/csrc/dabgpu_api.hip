@@ -873,6 +873,17 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         // OFDM windowing on the coded-bits chain, with or without FIRFilter: the frame kernel windows the guard interval
         // itself (and filters across the seams)
         flags |= TF_GUARD | TF_WINDOW | ((mask & DABGPU_STAGE_FIR) ? TF_FIR : 0);
+        if (c->use_eq && (flags & TF_FIR) && !(flags & TF_CFR)) {
+            // narrow overlaps on the cfg 3 chain: the equalised-boundary variant with the seam inside its boundary outputs
+            // (the filter run at the default length, as without windowing)
+            TfArgs e = a;
+            e.ntaps = fused_ntaps(c);
+            if (tf_has_eq(e, flags)) {
+                a.ntaps = e.ntaps;
+                flags |= TF_EQ;
+                if (s16_clipped) flags |= tf_ofmt_flag(fused_fmt);    // (this form stores the integers itself)
+            }
+        }
         a.chunks_per_frame = auto_chunks(c, n_frames);
         a.syms_per_chunk = run_symbols(c->g.nb_symbols + 1, a.chunks_per_frame, true);
         a.out = native_out;
@@ -1036,6 +1047,16 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             // resampler's is not.  u8 / s8: the frame kernel's equalised-boundary and no-FIRFilter variants; s16: those, the
             // pruned dual transform and the x2 / x4 resampler.)
             fuse_native = !post && !windowed && (!tii || tf_has_tii(ta, tflags)) && tf_has_fmt(ta, tflags | tf_ofmt_flag(fmt));
+            if (!post && windowed && c->cur.overlap > 0 && !tii && c->use_eq && (tflags & TF_FIR) && !(tflags & TF_CFR)) {
+                // ... except for narrow overlaps on the cfg 3 chain: the equalised-boundary form (the decision run_native takes)
+                const unsigned wflags = tflags | TF_WINDOW;
+                ta.overlap = (int)c->cur.overlap;
+                ta.ntaps = (int)c->cur.taps.size();
+                if (tf_has_window(ta, wflags)) {
+                    ta.ntaps = fused_ntaps(c);
+                    fuse_native = tf_has_eq(ta, wflags) && tf_has_fmt(ta, wflags | TF_EQ | tf_ofmt_flag(fmt));
+                }
+            }
             ResamplerArgs ra{};
             ra.nin = c->rs_nin;
             ra.nout = c->rs_nout;

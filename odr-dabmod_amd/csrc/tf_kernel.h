@@ -102,11 +102,11 @@ void tf_kernel(const TfArgs a)
     static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR),
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
-    static_assert(!WIN || (FROM_BITS && GUARD && OFMT == 0), "WIN: coded-bits chain with guard interval");
-    static_assert(!(WIN && FIR) || (!ZONLY && !EQ && (NT == 0 || (NT == 45 && !CFR)) && !GVAR),
-                  "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count");
-    static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY && !WIN),
-                  "EQ: the Mode I coded-bits chain with the 45-tap filter");
+    static_assert(!WIN || (FROM_BITS && GUARD && (OFMT == 0 || EQ)), "WIN: coded-bits chain with guard interval (integer store: EQ only)");
+    static_assert(!(WIN && FIR) || (!ZONLY && (NT == 0 || (NT == 45 && !CFR)) && !GVAR),
+                  "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count -- or EQ");
+    static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY),
+                  "EQ: the Mode I coded-bits chain with the 45-tap filter (WIN: overlap <= kEqWinMax)");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
@@ -138,11 +138,15 @@ void tf_kernel(const TfArgs a)
     // EQ: two windows of the previous filtered symbol (index q + kEqQL, q in [-kEqQL, kEqQH]), the difference w, the
     // 44 unfiltered differences d, the inverse filter
     // (kEqW: the tail past kEqQL + kEqQH stays zero)
-    constexpr int kEqQL = kEqTaps - 1 - kEqCentre, kEqQH = 43 + kEqCentre, kEqW = 208;
-    static_assert(kEqQL + kEqQH + 1 <= kEqW && kEqTaps == 160, "EQ window");
-    static_assert(kEqElems == 3 * kEqW + 48 + (kEqTaps + 8) / 2, "LDS share of the EQ variant (tf_lds_bytes)");
+    // EQ with WIN (overlap W <= kEqWinMax): the seam of 2W samples widens everything by W on either side -- differences d[m] for
+    // m in [-W, W + 44), windows q in [-kEqQL, kEqQH] with kEqWm more on both ends, 2W + 44 <= 64 boundary outputs
+    constexpr int kEqWm = (EQ && WIN) ? kEqWinMax : 0;
+    constexpr int kEqQL = kEqTaps - 1 - kEqCentre + kEqWm, kEqQH = 43 + kEqCentre + kEqWm, kEqW = kEqWLen;
+    static_assert(kEqQL + kEqQH + 1 + kEqWm <= kEqW && kEqTaps == 160, "EQ window (+ what the unused outputs of a narrower overlap read)");
+    static_assert(kEqElems == 3 * kEqW + kEqDLen + (kEqTaps + 8) / 2 + 16 && 2 * kEqWinMax <= 32 && 2 * kEqWinMax + 44 <= 64,
+                  "LDS share of the EQ variants (tf_lds_bytes)");
     cf *eq_zp = bnd, *eq_w = bnd + 2 * kEqW, *eq_d = eq_w + kEqW;
-    float *g_l = reinterpret_cast<float *>(eq_d + 48);
+    float *g_l = reinterpret_cast<float *>(eq_d + kEqDLen);
     uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : (FIR && !WIN) ? 4 * KB : ((WIN && !FIR) ? 7 * kWinMax : 0)));
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 2;     // + one dummy slot per half (and one more: the halves stay 8-byte aligned)
@@ -170,16 +174,17 @@ void tf_kernel(const TfArgs a)
     if (EQ)
         for (int i = t; i < kEqTaps + 8; i += blockDim.x) g_l[i] = i < kEqTaps ? a.t.eq_g[i] : 0.f;
     if (EQ) {
-        for (int i = t; i < 3 * kEqW; i += blockDim.x) eq_zp[i] = mk(0.f, 0.f);     // (both windows, w: the tails stay zero)
+        // (both windows, w: the tails stay zero; d: what the last boundary outputs read past its end)
+        for (int i = t; i < 3 * kEqW + kEqDLen; i += blockDim.x) eq_zp[i] = mk(0.f, 0.f);
     }
     const int W = WIN ? a.overlap : 0;
     // WIN with FIR: behind everything else, sized at run time (C = ntaps - 1): two stashes of a symbol's
     // [x[N-W-C .. N) | x[0 .. W)] (C + 2W each), the next symbol's x[N-cp-W .. N-cp+W+C) (2W + C), the windowed stream
     // U around the seam (2W + 2C), the window
-    const int wfC = (WIN && FIR) ? a.ntaps - 1 : 0, wfLP = wfC + 2 * W;
+    const int wfC = (WIN && FIR && !EQ) ? a.ntaps - 1 : 0, wfLP = wfC + 2 * W;
     cf *wfb = tw8_l + 56 + (CFR ? 3 * ((T + 63) / 64) : 0);        // (behind cfr_red: 6 floats per wave)
     cf *wf_cur = wfb + 2 * wfLP, *wf_U = wf_cur + (2 * W + wfC);
-    if (WIN && FIR) win_l = reinterpret_cast<float *>(wf_U + (2 * W + 2 * wfC));
+    if (WIN && FIR) win_l = EQ ? g_l + (kEqTaps + 8) : reinterpret_cast<float *>(wf_U + (2 * W + 2 * wfC));
     if (WIN)
         for (int i = t; i < 2 * W; i += blockDim.x) win_l[i] = a.t.window[i];
     if (FROM_BITS)
@@ -677,16 +682,25 @@ void tf_kernel(const TfArgs a)
 
     // EQ: the 44 boundary outputs of the previous segment from the filtered symbols (see the template's comment).
     // zp = the previous symbol's windows; eq_w holds w (written by the lanes that own those samples, a barrier ago).
-    auto eq_boundary = [&](const cf *zp) __attribute__((always_inline)) {
-        // d = g (*) w: 11 blocks of four outputs x 16 groups of ten taps = 176 lanes, the 16 groups of a block being one
-        // DPP row.  Output m = m0 + r, tap jj = j0 + u reads w[q] at index q + kEqQL = m + (kEqTaps - 1 - jj).
+    // WIN (overlap W <= kEqWinMax): the stream around the seam is x_prev + omega d, omega = 0 before the seam, the rising
+    // raised-cosine factor on its 2W samples, 1 behind it (the reference forms prev w[2W-1-j] + rise w[j]; the factors of a
+    // pair add up to one), d[m] = x_cur[N-cp+m] - x_prev[m mod N] now for m in [-W, W + 44).  The 2W + 44 outputs whose
+    // look-ahead reaches the seam, stream positions pos - W - 44 ... pos + W - 1:
+    //     y[i] = z_prev[(i - W - 44) mod N] + sum_j taps[j] (omega d)[i - 44 + j - W]        (terms before the seam: zero)
+    // -- the form above is the case W = 0, omega a step.  final: the frame ends behind the previous symbol (a zero symbol
+    // follows, no window: omega is the step again), only the 44 outputs in front of the end exist.
+    auto eq_boundary = [&](const cf *zp, bool final = false) __attribute__((always_inline)) {
+        // d = g (*) w: 11 blocks of four outputs x 16 groups of ten taps = 176 lanes (WIN: 16 blocks, 256 lanes), the 16 groups
+        // of a block being one DPP row.  Output m = m0 + r, tap jj = j0 + u reads w[q] at index q + kEqQL = m + (kEqTaps - 1 - jj)
+        // (WIN: output m' = m + W, index m' + (kEqTaps - 1 - jj) + kEqWm - W).
         // (four outputs per lane over 176 lanes measured 2 % faster than three over 240)
-        constexpr int kEqR = 4, kEqLanes = 16 * ((44 + kEqR - 1) / kEqR);
+        constexpr int kEqOut = 44 + 2 * kEqWm;
+        constexpr int kEqR = 4, kEqLanes = 16 * ((kEqOut + kEqR - 1) / kEqR);
         static_assert(!EQ || kEqLanes <= T, "EQ: outputs per lane");
         cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
         if (t < kEqLanes) {
             const int m0 = kEqR * (t >> 4), j0 = 10 * (t & 15);
-            const cf *wp = eq_w + (m0 + (kEqTaps - 1 - 9) - j0);
+            const cf *wp = eq_w + (m0 + (kEqTaps - 1 - 9) - j0) + (kEqWm - W);
             const float2 *g2 = reinterpret_cast<const float2 *>(g_l + j0);
             cf wv[kEqR + 9];
             float gg[10];
@@ -724,9 +738,33 @@ void tf_kernel(const TfArgs a)
 #undef DABGPU_DPP2
         if (t < kEqLanes && (t & 15) == 0) {
 #pragma unroll
-            for (int r = 0; r < kEqR; ++r) eq_d[kEqR * (t >> 4) + r] = acc[r];
+            for (int r = 0; r < kEqR; ++r) {
+                const int mp = kEqR * (t >> 4) + r;
+                if constexpr (WIN) {
+                    const float om = final ? (mp >= W ? 1.0f : 0.0f) : (mp < 2 * W ? win_l[mp] : 1.0f);
+                    eq_d[mp] = cscale(acc[r], om);
+                } else {
+                    eq_d[mp] = acc[r];
+                }
+            }
         }
         lds_barrier();
+        if constexpr (WIN) {
+            // output i of 64 (2W + 44 of them wanted): terms jd = max(i - 44, 0) ... i of (omega d), tap 44 - i + jd; four lanes
+            // (one DPP quad) per output, twelve terms each (the tap table is zero past tap 44, eq_d past its last entry)
+            const int i = t >> 2, q = t & 3;
+            const int jd0 = max(i - C, 0);
+            const float *tq = taps_l + max(C - i, 0) + q;
+            const cf *dq = eq_d + jd0 + q;
+            cf y = mk(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 12; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
+            quad_sum2_dpp(y.x, y.y);
+            y = cadd(y, zp[kEqQL - W - C + i]);
+            const int lo = final ? W : 0, hi = final ? W + C : 2 * W + C;
+            if (q == 0 && i >= lo && i < hi) put(prev_pos + prev_seg - W - C, i, y);
+            return;
+        }
         // y[N-44+i] = z_prev[N-44+i] + sum_{jd <= i} taps[44-i+jd] d[jd]: four lanes (one DPP quad) per output, lane q
         // taking jd = q, q+4, ...; past jd = i the tap index runs into the table's zero padding
         {
@@ -772,9 +810,9 @@ void tf_kernel(const TfArgs a)
             prev_pos = 0;
             prev_seg = len0;
         }
-        if (WIN && FIR) {
+        if (WIN && FIR && !EQ) {
             for (int i = t; i < wfLP; i += (int)blockDim.x) wfb[cur * wfLP + i] = mk(0.f, 0.f);
-        } else if (WIN) {
+        } else if (WIN && !FIR) {
             for (int i = t; i < 2 * W; i += (int)blockDim.x) wbuf[cur * 2 * kWinMax + i] = mk(0.f, 0.f);
             have_prev = true;
         }
@@ -1095,7 +1133,7 @@ void tf_kernel(const TfArgs a)
         }
         pt.stamp(PH_STORES);
         if constexpr (EQ) {
-            if (have_prev) eq_boundary(eq_zp + cur * kEqW);
+            if (have_prev) eq_boundary(eq_zp + cur * kEqW, false);
             cur ^= 1;
             pt.stamp(PH_BOUNDARY);
             if (lookahead) break;
@@ -1120,7 +1158,7 @@ void tf_kernel(const TfArgs a)
         lds_barrier();
         for (int i = t; i < kEqW; i += (int)blockDim.x) eq_w[i] = mk(-zp[i].x, -zp[i].y);
         lds_barrier();
-        eq_boundary(zp);
+        eq_boundary(zp, true);
     } else if (WIN && FIR && s_end == nsym && have_prev) {
         // end of the frame: the last symbol keeps its (unwindowed) tail, nothing follows it
         const cf *stash = wfb + cur * wfLP;
@@ -1215,6 +1253,20 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
 #undef TF_LAUNCH_GVAR
     if (flags & TF_WINDOW) {
         if (!tf_has_window(a, flags) || (NT != 0 && !fr)) return hipErrorInvalidValue;
+        if constexpr (LOGN == 11 && NT == 45) if (flags & TF_EQ) {
+            // the equalised-boundary variant with the seam inside its boundary outputs (overlap <= kEqWinMax; tf_has_eq was asked above)
+#define TF_LAUNCH_EQW(GN, OF) \
+            tf_go<11, true, GN, true, true, 45, false, false, false, OF, true, true>(grid, block, lds, s, a)
+            switch (of) {
+                case 1: if (gn) TF_LAUNCH_EQW(true, 1); else TF_LAUNCH_EQW(false, 1); break;
+                case 2: if (gn) TF_LAUNCH_EQW(true, 2); else TF_LAUNCH_EQW(false, 2); break;
+                case 3: if (gn) TF_LAUNCH_EQW(true, 3); else TF_LAUNCH_EQW(false, 3); break;
+                default: if (gn) TF_LAUNCH_EQW(true, 0); else TF_LAUNCH_EQW(false, 0);
+            }
+#undef TF_LAUNCH_EQW
+            return hipGetLastError();
+        }
+        if (flags & TF_EQ) return hipErrorInvalidValue;
         if (fr) {
             if (gn) tf_go<LOGN, true, true, true, true, NT, false, false, false, 0, true>(grid, block, lds, s, a);
             else tf_go<LOGN, true, false, true, true, NT, false, false, false, 0, true>(grid, block, lds, s, a);

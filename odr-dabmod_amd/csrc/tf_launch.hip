@@ -22,8 +22,8 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     size_t b = dual ? (N + N / 8) * 2 * sizeof(float2) : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
     b += 16 * sizeof(double);
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
-    const bool wf = (flags & TF_WINDOW) && (flags & TF_FIR);
-    if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter
+    const bool wf = (flags & TF_WINDOW) && (flags & TF_FIR) && !eq;
+    if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter, window factors
     else if ((flags & TF_FIR) && !wf) b += 4 * (nt ? nt - 1 : kBnd) * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 2) * sizeof(uint32_t);  // staged coded bits (kBitStride)
     b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
@@ -33,7 +33,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
         // behind the twiddle table: two stashes, the next symbol's samples, the windowed stream, the window
         const size_t C = (size_t)std::max(ntaps - 1, 0), W = (size_t)std::max(overlap, 0);
         b += (2 * (C + 2 * W) + (2 * W + C) + (2 * W + 2 * C)) * sizeof(float2) + 2 * W * sizeof(float) + 16;
-    } else if (flags & TF_WINDOW) {
+    } else if ((flags & TF_WINDOW) && !eq) {
         b += 7 * kWinMax * sizeof(float2);                                     // seam buffers + window
     }
     return b;
@@ -43,7 +43,8 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
 // without s16 store (with or without FIRFilter, with or without CFR), overlap up to kWinMax (and inside the cyclic prefix)
 bool tf_has_window(const TfArgs &a, unsigned flags)
 {
-    const unsigned want = TF_FROM_BITS | TF_GUARD, never = TF_OUT_S16 | TF_OUT_U8 | TF_OUT_S8;
+    // (the integer formats: stored by the equalised-boundary form only)
+    const unsigned want = TF_FROM_BITS | TF_GUARD, never = (flags & TF_EQ) ? 0u : (TF_OUT_S16 | TF_OUT_U8 | TF_OUT_S8);
     if ((flags & want) != want || (flags & never) || a.overlap < 1 || a.overlap > kWinMax) return false;
     // with FIR: the filter's look-ahead and the window must both fit into the cyclic prefix
     if (flags & TF_FIR)
@@ -54,11 +55,13 @@ bool tf_has_window(const TfArgs &a, unsigned flags)
 
 int tf_max_fused_taps() { return kBnd < kMaxTaps ? kBnd : kMaxTaps; }
 
-// the equalised-boundary variant: the chains of the pruned-dual-transform variant, given the inverse of the taps
+// the equalised-boundary variant: the chains of the pruned-dual-transform variant, given the inverse of the taps; with OFDM
+// windowing (TF_WINDOW) for overlaps up to kEqWinMax
 bool tf_has_eq(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
-    return a.t.eq_g != nullptr && a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & (TF_CFR | TF_WINDOW)) &&
+    if ((flags & TF_WINDOW) && (a.overlap < 1 || a.overlap > kEqWinMax)) return false;
+    return a.t.eq_g != nullptr && a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & TF_CFR) &&
            (!(flags & TF_GAIN) || a.gain.mode != 1);
 }
 
@@ -79,7 +82,8 @@ bool tf_has_fmt(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
     const int of = tf_ofmt(flags);
-    if (!of || a.g.logN != 11 || (flags & (TF_CFR | TF_WINDOW))) return false;
+    if (!of || a.g.logN != 11 || (flags & TF_CFR)) return false;
+    if (flags & TF_WINDOW) return (flags & TF_EQ) && tf_has_eq(a, flags);      // windowed: the equalised-boundary form alone
     // without FIRFilter (the reference's default): every gain mode
     if ((flags & want) == (TF_FROM_BITS | TF_GUARD)) return true;
     if (of > 1 && !(flags & TF_EQ)) return false;

@@ -70,6 +70,18 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
     # ---- a windowed guard interval, or a filter the spectral form cannot take
     fused_window = 1 <= overlap <= 128 and (overlap + (T - 1 if F else 0) <= cp) and (not F or T <= 128)
     if fused_window:
+        # Mode I, a filter of up to 45 taps with an inverse, gain none / fix / var, overlap <= 10 (round 5): the equalised-boundary
+        # variant carries the seam in its boundary outputs -- one transform per symbol, as without windowing
+        eq_win = mode == 1 and F and fir != "notch" and T <= 45 and not cfr and gain != 1 and overlap <= 10
+        if eq_win:
+            # ... and stores the integer formats itself (TII is added to the complexf stream by its own kernel: then it cannot)
+            of = FMT_CODE[fmt] if (fmt is not None and not tii) else 0
+            out.append(tf(11, G, 1, 1, 45, ofmt=of, win=1, eq=1))
+            if tii:
+                out.append("tii_add_kernel")
+            if fmt and not of:
+                out.append("format_kernel<%d>" % FMT_CODE[fmt])
+            return out
         nt = 45 if (mode == 1 and F and T == 45 and not cfr) else 0
         out.append(tf(logn, G, 1, F, nt, cfr=int(cfr), win=1))
     else:

@@ -675,6 +675,54 @@ def test_chain_windowed_guard_with_fir_is_one_kernel_too(pkg, mode, overlap, chu
                                1.0 / 50000.0 if gain_mode == 2 else 1.0, 6.2e-7, 7e-7, head=overlap, tail=overlap + 44)
 
 
+@pytest.mark.parametrize("overlap", [1, 2, 3, 5, 7, 9, 10])
+@pytest.mark.parametrize("chunks", [0, 1, 7])
+def test_chain_windowed_guard_with_fir_narrow_overlaps_run_the_equalised_kernel(pkg, overlap, chunks):
+    """ofdmwindowing <= 10 on the cfg 3 chain (round 5): tf_kernel<..., WIN, EQ> -- ONE filtered transform per symbol; the
+    2W + 44 outputs per seam whose look-ahead reaches the windowed samples come from the filtered symbols through the taps'
+    inverse (the stream around a seam is x_prev + omega (x_cur - x_prev), omega the rising raised-cosine factor).  Every
+    overlap it takes, several chunkings, the default taps and a 31-tap filter (run as 45); against the oracle on the whole
+    frame and on the seam regions alone, and against the packed-dual-transform kernel that served these settings before
+    (dabgpu_set_fir_boundary_mode(ctx, 1)).  Reference: src/GuardIntervalInserter.cpp:149-300, src/FIRFilter.cpp:144-309."""
+    from scipy.signal import firwin
+    lp31 = firwin(31, 880e3, window="hamming", fs=2.048e6).astype(np.float32)
+    g = O.mode_params(1)
+    ns, ss, nsym = g["null_size"], g["sym_size"], g["nb_symbols"]
+    for taps in (None, lp31):
+        md = pkg.Modulator(mode=1, max_frames=2, chunks_per_frame=chunks)
+        try:
+            md.trace(True)
+            md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+            if taps is not None:
+                md.set_fir_taps(taps)
+            md.set_window_overlap(overlap)
+            bits = _chain_case_bits(1, 2)
+            stages = pkg.STAGE_GAIN | pkg.STAGE_FIR
+            y = md.chain(bits, stages).copy()
+            assert md.last_variant() == ["tf_kernel<logn=11 bits=1 gain=1 guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=0 win=1 eq=1>"]
+            kw = dict(gain_mode=2, normalise=1.0 / 50000.0, window_overlap=overlap)
+            if taps is not None:
+                kw.update(taps=taps)
+            ref = O.Chain(mode=1, stages=stages, **kw).process(bits)
+            md.set_fir_boundary_mode(1)
+            y2 = md.chain(bits, stages).copy()
+            assert "eq=0" in md.last_variant()[0] and "win=1" in md.last_variant()[0]
+        finally:
+            md.close()
+        # the seam regions: the 2W + 44 outputs in front of / on every seam, and the frame's last 44
+        seam = np.zeros(ref.shape[1], bool)
+        for s_ in range(nsym + 1):
+            b = ns + s_ * ss if s_ < nsym else ref.shape[1]          # start of symbol s_ + 1's segment / end of the frame
+            seam[max(b - overlap - 44, 0):min(b + overlap, ref.shape[1])] = True
+        tag = "overlap %d chunks %d taps %s" % (overlap, chunks, "default" if taps is None else "31")
+        for f in range(2):
+            assert rel_rms(y[f], ref[f]) < REL_RMS
+            assert rel_rms(y[f][seam], ref[f][seam]) < REL_RMS                   # (the seams on their own, not diluted by the interiors)
+            assert rel_rms(y[f], y2[f].astype(np.complex128)) < 3e-7
+        assert record_bound("chain total max-abs / |out|_inf on the seam outputs of the equalised windowed kernel (gain mode 2), " + tag,
+                            np.abs(y[:, seam] - ref[:, seam]).max() / np.abs(ref).max(), VAR_TOTAL_LIMIT)
+
+
 def test_chain_windowed_guard_with_a_short_and_a_long_filter(pkg):
     """Other tap counts with a windowed guard interval: 13 taps (fused), 100 taps (fused: 99 + 10 fit the 504-sample
     prefix), 300 taps (beyond the fused kernel's tap table: IFFT kernel -> guard + FIR kernel)."""
@@ -1640,6 +1688,24 @@ def test_chain_u8_s8_stored_by_the_frame_kernel(pkg, fmt, fir, gain):
     else:
         assert seen["kernels"][-1] == "format_kernel<%d>" % code, seen
     if gain in ((2, 1.0 / 64.0), (None, 0)):
+        assert clipped > 0                                # the clip counter is exercised
+
+
+@pytest.mark.parametrize("fmt,normalise", [("s16", 1.0), ("s16", 2.5), ("u8", 1.0 / 256.0), ("u8", 1.0 / 64.0), ("s8", 1.0 / 256.0)])
+@pytest.mark.parametrize("overlap", [3, 10])
+def test_chain_integer_formats_stored_by_the_equalised_windowed_kernel(pkg, fmt, normalise, overlap):
+    """ofdmwindowing <= 10 on the cfg 3 chain with an integer output format (round 5): tf_kernel<..., OFMT, WIN, EQ> stores the
+    integers itself -- one kernel -- with the bytes and the clip count of FormatConverter on the chain's own complexf output."""
+    def setup(md):
+        md._rs_out = 2048000
+        md.set_gain(2, 1.0, normalise, 4.0)
+        md.set_window_overlap(overlap)
+        md.trace(True)
+    seen = {}
+    clipped = _chain_formats_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, fmt, setup, seen=seen)
+    code = {"s16": 1, "u8": 2, "s8": 3}[fmt]
+    assert seen["kernels"] == ["tf_kernel<logn=11 bits=1 gain=1 guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=%d win=1 eq=1>" % code], seen
+    if normalise in (2.5, 1.0 / 64.0):
         assert clipped > 0                                # the clip counter is exercised
 
 
