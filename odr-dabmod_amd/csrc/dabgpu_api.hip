@@ -888,6 +888,11 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         a.syms_per_chunk = run_symbols(c->g.nb_symbols + 1, a.chunks_per_frame, true);
         a.out = native_out;
         a.out_stride = native;
+        if (tii_seg && tf_has_tii(a, flags)) {
+            a.tii_seg = tii_seg;
+            a.tii_insert0 = c->tii_insert ? 1 : 0;
+            if (tii_done) *tii_done = true;
+        }
         HIPCHK(c, launch_tf(a, flags, s));
     } else {
         // OFDM windowing: IFFT(+gain) -> windowed guard -> FIR as separate kernels
@@ -1047,14 +1052,15 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             // resampler's is not.  u8 / s8: the frame kernel's equalised-boundary and no-FIRFilter variants; s16: those, the
             // pruned dual transform and the x2 / x4 resampler.)
             fuse_native = !post && !windowed && (!tii || tf_has_tii(ta, tflags)) && tf_has_fmt(ta, tflags | tf_ofmt_flag(fmt));
-            if (!post && windowed && c->cur.overlap > 0 && !tii && c->use_eq && (tflags & TF_FIR) && !(tflags & TF_CFR)) {
+            if (!post && windowed && c->cur.overlap > 0 && c->use_eq && (tflags & TF_FIR) && !(tflags & TF_CFR)) {
                 // ... except for narrow overlaps on the cfg 3 chain: the equalised-boundary form (the decision run_native takes)
                 const unsigned wflags = tflags | TF_WINDOW;
                 ta.overlap = (int)c->cur.overlap;
                 ta.ntaps = (int)c->cur.taps.size();
                 if (tf_has_window(ta, wflags)) {
                     ta.ntaps = fused_ntaps(c);
-                    fuse_native = tf_has_eq(ta, wflags) && tf_has_fmt(ta, wflags | TF_EQ | tf_ofmt_flag(fmt));
+                    fuse_native = tf_has_eq(ta, wflags) && tf_has_fmt(ta, wflags | TF_EQ | tf_ofmt_flag(fmt)) &&
+                                  (!tii || tf_has_tii(ta, wflags | TF_EQ));
                 }
             }
             ResamplerArgs ra{};

@@ -201,7 +201,7 @@ void tf_kernel(const TfArgs a)
     // so on a frame that carries TII the null symbol's segment is g_1 times a constant segment (a.tii_seg, computed once per
     // setting) instead of zeros: stored by the workgroup that owns symbols 0 and 1 when its run is over, its last C
     // samples added to the boundary outputs that symbol 1 completes.
-    constexpr bool TII_IN = FROM_BITS && GUARD && !WIN && !CFR && (EQ || !FIR);
+    constexpr bool TII_IN = FROM_BITS && GUARD && !CFR && (EQ || (!FIR && !WIN));
     const bool tii_on = TII_IN && a.tii_seg != nullptr && s_begin == 0 && (((frame & 1) == 0) == (a.tii_insert0 != 0));
     float g1s = 1.0f;            // the multiplier of symbol 1 (wave-uniform: a scalar register)
     if (frame >= a.n_frames || s_begin >= nsym) return;
@@ -761,6 +761,10 @@ void tf_kernel(const TfArgs a)
             for (int k = 0; k < 12; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
             quad_sum2_dpp(y.x, y.y);
             y = cadd(y, zp[kEqQL - W - C + i]);
+            if (TII_IN && tii_on && prev_pos == 0 && i < 2 * W + C) {   // (the null symbol's outputs and its spill into symbol 1: plus the TII segment's)
+                const cf ts = a.tii_seg[len0 - W - C + i];
+                y = mk(fmaf(g1s, ts.x, y.x), fmaf(g1s, ts.y, y.y));
+            }
             const int lo = final ? W : 0, hi = final ? W + C : 2 * W + C;
             if (q == 0 && i >= lo && i < hi) put(prev_pos + prev_seg - W - C, i, y);
             return;
@@ -1144,7 +1148,7 @@ void tf_kernel(const TfArgs a)
     }
     if (TII_IN && tii_on) {
         // the TII null symbol (all of it without FIRFilter; up to the boundary outputs with it)
-        const int nz = len0 - C;
+        const int nz = len0 - C - W;
         for (int i0 = 0; i0 < nz; i0 += kThreads) {
             if (i0 + t < nz) {
                 const cf ts = a.tii_seg[i0 + t];

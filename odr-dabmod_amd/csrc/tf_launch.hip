@@ -71,7 +71,8 @@ bool tf_has_eq(const TfArgs &a, unsigned flags)
 bool tf_has_tii(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD;
-    if ((flags & want) != want || (flags & (TF_CFR | TF_WINDOW)) || a.syms_per_chunk < 2) return false;
+    if ((flags & want) != want || (flags & TF_CFR) || a.syms_per_chunk < 2) return false;
+    if (flags & TF_WINDOW) return (flags & TF_EQ) && tf_has_eq(a, flags);     // windowed: the equalised-boundary form alone
     return (flags & TF_EQ) ? tf_has_eq(a, flags) : !(flags & TF_FIR);
 }
 

@@ -74,13 +74,8 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
         # variant carries the seam in its boundary outputs -- one transform per symbol, as without windowing
         eq_win = mode == 1 and F and fir != "notch" and T <= 45 and not cfr and gain != 1 and overlap <= 10
         if eq_win:
-            # ... and stores the integer formats itself (TII is added to the complexf stream by its own kernel: then it cannot)
-            of = FMT_CODE[fmt] if (fmt is not None and not tii) else 0
-            out.append(tf(11, G, 1, 1, 45, ofmt=of, win=1, eq=1))
-            if tii:
-                out.append("tii_add_kernel")
-            if fmt and not of:
-                out.append("format_kernel<%d>" % FMT_CODE[fmt])
+            # ... adds the TII segment and stores the integer formats itself, as it does without windowing
+            out.append(tf(11, G, 1, 1, 45, ofmt=FMT_CODE[fmt] if fmt is not None else 0, win=1, eq=1))
             return out
         nt = 45 if (mode == 1 and F and T == 45 and not cfr) else 0
         out.append(tf(logn, G, 1, F, nt, cfr=int(cfr), win=1))

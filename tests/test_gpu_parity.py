@@ -1014,12 +1014,32 @@ def test_chain_tii_on_the_default_chain(pkg, chunks):
                     lambda md: md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0), chunks=chunks)
 
 
-def test_chain_tii_windowed_guard(pkg):
+@pytest.mark.parametrize("overlap,chunks", [(10, 1), (10, 5), (10, 77), (3, 1), (3, 39), (40, 1)])
+def test_chain_tii_windowed_guard(pkg, overlap, chunks):
+    """TII with a windowed guard interval and FIRFilter.  Overlaps up to 10 (round 5): the equalised-boundary kernel adds the
+    null symbol's segment itself -- all of it up to the 2W + 44 outputs around the seam to symbol 1, those with the segment's
+    share added -- when the workgroup that owns the null symbol owns symbol 1 too; 77 single-symbol runs, and wider overlaps
+    (the packed dual transform), leave it to tii_add_kernel."""
+    seen = {}
     def setup(md):
         md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
-        md.set_window_overlap(10)
-    _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR,
-                    dict(gain_mode=2, normalise=1.0 / 50000.0, window_overlap=10), setup)
+        md.set_window_overlap(overlap)
+        md.trace(True)
+        seen["md"] = md
+    real_close = pkg.Modulator.close
+    _orig = {}
+    def grab(md):
+        _orig["kernels"] = md.last_variant()
+        real_close(md)
+    pkg.Modulator.close = grab
+    try:
+        _tii_chain_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR,
+                        dict(gain_mode=2, normalise=1.0 / 50000.0, window_overlap=overlap), setup, chunks=chunks)
+    finally:
+        pkg.Modulator.close = real_close
+    inside = overlap <= 10 and chunks != 77
+    want = ["tf_kernel<logn=11 bits=1 gain=1 guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=0 win=1 eq=%d>" % (overlap <= 10)]
+    assert _orig["kernels"] == want + ([] if inside else ["tii_add_kernel"]), _orig
 
 
 def test_chain_tii_windowed_guard_without_fir(pkg):
