@@ -93,7 +93,9 @@ DABGPU_API int dabgpu_set_gain(dabgpu_ctx *ctx, int gain_mode, float digital, fl
 DABGPU_API int dabgpu_set_fir_taps(dabgpu_ctx *ctx, const float *taps, size_t n);
 /* FIRFilter("default"): the built-in 45 taps, src/FIRFilter.cpp:59-71 */
 DABGPU_API int dabgpu_set_fir_default_taps(dabgpu_ctx *ctx);
-/* GuardIntervalInserter::update_window, src/GuardIntervalInserter.cpp:96-113 */
+/* GuardIntervalInserter::update_window, src/GuardIntervalInserter.cpp:96-113.  (The fused chain windows overlaps up to 128
+ * samples inside the frame kernel; up to 10 on the Mode I chain with a filter of up to the default length it stays the
+ * one-transform-per-symbol kernel of that chain.) */
 DABGPU_API int dabgpu_set_window_overlap(dabgpu_ctx *ctx, size_t overlap);
 /* Resampler(inputRate, outputRate, resolution = spacing), src/Resampler.cpp:51-112;
  * resets the stream state (prev-input halo and overlap tail).  Built: every ratio L / M (the
@@ -236,8 +238,8 @@ DABGPU_API int dabgpu_set_fir_boundary_mode(dabgpu_ctx *ctx, int mode);
  * kernel stores the integers itself where it has a variant for it -- s16: Mode I coded-bits chain ending in the guard interval
  * or in the default-length filter, or in the x2 / x4 resampler with or without the polynomial predistorter; u8 / s8: Mode I
  * coded-bits chain ending in the guard interval or in a filter of up to the default length whose boundary outputs come through
- * the taps' inverse (the default) -- half / a quarter of the bytes written and copied to the host; every other combination
- * converts in a kernel of its own.  Output sizes of
+ * the taps' inverse (the default); all three also with OFDM windowing of up to 10 samples on that last chain -- half / a
+ * quarter of the bytes written and copied to the host; every other combination converts in a kernel of its own.  Output sizes of
  * dabgpu_chain_out_bytes_per_frame / _process / _submit follow the format.  dabgpu_get_num_clipped: the number of
  * clipped components of the most recent chain call (FormatConverter::get_num_clipped_samples, :56-59), after
  * waiting for that call -- or, on the asynchronous path, of the batch dabgpu_chain_collect returned last. */

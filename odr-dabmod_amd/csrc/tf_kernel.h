@@ -23,7 +23,8 @@
 //     ONE packed dual transform (struct c2), the unfiltered half pruned to the 88 samples the boundary FIR reads
 //     (Fft::run_dual_zonly), those boundary outputs a direct FIR;
 //   * OFDM windowing (WIN): the raised-cosine seams between symbols through LDS; with FIR as well, the windowed stream
-//     around every seam is built in LDS and the outputs that look into it are a direct FIR (packed dual transform).
+//     around every seam is built in LDS and the outputs that look into it are a direct FIR (packed dual transform) -- except
+//     on the EQ chain with overlaps up to kEqWinMax, where the seam rides on the equalised boundary outputs (WIN && EQ).
 // HBM traffic is therefore the compulsory 28.8 kB in + 1.57 MB out per frame.
 //
 // No MFMA (no dense contraction in this path), wave64 throughout.
@@ -87,6 +88,11 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 //     d[m] = sum_j g[j] w[m - (j - c)],   w[q] = z_cur[N-cp+q] - z_prev[q mod N],   q in [-103, 99].
 // 44 x 160 + 990 real-by-complex multiply-adds per symbol replace half of a packed 2048-point transform, its 16-byte
 // exchanges and the pack / unpack around it.
+// EQ with WIN (round 5; overlap W <= kEqWinMax = 10): around a seam the windowed stream is x_prev + omega d with omega the rising
+// raised-cosine factor (0 before the seam, 1 behind it; the reference's two factors of a seam sample add up to one), so the
+// same correction serves with d taken on [-W, W + 44) and weighted: 2W + 44 <= 64 outputs per seam, (2W + 44) x 160 for d
+// (all 256 lanes where the plain form keeps 176 busy) and up to 45 terms per output.  TII and the integer formats as in the
+// plain form.  Measured: 2.51 M frames/s against 1.91 M for the packed dual transform that served these settings before.
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
           bool ZONLY = false, int OFMT = 0, bool WIN = false, bool EQ = false>
 // Waves per SIMD asked of the register allocator: EQ 4 (128 VGPRs, 28 KB of LDS: four workgroups per CU); CFR 2; no
@@ -752,7 +758,11 @@ void tf_kernel(const TfArgs a)
         if constexpr (WIN) {
             // output i of 64 (2W + 44 of them wanted): terms jd = max(i - 44, 0) ... i of (omega d), tap 44 - i + jd; four lanes
             // (one DPP quad) per output, twelve terms each (the tap table is zero past tap 44, eq_d past its last entry)
-            const int i = t >> 2, q = t & 3;
+            // (the lane's output index re-derived here, behind an opaque move: as a loop invariant it is a lane register held --
+            // or spilled, and reloaded behind a wait for the symbol's stores -- across the transform)
+            int tb = t;
+            asm volatile("" : "+v"(tb));
+            const int i = tb >> 2, q = tb & 3;
             const int jd0 = max(i - C, 0);
             const float *tq = taps_l + max(C - i, 0) + q;
             const cf *dq = eq_d + jd0 + q;
@@ -866,7 +876,9 @@ void tf_kernel(const TfArgs a)
                 }
                 const float part = (float)cnt;
                 float *redf = reinterpret_cast<float *>(red + 8 * (s & 1));
-                if ((t & 63) == 0) redf[t >> 6] = part;      // combined after the transform's barriers
+                // (WIN, at the register limit: the wave's index as a scalar -- the slot's address is scalar arithmetic and a
+                // move, not a lane register that stays live across the transform and gets spilled)
+                if ((t & 63) == 0) redf[WIN ? __builtin_amdgcn_readfirstlane(t >> 6) : t >> 6] = part;      // combined after the transform's barriers
             }
         } else {
 #pragma unroll
@@ -958,8 +970,10 @@ void tf_kernel(const TfArgs a)
                                   : (par1 == 1.0f ? 1.0f - mg : fmaf(-mg, 2.4203e-8f, fmaf(-mg, 1.41421354f, 1.0f)));
                 // "(int)(var_variance sigma_re) == 0 -> gain 1" (src/GainControl.cpp:324-331): sigma_re^2 var^2 < 1
                 const bool blank = m2 * fmaxf((float)(K / 2) + S, 0.f) * a.gain.var_sq < 1.0f;
-                g = blank ? a.gain.constant * (MAG_IN_GAIN ? mg : 1.0f)
-                          : fmaf(a.gain.var_c1, r, fmaf(a.gain.var_c1, dlt, a.gain.var_c1_lo) * r);
+                // (MAG_IN_GAIN: dlt = 0 and the low word is the kernel argument itself.  Spelled out for WIN, at the register
+                // limit: the fused form fma(c1, 0, lo) is hoisted out of the symbol loop into a lane register, spilled there)
+                const float lo = (MAG_IN_GAIN && WIN) ? a.gain.var_c1_lo : fmaf(a.gain.var_c1, dlt, a.gain.var_c1_lo);
+                g = blank ? a.gain.constant * (MAG_IN_GAIN ? mg : 1.0f) : fmaf(a.gain.var_c1, r, lo * r);
                 g_final = true;
             } else if (!FROM_BITS && !CFR && (GVAR || a.gain.mode == 2) && s > 0) {
                 g = spectral_gain(reinterpret_cast<const float *>(red + 8 * (s & 1)));
