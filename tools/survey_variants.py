@@ -47,6 +47,9 @@ run("custom 45 taps", setup=lambda m: m.set_fir_taps(lp(45)))
 run("custom 31 taps", setup=lambda m: m.set_fir_taps(lp(31)))
 run("custom 101 taps", setup=lambda m: m.set_fir_taps(lp(101)))
 run("custom 255 taps (unfused)", setup=lambda m: m.set_fir_taps(lp(255)), B=1024)
+run("window 10 (equalised boundaries)", setup=lambda m: m.set_window_overlap(10))
+run("window 10 -> s16", setup=lambda m: m.set_window_overlap(10), fmt="s16")
+run("window 10 + TII", setup=lambda m: (m.set_window_overlap(10), m.set_tii(True, 3, 5)))
 run("window 100", setup=lambda m: m.set_window_overlap(100))
 run("window 100, no FIR", mask=1, setup=lambda m: m.set_window_overlap(100))
 run("TII", setup=lambda m: m.set_tii(True, 3, 5))
