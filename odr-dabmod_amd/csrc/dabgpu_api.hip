@@ -884,6 +884,8 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
                 if (s16_clipped) flags |= tf_ofmt_flag(fused_fmt);    // (this form stores the integers itself)
             }
         }
+        // (the default chain -- no FIRFilter -- with a windowed guard interval: its s16 store; run_chain asked tf_has_fmt)
+        if (s16_clipped && !(flags & (TF_FIR | TF_CFR))) flags |= tf_ofmt_flag(fused_fmt);
         a.chunks_per_frame = auto_chunks(c, n_frames);
         a.syms_per_chunk = run_symbols(c->g.nb_symbols + 1, a.chunks_per_frame, true);
         a.out = native_out;
@@ -1052,15 +1054,20 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
             // resampler's is not.  u8 / s8: the frame kernel's equalised-boundary and no-FIRFilter variants; s16: those, the
             // pruned dual transform and the x2 / x4 resampler.)
             fuse_native = !post && !windowed && (!tii || tf_has_tii(ta, tflags)) && tf_has_fmt(ta, tflags | tf_ofmt_flag(fmt));
-            if (!post && windowed && c->cur.overlap > 0 && c->use_eq && (tflags & TF_FIR) && !(tflags & TF_CFR)) {
-                // ... except for narrow overlaps on the cfg 3 chain: the equalised-boundary form (the decision run_native takes)
+            if (!post && windowed && c->cur.overlap > 0 && !(tflags & TF_CFR)) {
+                // ... except where a windowed form has the store (the decisions run_native takes): narrow overlaps on the cfg 3
+                // chain (the equalised-boundary form, every format, TII inside), the chain without FIRFilter (s16, no TII)
                 const unsigned wflags = tflags | TF_WINDOW;
                 ta.overlap = (int)c->cur.overlap;
                 ta.ntaps = (int)c->cur.taps.size();
                 if (tf_has_window(ta, wflags)) {
-                    ta.ntaps = fused_ntaps(c);
-                    fuse_native = tf_has_eq(ta, wflags) && tf_has_fmt(ta, wflags | TF_EQ | tf_ofmt_flag(fmt)) &&
-                                  (!tii || tf_has_tii(ta, wflags | TF_EQ));
+                    if (tflags & TF_FIR) {
+                        ta.ntaps = fused_ntaps(c);
+                        fuse_native = c->use_eq && tf_has_eq(ta, wflags) && tf_has_fmt(ta, wflags | TF_EQ | tf_ofmt_flag(fmt)) &&
+                                      (!tii || tf_has_tii(ta, wflags | TF_EQ));
+                    } else {
+                        fuse_native = !tii && tf_has_fmt(ta, wflags | tf_ofmt_flag(fmt));
+                    }
                 }
             }
             ResamplerArgs ra{};

@@ -108,7 +108,8 @@ void tf_kernel(const TfArgs a)
     static_assert(!ZONLY || (LOGN == 11 && GUARD && FIR && NT > 0 && !CFR),
                   "ZONLY: the dual transform of the Mode I chain with the fused FIR");
     static_assert(!ZONLY || FROM_BITS || GVAR || !GAIN, "ZONLY: no gain statistics over the time domain");
-    static_assert(!WIN || (FROM_BITS && GUARD && (OFMT == 0 || EQ)), "WIN: coded-bits chain with guard interval (integer store: EQ only)");
+    static_assert(!WIN || (FROM_BITS && GUARD && (OFMT == 0 || EQ || (OFMT == 1 && !FIR && !CFR))),
+                  "WIN: coded-bits chain with guard interval (integer store: every format with EQ, s16 without FIRFilter)");
     static_assert(!(WIN && FIR) || (!ZONLY && (NT == 0 || (NT == 45 && !CFR)) && !GVAR),
                   "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count -- or EQ");
     static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY),
@@ -207,7 +208,7 @@ void tf_kernel(const TfArgs a)
     // so on a frame that carries TII the null symbol's segment is g_1 times a constant segment (a.tii_seg, computed once per
     // setting) instead of zeros: stored by the workgroup that owns symbols 0 and 1 when its run is over, its last C
     // samples added to the boundary outputs that symbol 1 completes.
-    constexpr bool TII_IN = FROM_BITS && GUARD && !CFR && (EQ || (!FIR && !WIN));
+    constexpr bool TII_IN = FROM_BITS && GUARD && (EQ || !WIN);
     const bool tii_on = TII_IN && a.tii_seg != nullptr && s_begin == 0 && (((frame & 1) == 0) == (a.tii_insert0 != 0));
     float g1s = 1.0f;            // the multiplier of symbol 1 (wave-uniform: a scalar register)
     if (frame >= a.n_frames || s_begin >= nsym) return;
@@ -671,6 +672,10 @@ void tf_kernel(const TfArgs a)
             const int ii = i < C ? i : 0;
             cf acc = fir_quad_lane(src + ii, q);
             quad_sum2_dpp(acc.x, acc.y);                                    // the 4 lanes of an output are one DPP quad
+            if (TII_IN && tii_on && prev_pos == 0 && i < C) {               // (the null symbol's boundary outputs: plus the TII segment's)
+                const cf ts = a.tii_seg[len0 - C + i];
+                acc = mk(fmaf(g1s, ts.x, acc.x), fmaf(g1s, ts.y, acc.y));
+            }
             if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, t >> 2, acc);
         }
     };
@@ -1247,6 +1252,18 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
             if (fr) { if (gn) TF_LAUNCH_CFR_WIN(true, true); else TF_LAUNCH_CFR_WIN(false, true); }
             else    { if (gn) TF_LAUNCH_CFR_WIN(true, false); else TF_LAUNCH_CFR_WIN(false, false); }
 #undef TF_LAUNCH_CFR_WIN
+        } else if (of) {
+            // s16 stored by the CFR kernel itself (round 5): the Mode I coded-bits chain with the guard interval, with or without FIRFilter
+            if (of != 1 || !fb || !gd) return hipErrorInvalidValue;
+            if constexpr (LOGN == 11) {
+                if (fr) {
+                    if (gn) tf_go<11, true, true, true, true, NT, true, false, false, 1>(grid, block, lds, s, a);
+                    else tf_go<11, true, false, true, true, NT, true, false, false, 1>(grid, block, lds, s, a);
+                } else if constexpr (NT == 0) {
+                    if (gn) tf_go<11, true, true, true, false, 0, true, false, false, 1>(grid, block, lds, s, a);
+                    else tf_go<11, true, false, true, false, 0, true, false, false, 1>(grid, block, lds, s, a);
+                }
+            }
         } else if (gd && !fr) {
             if (gn) TF_LAUNCH_CFR_GUARD(true); else TF_LAUNCH_CFR_GUARD(false);
         } else if (fr) {
@@ -1289,6 +1306,15 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
             if (gn) tf_go<LOGN, true, true, true, true, NT, false, false, false, 0, true>(grid, block, lds, s, a);
             else tf_go<LOGN, true, false, true, true, NT, false, false, false, 0, true>(grid, block, lds, s, a);
         } else if constexpr (NT == 0) {
+            if (of) {
+                // the reference's default chain (no FIRFilter) with a windowed guard interval and s16 output, Mode I
+                if (of != 1 || LOGN != 11) return hipErrorInvalidValue;
+                if constexpr (LOGN == 11) {
+                    if (gn) tf_go<11, true, true, true, false, 0, false, false, false, 1, true>(grid, block, lds, s, a);
+                    else tf_go<11, true, false, true, false, 0, false, false, false, 1, true>(grid, block, lds, s, a);
+                }
+                return hipGetLastError();
+            }
             if (gn) tf_go<LOGN, true, true, true, false, 0, false, false, false, 0, true>(grid, block, lds, s, a);
             else tf_go<LOGN, true, false, true, false, 0, false, false, false, 0, true>(grid, block, lds, s, a);
         }

@@ -43,9 +43,9 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
 // without s16 store (with or without FIRFilter, with or without CFR), overlap up to kWinMax (and inside the cyclic prefix)
 bool tf_has_window(const TfArgs &a, unsigned flags)
 {
-    // (the integer formats: stored by the equalised-boundary form only)
-    const unsigned want = TF_FROM_BITS | TF_GUARD, never = (flags & TF_EQ) ? 0u : (TF_OUT_S16 | TF_OUT_U8 | TF_OUT_S8);
-    if ((flags & want) != want || (flags & never) || a.overlap < 1 || a.overlap > kWinMax) return false;
+    // (which of them store an integer format: tf_has_fmt)
+    const unsigned want = TF_FROM_BITS | TF_GUARD;
+    if ((flags & want) != want || a.overlap < 1 || a.overlap > kWinMax) return false;
     // with FIR: the filter's look-ahead and the window must both fit into the cyclic prefix
     if (flags & TF_FIR)
         return a.ntaps >= 1 && a.ntaps <= kBnd && a.ntaps <= kMaxTaps &&
@@ -71,9 +71,11 @@ bool tf_has_eq(const TfArgs &a, unsigned flags)
 bool tf_has_tii(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD;
-    if ((flags & want) != want || (flags & TF_CFR) || a.syms_per_chunk < 2) return false;
+    if ((flags & want) != want || a.syms_per_chunk < 2) return false;
     if (flags & TF_WINDOW) return (flags & TF_EQ) && tf_has_eq(a, flags);     // windowed: the equalised-boundary form alone
-    return (flags & TF_EQ) ? tf_has_eq(a, flags) : !(flags & TF_FIR);
+    // every other form with the guard interval (round 5): with or without FIRFilter (the segment's last ntaps - 1 samples ride on
+    // the null symbol's boundary outputs), with or without CFR (the cached segment is the CFR'd null symbol)
+    return (flags & TF_EQ) ? tf_has_eq(a, flags) : true;
 }
 
 // the frame-kernel variants that store an integer format (flags' TF_OUT_* bit) themselves: the Mode I coded-bits chain with the
@@ -83,8 +85,13 @@ bool tf_has_fmt(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
     const int of = tf_ofmt(flags);
-    if (!of || a.g.logN != 11 || (flags & TF_CFR)) return false;
-    if (flags & TF_WINDOW) return (flags & TF_EQ) && tf_has_eq(a, flags);      // windowed: the equalised-boundary form alone
+    if (!of || a.g.logN != 11 || (flags & (TF_FROM_BITS | TF_GUARD)) != (TF_FROM_BITS | TF_GUARD)) return false;
+    if (flags & TF_WINDOW) {
+        // windowed: every format on the equalised-boundary form, s16 on the chain without FIRFilter
+        if (flags & TF_CFR) return false;
+        return (flags & TF_FIR) ? ((flags & TF_EQ) && tf_has_eq(a, flags)) : of == 1;      // (1 = s16)
+    }
+    if (flags & TF_CFR) return of == 1;       // crest-factor reduction, with or without FIRFilter: s16
     // without FIRFilter (the reference's default): every gain mode
     if ((flags & want) == (TF_FROM_BITS | TF_GUARD)) return true;
     if (of > 1 && !(flags & TF_EQ)) return false;

@@ -49,15 +49,15 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
         nt = 45 if (mode == 1 and F and ntaps == 45) else 0
         default_len = mode == 1 and F and ntaps == 45 and not cfr and gain != 1      # (gain max needs the unfiltered samples)
         eq = default_len and fir != "notch"              # boundary outputs through the taps' inverse
-        tii_inside = tii and not cfr and (eq or not F)
-        # integer output stored by the frame kernel itself: s16 on the no-FIRFilter and both default-length variants, u8 / s8
-        # (round 5) on the no-FIRFilter and the equalised-boundary variants
-        fmt_inside = (fmt is not None and mode == 1 and not cfr and (not tii or tii_inside) and
-                      ((not F or default_len) if fmt == "s16" else (not F or eq)))
+        tii_inside = tii                                  # (round 5: every form of the one frame kernel adds the TII null symbol itself)
+        # integer output stored by the frame kernel itself (Mode I): s16 on the no-FIRFilter and both default-length variants and
+        # (round 5) on the CFR variants; u8 / s8 (round 5) on the no-FIRFilter and the equalised-boundary variants
+        fmt_inside = fmt is not None and mode == 1 and (
+            fmt == "s16" if cfr else ((not F or default_len) if fmt == "s16" else (not F or eq)))
         s16_inside = fmt_inside
         of = FMT_CODE[fmt] if fmt_inside else 0
         if cfr:
-            out.append(tf(logn, G, 1, F, nt if F else 0, cfr=1))
+            out.append(tf(logn, G, 1, F, nt if F else 0, cfr=1, ofmt=of))
         elif default_len:
             out.append(tf(11, G, 1, 1, 45, ofmt=of, eq=1) if eq else tf(11, G, 1, 1, 45, zonly=1, ofmt=of))
         else:
@@ -78,7 +78,14 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
             out.append(tf(11, G, 1, 1, 45, ofmt=FMT_CODE[fmt] if fmt is not None else 0, win=1, eq=1))
             return out
         nt = 45 if (mode == 1 and F and T == 45 and not cfr) else 0
-        out.append(tf(logn, G, 1, F, nt, cfr=int(cfr), win=1))
+        # (the windowed default chain -- no FIRFilter -- stores s16 itself; TII is added to the complexf stream: then it cannot)
+        of = 1 if (fmt == "s16" and mode == 1 and not F and not cfr and not tii) else 0
+        out.append(tf(logn, G, 1, F, nt, cfr=int(cfr), ofmt=of, win=1))
+        if tii:
+            out.append("tii_add_kernel")
+        if fmt and not of:
+            out.append("format_kernel<%d>" % FMT_CODE[fmt])
+        return out
     else:
         out.append(tf(logn, G, 0, 0, 0, cfr=int(cfr)))
         if F:

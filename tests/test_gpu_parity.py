@@ -1042,6 +1042,47 @@ def test_chain_tii_windowed_guard(pkg, overlap, chunks):
     assert _orig["kernels"] == want + ([] if inside else ["tii_add_kernel"]), _orig
 
 
+@pytest.mark.parametrize("case", ["gain_max", "notch", "taps101", "cfr", "cfr_nofir", "mode2"])
+@pytest.mark.parametrize("chunks", [1, 5])
+def test_chain_tii_inside_every_form_of_the_frame_kernel(pkg, case, chunks):
+    """Round 5: every form of the one frame kernel adds the TII null symbol itself (with FIRFilter: the segment's last
+    ntaps - 1 samples ride on the null symbol's boundary outputs; with CFR: the cached segment is the CFR'd null symbol) --
+    gain mode max (packed dual transform), a 45-tap filter without an inverse (pruned dual transform), 101 taps (run-time
+    tap count), CFR with and without FIRFilter, Mode II."""
+    from scipy.signal import firwin
+    mode = 2 if case == "mode2" else 1
+    kw = dict(gain_mode=1 if case == "gain_max" else 2, normalise=1.0 if case == "gain_max" else 1.0 / 50000.0)
+    taps = None
+    if case == "notch":
+        d = O.fir_default_taps().astype(np.float64)
+        taps = np.convolve(d[:43], [1, -2 * np.cos(2 * np.pi * 300 / 2048), 1]).astype(np.float32)
+    elif case == "taps101":
+        taps = firwin(101, 800e3, window="hamming", fs=2.048e6).astype(np.float32)
+    if taps is not None:
+        kw.update(taps=taps)
+    if case.startswith("cfr"):
+        kw.update(cfr=(50.0, 0.1))
+    kern = {}
+    def setup(md):
+        md.set_gain(kw["gain_mode"], 1.0, kw["normalise"], 4.0)
+        if taps is not None:
+            md.set_fir_taps(taps)
+        if case.startswith("cfr"):
+            md.set_cfr(True, 50.0, 0.1)
+        md.trace(True)
+    real_close = pkg.Modulator.close
+    def grab(md):
+        kern["k"] = md.last_variant()
+        real_close(md)
+    pkg.Modulator.close = grab
+    try:
+        stages = pkg.STAGE_GAIN | (0 if case == "cfr_nofir" else pkg.STAGE_FIR)
+        _tii_chain_case(pkg, mode, stages, kw, setup, chunks=chunks)
+    finally:
+        pkg.Modulator.close = real_close
+    assert len(kern["k"]) == 1 and kern["k"][0].startswith("tf_kernel<"), kern
+
+
 def test_chain_tii_windowed_guard_without_fir(pkg):
     """TII on the chain whose guard interval the frame kernel windows itself: the cached TII segment (null symbol through
     the unfused windowed guard, its suffix spilling into symbol 1's seam) adds onto the fused kernel's output."""
@@ -1636,10 +1677,10 @@ def test_async_host_path_zero_copy_buffer_lifetime(pkg):
 
 
 # --------------------------------------------------------------------------- f-2 fused into the chain
-def _chain_formats_case(pkg, mode, stages, fmt, setup, n_frames=2, seed=1900, seen=None):
+def _chain_formats_case(pkg, mode, stages, fmt, setup, n_frames=2, seed=1900, seen=None, chunks=0):
     """The chain with an integer output format against FormatConverter applied to the chain's own complexf output:
     the conversion is integer work on identical floats, so the bytes and the clip count must be equal."""
-    md = pkg.Modulator(mode=mode, max_frames=n_frames)
+    md = pkg.Modulator(mode=mode, max_frames=n_frames, chunks_per_frame=chunks)
     try:
         setup(md)
         per = md.geometry["tf_input_bytes"]
@@ -1727,6 +1768,53 @@ def test_chain_integer_formats_stored_by_the_equalised_windowed_kernel(pkg, fmt,
     assert seen["kernels"] == ["tf_kernel<logn=11 bits=1 gain=1 guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=%d win=1 eq=1>" % code], seen
     if normalise in (2.5, 1.0 / 64.0):
         assert clipped > 0                                # the clip counter is exercised
+
+
+@pytest.mark.parametrize("fir", [True, False, 31])
+@pytest.mark.parametrize("gain", [(2, 1.0), (2, 2.5), (None, 0)])
+@pytest.mark.parametrize("tii", [False, True])
+def test_chain_s16_stored_by_the_cfr_kernel(pkg, fir, gain, tii):
+    """Crest-factor reduction with s16 output (round 5; what a transmitter with cfr.enable = 1 feeding a UHD / Soapy device
+    runs): tf_kernel<..., CFR, OFMT = 1> stores the integers itself -- and adds the TII null symbol itself --, with or without
+    FIRFilter (default length: compile-time tap count; 31 taps: run-time), ONE kernel where the CFR kernel was followed by
+    tii_add_kernel and format_kernel.  Bytes and clip count of FormatConverter on the chain's own complexf output."""
+    from scipy.signal import firwin
+    def setup(md):
+        md._rs_out = 2048000
+        if gain[0] is not None:
+            md.set_gain(gain[0], gain[1], 1.0, 4.0)
+        if fir == 31:
+            md.set_fir_taps(firwin(31, 880e3, window="hamming", fs=2.048e6).astype(np.float32))
+        md.set_cfr(True, 50.0, 0.1)
+        if tii:
+            md.set_tii(True, 3, 5)
+        md.trace(True)
+    stages = (pkg.STAGE_FIR if fir else 0) | (pkg.STAGE_GAIN if gain[0] is not None else 0)
+    seen = {}
+    # (TII inside needs the workgroup that owns the null symbol to own symbol 1 too: five runs per frame; two frames on their
+    # own are cut into single-symbol runs)
+    clipped = _chain_formats_case(pkg, 1, stages, "s16", setup, seen=seen, chunks=5 if tii else 0)
+    assert len(seen["kernels"]) == 1 and "cfr=1" in seen["kernels"][0] and "ofmt=1" in seen["kernels"][0], seen
+    if gain == (2, 2.5):
+        assert clipped > 0
+
+
+@pytest.mark.parametrize("gain", [(2, 1.0), (2, 2.5), (1, 0.9), (None, 0)])
+@pytest.mark.parametrize("overlap", [10, 128])
+def test_chain_s16_stored_by_the_windowed_kernel_without_firfilter(pkg, gain, overlap):
+    """The reference's default chain (firfilter.enabled = 0) with ofdmwindowing and s16 output (round 5): tf_kernel<..., OFMT = 1,
+    WIN> stores the integers itself."""
+    def setup(md):
+        md._rs_out = 2048000
+        if gain[0] is not None:
+            md.set_gain(gain[0], 1.0 if gain[0] == 1 else gain[1], gain[1] if gain[0] == 1 else 1.0, 4.0)
+        md.set_window_overlap(overlap)
+        md.trace(True)
+    seen = {}
+    clipped = _chain_formats_case(pkg, 1, pkg.STAGE_GAIN if gain[0] is not None else 0, "s16", setup, seen=seen)
+    assert len(seen["kernels"]) == 1 and "win=1" in seen["kernels"][0] and "ofmt=1" in seen["kernels"][0], seen
+    if gain == (2, 2.5):
+        assert clipped > 0
 
 
 @pytest.mark.parametrize("out_rate,poly", [(8192000, True), (8192000, False), (4096000, True)])
