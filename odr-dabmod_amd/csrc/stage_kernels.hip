@@ -550,15 +550,20 @@ __global__ void tii_add_kernel(cf *__restrict__ out, size_t stride, const cf *__
 // f-2 FormatConverter, float input (reference src/FormatConverter.cpp:111-178): range test
 // against the integer limits (clipped components counted), otherwise float -> integer by
 // truncation toward zero; u8 adds 128.0f first.  FMT: 1 = s16, 2 = u8, 3 = s8.
-// HBM-bound elementwise: 8 floats per lane (two 16-byte loads, one 16- or 8-byte store), the
-// clip count reduced per wave and added to a device counter.
+// HBM-bound elementwise: 8 floats per lane and tile (two 16-byte loads, one 16- or 8-byte store), a workgroup walks
+// `tiles` consecutive tiles; the clip count is reduced per workgroup and added to a device counter -- ONE atomic per
+// workgroup (a badly scaled stream clips everywhere: one atomic per wave and tile then was 6 million additions to one address
+// for 8192 frames, twenty times the kernel's own time).
 // (format_one: device_common.h)
 template <int FMT> __global__ __launch_bounds__(256)
 void format_kernel(const float *__restrict__ in, size_t n, void *__restrict__ out,
-                   unsigned long long *__restrict__ clipped_total)
+                   unsigned long long *__restrict__ clipped_total, int tiles)
 {
-    const size_t i0 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 8;
+    __shared__ unsigned wave_sum[4];
     unsigned clipped = 0;
+    for (int k = 0; k < tiles; ++k) {
+    const size_t i0 = (((size_t)blockIdx.x * tiles + k) * 256 + threadIdx.x) * 8;
+    if (i0 >= n) break;
     if (i0 + 8 <= n) {
         const float4 a = reinterpret_cast<const float4 *>(in + i0)[0];
         const float4 b = reinterpret_cast<const float4 *>(in + i0)[1];
@@ -588,10 +593,16 @@ void format_kernel(const float *__restrict__ in, size_t n, void *__restrict__ ou
             else reinterpret_cast<uint8_t *>(out)[i] = (uint8_t)y;
         }
     }
+    }
     unsigned tot = clipped;
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) tot += __shfl_xor(tot, o, 64);
-    if ((threadIdx.x & 63) == 0 && tot) atomicAdd(clipped_total, (unsigned long long)tot);
+    if ((threadIdx.x & 63) == 0) wave_sum[threadIdx.x >> 6] = tot;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned all = wave_sum[0] + wave_sum[1] + wave_sum[2] + wave_sum[3];
+        if (all) atomicAdd(clipped_total, (unsigned long long)all);
+    }
 }
 
 }  // namespace
@@ -623,11 +634,14 @@ hipError_t launch_format(const float *in, size_t nfloats, int fmt, void *out, un
                          hipStream_t s)
 {
     if (nfloats == 0) return hipSuccess;
-    const dim3 grid(blocks_for((nfloats + 7) / 8, 256)), block(256);
+    // tiles of 2048 floats; a workgroup takes up to 16 of them once there are enough workgroups to fill the chip
+    const size_t n_tiles = blocks_for((nfloats + 7) / 8, 256);
+    const int tiles = (int)std::min<size_t>(16, std::max<size_t>(1, n_tiles / 4096));
+    const dim3 grid((unsigned)((n_tiles + tiles - 1) / tiles)), block(256);
     switch (fmt) {
-        case 1: DABGPU_LAUNCH(format_kernel<1>, grid, block, 0, s, in, nfloats, out, clipped); break;
-        case 2: DABGPU_LAUNCH(format_kernel<2>, grid, block, 0, s, in, nfloats, out, clipped); break;
-        case 3: DABGPU_LAUNCH(format_kernel<3>, grid, block, 0, s, in, nfloats, out, clipped); break;
+        case 1: DABGPU_LAUNCH(format_kernel<1>, grid, block, 0, s, in, nfloats, out, clipped, tiles); break;
+        case 2: DABGPU_LAUNCH(format_kernel<2>, grid, block, 0, s, in, nfloats, out, clipped, tiles); break;
+        case 3: DABGPU_LAUNCH(format_kernel<3>, grid, block, 0, s, in, nfloats, out, clipped, tiles); break;
         default: return hipErrorInvalidValue;
     }
     return hipGetLastError();
