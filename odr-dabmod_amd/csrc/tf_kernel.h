@@ -1350,6 +1350,16 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
         else tf_go<11, true, false, true, true, 45, false, false, true>(grid, block, lds, s, a);
         return hipGetLastError();
     }
+    if (of == 1 && fr) {
+        // s16 behind the generic FIR forms of Mode I (round 5): gain mode max with the default-length filter (NT = 45: the packed
+        // dual transform), any other tap count (NT = 0)
+        if (LOGN != 11 || !fb || !gd) return hipErrorInvalidValue;
+        if constexpr (LOGN == 11) {
+            if (gn) tf_go<11, true, true, true, true, NT, false, false, false, 1>(grid, block, lds, s, a);
+            else tf_go<11, true, false, true, true, NT, false, false, false, 1>(grid, block, lds, s, a);
+        }
+        return hipGetLastError();
+    }
     if (of) {
         // the reference's default chain (no FIRFilter) with integer output, Mode I: any gain mode
         if (LOGN != 11 || NT != 0 || !fb || !gd || fr) return hipErrorInvalidValue;   // (callers ask tf_has_fmt first)

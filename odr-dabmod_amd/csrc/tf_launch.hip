@@ -79,11 +79,10 @@ bool tf_has_tii(const TfArgs &a, unsigned flags)
 }
 
 // the frame-kernel variants that store an integer format (flags' TF_OUT_* bit) themselves: the Mode I coded-bits chain with the
-// guard interval, without FIRFilter (any gain mode) or with the default-length filter (gain none / fix / var) -- s16 on both
-// forms of the latter, u8 / s8 on its equalised-boundary form (TF_EQ set by the caller) only
+// guard interval -- s16 on every form that is one kernel (with or without FIRFilter, CFR, a windowed guard interval without
+// FIRFilter), u8 / s8 without FIRFilter and on the equalised-boundary form (TF_EQ set by the caller)
 bool tf_has_fmt(const TfArgs &a, unsigned flags)
 {
-    const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
     const int of = tf_ofmt(flags);
     if (!of || a.g.logN != 11 || (flags & (TF_FROM_BITS | TF_GUARD)) != (TF_FROM_BITS | TF_GUARD)) return false;
     if (flags & TF_WINDOW) {
@@ -93,9 +92,11 @@ bool tf_has_fmt(const TfArgs &a, unsigned flags)
     }
     if (flags & TF_CFR) return of == 1;       // crest-factor reduction, with or without FIRFilter: s16
     // without FIRFilter (the reference's default): every gain mode
-    if ((flags & want) == (TF_FROM_BITS | TF_GUARD)) return true;
-    if (of > 1 && !(flags & TF_EQ)) return false;
-    return a.ntaps == 45 && (flags & want) == want && (!(flags & TF_GAIN) || a.gain.mode != 1);
+    if (!(flags & TF_FIR)) return true;
+    // with FIRFilter: s16 on every form (equalised, pruned, packed dual transform; any tap count the fused filter takes, any gain
+    // mode -- round 5), u8 / s8 on the equalised-boundary form
+    if (of == 1) return true;
+    return (flags & TF_EQ) && a.ntaps == 45 && (!(flags & TF_GAIN) || a.gain.mode != 1);
 }
 
 hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)

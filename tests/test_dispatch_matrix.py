@@ -50,10 +50,9 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
         default_len = mode == 1 and F and ntaps == 45 and not cfr and gain != 1      # (gain max needs the unfiltered samples)
         eq = default_len and fir != "notch"              # boundary outputs through the taps' inverse
         tii_inside = tii                                  # (round 5: every form of the one frame kernel adds the TII null symbol itself)
-        # integer output stored by the frame kernel itself (Mode I): s16 on the no-FIRFilter and both default-length variants and
-        # (round 5) on the CFR variants; u8 / s8 (round 5) on the no-FIRFilter and the equalised-boundary variants
-        fmt_inside = fmt is not None and mode == 1 and (
-            fmt == "s16" if cfr else ((not F or default_len) if fmt == "s16" else (not F or eq)))
+        # integer output stored by the frame kernel itself (Mode I): s16 on every form (round 5: also CFR, gain mode max, other tap
+        # counts); u8 / s8 (round 5) on the no-FIRFilter and the equalised-boundary variants
+        fmt_inside = fmt is not None and mode == 1 and (fmt == "s16" or (not cfr and (not F or eq)))
         s16_inside = fmt_inside
         of = FMT_CODE[fmt] if fmt_inside else 0
         if cfr:

@@ -1770,6 +1770,27 @@ def test_chain_integer_formats_stored_by_the_equalised_windowed_kernel(pkg, fmt,
         assert clipped > 0                                # the clip counter is exercised
 
 
+@pytest.mark.parametrize("case", ["gain_max", "gain_max_tii", "taps101", "taps101_gain_max", "taps13_no_inverse"])
+def test_chain_s16_stored_by_the_generic_fir_forms(pkg, case):
+    """s16 behind the FIR forms that are neither equalised nor pruned (round 5): gain mode max with the default taps (packed dual
+    transform, compile-time tap count), 101 taps and a 13-tap filter without a usable inverse (run-time tap count) -- the same
+    fused store, one kernel."""
+    from scipy.signal import firwin
+    def setup(md):
+        md._rs_out = 2048000
+        md.set_gain(1 if "gain_max" in case else 2, 1.0, 0.9 if "gain_max" in case else 1.0, 4.0)
+        if "taps101" in case:
+            md.set_fir_taps(firwin(101, 800e3, window="hamming", fs=2.048e6).astype(np.float32))
+        if "taps13" in case:
+            md.set_fir_taps((synth_signal(13, seed=13).real * np.float32(1 / 200)).astype(np.float32))
+        if "tii" in case:
+            md.set_tii(True, 3, 5)
+        md.trace(True)
+    seen = {}
+    _chain_formats_case(pkg, 1, pkg.STAGE_GAIN | pkg.STAGE_FIR, "s16", setup, seen=seen, chunks=5 if "tii" in case else 0)
+    assert len(seen["kernels"]) == 1 and "ofmt=1" in seen["kernels"][0] and "eq=0" in seen["kernels"][0], seen
+
+
 @pytest.mark.parametrize("fir", [True, False, 31])
 @pytest.mark.parametrize("gain", [(2, 1.0), (2, 2.5), (None, 0)])
 @pytest.mark.parametrize("tii", [False, True])

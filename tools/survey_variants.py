@@ -56,6 +56,12 @@ run("TII", setup=lambda m: m.set_tii(True, 3, 5))
 run("CFR", setup=lambda m: m.set_cfr(True, 50.0, 0.1))
 run("CFR, no FIR", mask=1, setup=lambda m: m.set_cfr(True, 50.0, 0.1))
 run("CFR + TII", setup=lambda m: (m.set_cfr(True, 50.0, 0.1), m.set_tii(True, 3, 5)))
+run("CFR -> s16", setup=lambda m: m.set_cfr(True, 50.0, 0.1), fmt="s16")
+run("CFR + TII -> s16", setup=lambda m: (m.set_cfr(True, 50.0, 0.1), m.set_tii(True, 3, 5)), fmt="s16")
+run("CFR, no FIR -> s16", mask=1, setup=lambda m: m.set_cfr(True, 50.0, 0.1), fmt="s16")
+run("window 10, no FIR -> s16", mask=1, setup=lambda m: m.set_window_overlap(10), fmt="s16")
+run("gain max -> s16", setup=lambda m: m.set_gain(1, 1.0, 0.9, 4.0), fmt="s16")
+run("custom 101 taps -> s16", setup=lambda m: m.set_fir_taps(lp(101)), fmt="s16")
 for f in ("s16", "u8", "s8"):
     run("cfg3 -> " + f, fmt=f)
 poly = lambda m: m.set_poly([1.0, 0.05, -0.01, 0.002, 0.0], [0.0, 0.02, 0.003, 0.0, 0.0])
