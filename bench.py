@@ -695,12 +695,14 @@ def main():
                            (args.workload + "_B1_one_lane", 1), (args.workload + "_B16_one_lane", 16),
                            (args.workload + "_B256_one_lane", 256),
                            ("cfg3_s16", B), ("cfg4_s16", max(64, bs // 4)),
-                           ("cfg3_cfr", max(64, bs // 2)), ("cfg3_window", max(64, bs // 2)), ("cfg3_nofir", B)):
+                           ("cfg3_cfr", max(64, bs // 2)), ("cfg3_cfr_s16", max(64, bs // 2)),
+                           ("cfg3_window", max(64, bs // 2)), ("cfg3_nofir", B)):
                 if wl == args.workload:
                     continue
                 try:
-                    base = wl.split("_B")[0].replace("_s16", "").replace("_cfr", "").replace("_window", "").replace("_nofir", "")
-                    option = wl.rsplit("_", 1)[1] if wl.endswith(("_cfr", "_window", "_nofir")) else None
+                    parts = wl.split("_B")[0].split("_")           # e.g. cfg3_cfr_s16 / ifft_fir_stage / cfg3_B16_one_lane
+                    option = next((p for p in parts[1:] if p in ("cfr", "window", "nofir")), None)
+                    base = "_".join(p for p in parts if p not in ("cfr", "window", "nofir", "s16"))
                     # (small batches: regions of 30 ... 80 ms -- a region of a few milliseconds right after a synchronisation
                     #  is spent in the clock's ramp from idle and under-reports by a third)
                     k = max(3, args.steps // 4) if b2 > 256 else (3000 if b2 <= 16 else 800)

@@ -235,12 +235,12 @@ DABGPU_API int dabgpu_set_fir_boundary_mode(dabgpu_ctx *ctx, int mode);
 
 /* FormatConverter as the last step of the chain (the reference wires it after cifPoly when the output is not
  * complexf, src/DabModulator.cpp:270-276, :407): format = 0 (complexf, the default) or DABGPU_FMT_*.  The chain's last
- * kernel stores the integers itself where it has a variant for it -- s16: Mode I coded-bits chain ending in the guard interval
- * (windowed or not) or in the default-length filter, with or without crest-factor reduction, or in the x2 / x4 resampler with or
- * without the polynomial predistorter; u8 / s8: Mode I coded-bits chain ending in the guard interval or in a filter of up to
- * the default length whose boundary outputs come through the taps' inverse (the default); all three also with OFDM windowing of
- * up to 10 samples on that last chain -- half / a quarter of the bytes written and copied to the host; every other combination
- * converts in a kernel of its own.  Output sizes of
+ * kernel stores the integers itself where it has a variant for it -- s16: every Mode I coded-bits chain that is one frame kernel
+ * (any filter the fused FIRFilter takes, any gain mode, with or without crest-factor reduction; a windowed guard interval
+ * without FIRFilter, or with it up to 10 samples of overlap), and the x2 / x4 resampler with or without the polynomial
+ * predistorter; u8 / s8: Mode I coded-bits chain ending in the guard interval or in a filter of up to the default length whose
+ * boundary outputs come through the taps' inverse (the default), also with up to 10 samples of OFDM windowing -- half / a
+ * quarter of the bytes written and copied to the host; every other combination converts in a kernel of its own.  Output sizes of
  * dabgpu_chain_out_bytes_per_frame / _process / _submit follow the format.  dabgpu_get_num_clipped: the number of
  * clipped components of the most recent chain call (FormatConverter::get_num_clipped_samples, :56-59), after
  * waiting for that call -- or, on the asynchronous path, of the batch dabgpu_chain_collect returned last. */
