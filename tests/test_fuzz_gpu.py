@@ -22,6 +22,7 @@ pytestmark = pytest.mark.gpu
 CP = {1: 504, 2: 126, 3: 63, 4: 252}
 import os
 
+NARROW = os.environ.get("DABGPU_FUZZ_NARROW", "") == "1"
 N_CASES = int(os.environ.get("DABGPU_FUZZ_CASES", "256"))     # (a one-off hunt: DABGPU_FUZZ_CASES=2000 python -m pytest tests/test_fuzz_gpu.py -m gpu)
 
 
@@ -42,6 +43,8 @@ def _draw(rs):
         h = 0.79 * np.sinc(0.79 * k) * np.hamming(n) if n > 1 else np.ones(1)
         c["taps"] = (h / h.sum()).astype(np.float32)
     c["overlap"] = 0 if rs.rand() < 0.6 else int(rs.randint(1, min(128, cp) + 1))
+    if NARROW and c["overlap"]:
+        c["overlap"] = 1 + c["overlap"] % 10              # (a one-off hunt on the equalised windowed kernel: DABGPU_FUZZ_NARROW=1)
     c["cfr"] = bool(rs.rand() < 0.2)
     c["tii"] = bool(mode in (1, 2) and rs.rand() < 0.25)
     c["fmt"] = rs.choice([None, None, None, "s16", "u8", "s8"])
