@@ -99,7 +99,7 @@ template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, boo
 // FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
 // 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             EQ ? 4 : CFR ? (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+                             EQ ? 4 : CFR ? ((LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !WIN) ? 4 : (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2)) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
@@ -129,7 +129,12 @@ void tf_kernel(const TfArgs a)
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
     int fpar = 0;                                                       // which half the next exchange uses
     // packed dual transforms (FIR variants other than EQ) exchange 16-byte elements
-    constexpr int kXElems = (FIR && !EQ) ? 2 * F::LDS_ELEMS : (DBUF ? 2 : 1) * F::LDS_ELEMS;
+    // CFR_SEQ (Mode I coded-bits chain, CFR with the fused FIRFilter): the corrected spectrum's two inverse transforms run one
+    // after the other as plain transforms instead of one packed pair -- the same instruction count (a packed fp32 instruction
+    // occupies the SIMD twice as long), 8-byte exchanges, and registers for a fourth wave per SIMD
+    // (the default filter length only: the run-time tap count's boundary loop does not fit the 128 registers)
+    constexpr bool CFR_SEQ = CFR && LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !WIN;
+    constexpr int kXElems = (FIR && !EQ && !CFR_SEQ) ? 2 * F::LDS_ELEMS : (DBUF ? 2 : 1) * F::LDS_ELEMS;
     double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
     // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
     // that the boundary outputs read in[i + j] without a tail/head case split
@@ -171,6 +176,7 @@ void tf_kernel(const TfArgs a)
     F::fill_tw8(a.t.twiddle, tw8_l, t);
     // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
     float *cfr_red = reinterpret_cast<float *>(tw8_l + 56);
+    uint2 *bsh_l = reinterpret_cast<uint2 *>(cfr_red + 6 * ((T + 63) / 64));     // CFR_SEQ: [3][T] bit positions of the lane's six carriers
     if (t < 64) {
         const unsigned p = ((unsigned)t + ((unsigned)t >> 3)) & 7u;
         const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
@@ -237,7 +243,7 @@ void tf_kernel(const TfArgs a)
             if (FIR) hk[c] = a.t.fir_h[bin];
         }
     }
-    if (CFR && FIR) {
+    if (CFR && FIR && !CFR_SEQ) {          // (CFR_SEQ reads them where it uses them: sixteen registers less across the transforms)
 #pragma unroll
         for (int m = 0; m < 8; ++m) hk8[m] = a.t.fir_h[tt + T * m];
     }
@@ -260,6 +266,10 @@ void tf_kernel(const TfArgs a)
             bitpos[c] = a.t.src_carrier[kpos[c]];
             bsh[c] = (unsigned)bitpos[c] ^ 7u;
             P |= ((unsigned)a.t.phase_q[kpos[c]] & 3u) << fpos[c];
+        }
+        if constexpr (CFR_SEQ) {
+#pragma unroll
+            for (int j = 0; j < 3; ++j) bsh_l[j * T + t] = make_uint2(bsh[2 * j], bsh[2 * j + 1]);
         }
     }
     const cf *fcar = FROM_BITS ? nullptr
@@ -309,14 +319,31 @@ void tf_kernel(const TfArgs a)
     // bits of its offset operand, so n ^ 7 (bsh) serves as it is, and bits 5 ... of it are the dword index.
     auto advance = [&](const uint32_t *blk) __attribute__((always_inline)) {
         uint2 w[6];
+        unsigned bs[6];
+        if constexpr (CFR_SEQ) {
+            // (at the register limit: the six bit positions live in LDS -- three 8-byte reads per symbol -- instead of six lane
+            // registers and six more for the dword offsets hoisted out of the loop; spilled, they came back from scratch behind a
+            // wait for the previous symbol's stores)
+            int tl = t;
+            asm volatile("" : "+v"(tl));
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const uint2 b2 = bsh_l[j * T + tl];
+                bs[2 * j] = b2.x;
+                bs[2 * j + 1] = b2.y;
+            }
+        } else {
+#pragma unroll
+            for (int c = 0; c < 6; ++c) bs[c] = bsh[c];
+        }
 #pragma unroll
         for (int c = 0; c < 6; ++c)
-            w[c] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(blk) + (__builtin_amdgcn_ubfe(bsh[c], 5u, 6u) << 3));
+            w[c] = *reinterpret_cast<const uint2 *>(reinterpret_cast<const char *>(blk) + (__builtin_amdgcn_ubfe(bs[c], 5u, 6u) << 3));
         unsigned I = 0u, Q = 0u;
 #pragma unroll
         for (int c = 0; c < 6; ++c) {
-            I |= __builtin_amdgcn_ubfe(w[c].x, bsh[c], 1u) << fpos[c];
-            Q |= __builtin_amdgcn_ubfe(w[c].y, bsh[c], 1u) << fpos[c];
+            I |= __builtin_amdgcn_ubfe(w[c].x, bs[c], 1u) << fpos[c];
+            Q |= __builtin_amdgcn_ubfe(w[c].y, bs[c], 1u) << fpos[c];
         }
         // (I, Q) = 00 -> 0, 10 -> 1, 11 -> 2, 01 -> 3 quarter turns, in every field at once; the guard bits absorb the carry
         P = (P + ((I ^ Q) | (Q << 1))) & 0x333333u;
@@ -328,7 +355,9 @@ void tf_kernel(const TfArgs a)
     // at the top of the next iteration.
     auto fetch_block = [&](int d) __attribute__((always_inline)) -> uint32_t {
         const int dd = min(max(d, 0), G::nb_symbols - 2);
-        return reinterpret_cast<const uint32_t *>(fbits + (size_t)dd * (size_t)(K / 4))[t < kBitWords ? t : 0];
+        int tf = t < kBitWords ? t : 0;
+        if constexpr (CFR_SEQ) asm volatile("" : "+v"(tf));    // (the address formed here, not held as a lane register pair)
+        return reinterpret_cast<const uint32_t *>(fbits + (size_t)dd * (size_t)(K / 4))[tf];
     };
     // (I dword j -> slot 2 j, Q dword j -> slot 2 j + 1; kBitWords = dummy slot)
     const int bit_slot = t < kBitWords / 2 ? 2 * t : (t < kBitWords ? 2 * (t - kBitWords / 2) + 1 : kBitWords);
@@ -440,7 +469,10 @@ void tf_kernel(const TfArgs a)
         const float clip2 = a.cfr_clip * a.cfr_clip, eclip2 = a.cfr_errclip * a.cfr_errclip;   // :315, :339
         const bool mer_sym = stats && s > 0 && s == (a.cfr_mer_base + frame) % nsym;             // :198, :250
         constexpr int NW = (T + 63) / 64;
-        cf before[8];
+        // (CFR_SEQ: the symbol before CFR is not held across the three transforms for the one MER symbol of a frame -- that symbol
+        // is transformed once more, when the sums are due)
+        constexpr bool KEEP_BEFORE = !CFR_SEQ;
+        cf before[KEEP_BEFORE ? 8 : 1];
         float pk = 0.f, sm = 0.f;
         unsigned nclip = 0, neclip = 0;
 #pragma unroll
@@ -448,7 +480,7 @@ void tf_kernel(const TfArgs a)
             const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
             pk = fmaxf(pk, mag2);
             sm += mag2;
-            before[m] = v[m];
+            if (KEEP_BEFORE) before[m] = v[m];
             // :320-330, x * sqrt(clip^2 / |x|^2) as x * clip * rsq(|x|^2): one v_rsq_f32 and a select, no branch, no
             // correctly rounded division and square root (twenty-odd instructions each; the factor is good to 1 ulp and
             // the transforms that follow round more than that)
@@ -473,6 +505,15 @@ void tf_kernel(const TfArgs a)
             pp[0] = (double)p;
             pp[1] = q / (double)N;
         }
+        // (CFR_SEQ: the lane's reference bins are formed again here -- six reads of the unit-vector table -- rather than held across
+        // two transforms)
+        cf rv[CFR_SEQ ? 8 : 1];
+        if constexpr (CFR_SEQ) {
+            cf val2[6];
+            load_active(s, val2);
+            place(val2, rv);
+            refv = rv;
+        }
 #pragma unroll
         for (int m = 0; m < 8; ++m) {
             const cf c = cscale(v[m], 1.0f / (float)N);         // :349-350 (a power of two: exact)
@@ -483,7 +524,20 @@ void tf_kernel(const TfArgs a)
             neclip += over ? 1u : 0u;
             v[m] = mk(fmaf(e.x, f, c.x), fmaf(e.y, f, c.y));
         }
-        if (FIR) {
+        if constexpr (CFR_SEQ) {
+            // the filtered copy first (zf), then the corrected spectrum itself.  The filter's response at the lane's eight bins comes
+            // from memory here (a 16 kB table, cache-resident; the previous symbol's stores, which the wait for these loads also
+            // covers, are two transforms old)
+            cf hh[8];
+            int tl = tt;
+            asm volatile("" : "+v"(tl));          // (the table address formed here, not held as a lane register pair)
+#pragma unroll
+            for (int m = 0; m < 8; ++m) hh[m] = a.t.fir_h[tl + T * m];
+#pragma unroll
+            for (int m = 0; m < 8; ++m) zf[m] = cmul(v[m], hh[m]);
+            F::template run<+1, DBUF, cf, true>(zf, fbuf, fpar, tw, tt, tw8_l);
+            F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
+        } else if (FIR) {
             // the corrected spectrum and its filtered copy go back to the time domain as one packed transform;
             // zf receives the filtered symbol
             c2 v2[8];
@@ -517,9 +571,23 @@ void tf_kernel(const TfArgs a)
                     const float mag2 = v[m].x * v[m].x + v[m].y * v[m].y;
                     pk2 = fmaxf(pk2, mag2);
                     sm2 += mag2;
-                    const cf d = csub(v[m], before[m]);
-                    siq += before[m].x * before[m].x + before[m].y * before[m].y;
-                    sdl += d.x * d.x + d.y * d.y;
+                    if (KEEP_BEFORE) {
+                        const cf d = csub(v[m], before[m]);
+                        siq += before[m].x * before[m].x + before[m].y * before[m].y;
+                        sdl += d.x * d.x + d.y * d.y;
+                    }
+                }
+                if (!KEEP_BEFORE && mer_sym) {
+                    cf val2[6], b[8];
+                    load_active(s, val2);
+                    place(val2, b);
+                    F::template run<+1, DBUF, cf, true>(b, fbuf, fpar, tw, tt, tw8_l);
+#pragma unroll
+                    for (int m = 0; m < 8; ++m) {
+                        const cf d = csub(v[m], b[m]);
+                        siq += b[m].x * b[m].x + b[m].y * b[m].y;
+                        sdl += d.x * d.x + d.y * d.y;
+                    }
                 }
                 pk2 = lane_on ? pk2 : 0.f; sm2 = lane_on ? sm2 : 0.f; siq = lane_on ? siq : 0.f; sdl = lane_on ? sdl : 0.f;
                 wave_max_sum3_dpp(pk2, sm2, siq, sdl);
@@ -667,8 +735,10 @@ void tf_kernel(const TfArgs a)
     auto boundary = [&](const cf *src) __attribute__((always_inline)) {
         // src = [tail (C) | head (C)]; output i of the C boundary outputs = sum_j taps[j] src[i + j].
         // Four lanes (one DPP quad) share an output, lane q taking taps q, q+4, ...
+        int tb = t;
+        if constexpr (CFR_SEQ) asm volatile("" : "+v"(tb));    // (at the register limit: lane indices re-derived, not held)
         for (int i0 = 0; i0 < C; i0 += kThreads / 4) {
-            const int i = i0 + (t >> 2), q = t & 3;
+            const int i = i0 + (tb >> 2), q = tb & 3;
             const int ii = i < C ? i : 0;
             cf acc = fir_quad_lane(src + ii, q);
             quad_sum2_dpp(acc.x, acc.y);                                    // the 4 lanes of an output are one DPP quad
@@ -676,7 +746,7 @@ void tf_kernel(const TfArgs a)
                 const cf ts = a.tii_seg[len0 - C + i];
                 acc = mk(fmaf(g1s, ts.x, acc.x), fmaf(g1s, ts.y, acc.y));
             }
-            if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, t >> 2, acc);
+            if (i < C && q == 0) put(prev_pos + prev_seg - C + i0, tb >> 2, acc);
         }
     };
 
@@ -897,11 +967,15 @@ void tf_kernel(const TfArgs a)
         cf uedge = mk(0.f, 0.f);                  // ZONLY: the lane's boundary sample of the unfiltered symbol
         if (DUAL && CFR) {
             // IFFT alone, crest-factor reduction on it, and back through the packed pair (inside cfr_symbol)
-            cf refv[8];
             place(val, v);
             F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l);
-            place(val, refv);
-            cfr_symbol(v, z, refv, s, !lookahead);
+            if constexpr (CFR_SEQ) {
+                cfr_symbol(v, z, nullptr, s, !lookahead);         // (forms the reference bins again itself, behind the forward transform)
+            } else {
+                cf refv[8];
+                place(val, refv);
+                cfr_symbol(v, z, refv, s, !lookahead);
+            }
         } else if (DUAL) {
             // unfiltered and filtered transform of the symbol in lockstep (see struct c2)
             cf valf[6];
