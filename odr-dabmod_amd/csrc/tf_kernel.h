@@ -99,7 +99,7 @@ template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, boo
 // FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
 // 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             EQ ? 4 : CFR ? ((LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !WIN) ? 4 : (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2)) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+                             EQ ? 4 : CFR ? ((LOGN == 11 && FROM_BITS && GUARD && !WIN && (!FIR || NT == 45)) ? 4 : (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2)) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
@@ -119,7 +119,12 @@ void tf_kernel(const TfArgs a)
     constexpr int N = F::N, T = F::T;
     // exchange buffers: the variants without FIR alternate between two (one barrier per exchange); the FIR variants
     // keep one (two barriers per exchange) -- 36 KB of LDS per workgroup and three workgroups per CU, EQ 28 KB and four
-    constexpr bool DBUF = !FIR;
+    // CFR_LEAN (round 5: the Mode I coded-bits CFR chains with the guard interval -- no FIRFilter, or the default-length one): built
+    // for FOUR waves per SIMD.  What kept these kernels above 128 registers were loop invariants, not the transforms; each went
+    // where it costs an instruction or two per symbol instead of a register (see advance, fetch_block, cfr_symbol, boundary), and
+    // one exchange buffer serves (two barriers per exchange; 24 kB of LDS per workgroup).
+    constexpr bool CFR_LEAN = CFR && LOGN == 11 && FROM_BITS && GUARD && !WIN && (!FIR || NT == 45);
+    constexpr bool DBUF = !FIR && !CFR_LEAN;
     const int t = threadIdx.x;
     const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
     const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
@@ -133,7 +138,7 @@ void tf_kernel(const TfArgs a)
     // after the other as plain transforms instead of one packed pair -- the same instruction count (a packed fp32 instruction
     // occupies the SIMD twice as long), 8-byte exchanges, and registers for a fourth wave per SIMD
     // (the default filter length only: the run-time tap count's boundary loop does not fit the 128 registers)
-    constexpr bool CFR_SEQ = CFR && LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !WIN;
+    constexpr bool CFR_SEQ = CFR_LEAN && FIR;
     constexpr int kXElems = (FIR && !EQ && !CFR_SEQ) ? 2 * F::LDS_ELEMS : (DBUF ? 2 : 1) * F::LDS_ELEMS;
     double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
     // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
@@ -176,7 +181,7 @@ void tf_kernel(const TfArgs a)
     F::fill_tw8(a.t.twiddle, tw8_l, t);
     // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
     float *cfr_red = reinterpret_cast<float *>(tw8_l + 56);
-    uint2 *bsh_l = reinterpret_cast<uint2 *>(cfr_red + 6 * ((T + 63) / 64));     // CFR_SEQ: [3][T] bit positions of the lane's six carriers
+    uint2 *bsh_l = reinterpret_cast<uint2 *>(cfr_red + 6 * ((T + 63) / 64));     // CFR_LEAN: [3][T] bit positions of the lane's six carriers
     if (t < 64) {
         const unsigned p = ((unsigned)t + ((unsigned)t >> 3)) & 7u;
         const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
@@ -267,7 +272,7 @@ void tf_kernel(const TfArgs a)
             bsh[c] = (unsigned)bitpos[c] ^ 7u;
             P |= ((unsigned)a.t.phase_q[kpos[c]] & 3u) << fpos[c];
         }
-        if constexpr (CFR_SEQ) {
+        if constexpr (CFR_LEAN) {
 #pragma unroll
             for (int j = 0; j < 3; ++j) bsh_l[j * T + t] = make_uint2(bsh[2 * j], bsh[2 * j + 1]);
         }
@@ -320,7 +325,7 @@ void tf_kernel(const TfArgs a)
     auto advance = [&](const uint32_t *blk) __attribute__((always_inline)) {
         uint2 w[6];
         unsigned bs[6];
-        if constexpr (CFR_SEQ) {
+        if constexpr (CFR_LEAN) {
             // (at the register limit: the six bit positions live in LDS -- three 8-byte reads per symbol -- instead of six lane
             // registers and six more for the dword offsets hoisted out of the loop; spilled, they came back from scratch behind a
             // wait for the previous symbol's stores)
@@ -356,7 +361,7 @@ void tf_kernel(const TfArgs a)
     auto fetch_block = [&](int d) __attribute__((always_inline)) -> uint32_t {
         const int dd = min(max(d, 0), G::nb_symbols - 2);
         int tf = t < kBitWords ? t : 0;
-        if constexpr (CFR_SEQ) asm volatile("" : "+v"(tf));    // (the address formed here, not held as a lane register pair)
+        if constexpr (CFR_LEAN) asm volatile("" : "+v"(tf));    // (the address formed here, not held as a lane register pair)
         return reinterpret_cast<const uint32_t *>(fbits + (size_t)dd * (size_t)(K / 4))[tf];
     };
     // (I dword j -> slot 2 j, Q dword j -> slot 2 j + 1; kBitWords = dummy slot)
@@ -469,9 +474,9 @@ void tf_kernel(const TfArgs a)
         const float clip2 = a.cfr_clip * a.cfr_clip, eclip2 = a.cfr_errclip * a.cfr_errclip;   // :315, :339
         const bool mer_sym = stats && s > 0 && s == (a.cfr_mer_base + frame) % nsym;             // :198, :250
         constexpr int NW = (T + 63) / 64;
-        // (CFR_SEQ: the symbol before CFR is not held across the three transforms for the one MER symbol of a frame -- that symbol
+        // (CFR_LEAN: the symbol before CFR is not held across the three transforms for the one MER symbol of a frame -- that symbol
         // is transformed once more, when the sums are due)
-        constexpr bool KEEP_BEFORE = !CFR_SEQ;
+        constexpr bool KEEP_BEFORE = !CFR_LEAN;
         cf before[KEEP_BEFORE ? 8 : 1];
         float pk = 0.f, sm = 0.f;
         unsigned nclip = 0, neclip = 0;
@@ -505,10 +510,10 @@ void tf_kernel(const TfArgs a)
             pp[0] = (double)p;
             pp[1] = q / (double)N;
         }
-        // (CFR_SEQ: the lane's reference bins are formed again here -- six reads of the unit-vector table -- rather than held across
+        // (CFR_LEAN: the lane's reference bins are formed again here -- six reads of the unit-vector table -- rather than held across
         // two transforms)
-        cf rv[CFR_SEQ ? 8 : 1];
-        if constexpr (CFR_SEQ) {
+        cf rv[CFR_LEAN ? 8 : 1];
+        if constexpr (CFR_LEAN) {
             cf val2[6];
             load_active(s, val2);
             place(val2, rv);
@@ -1005,7 +1010,9 @@ void tf_kernel(const TfArgs a)
             place(val, v);
             pt.stamp(PH_INPUT);
             F::template run<+1, DBUF, cf, true>(v, fbuf, fpar, tw, tt, tw8_l, &pt);
-            if (CFR) {
+            if constexpr (CFR_LEAN) {
+                cfr_symbol(v, z, nullptr, s, !lookahead);
+            } else if (CFR) {
                 cf refv[8];
                 place(val, refv);
                 cfr_symbol(v, z, refv, s, !lookahead);       // (WIN without FIR looks one symbol ahead: no statistics for it)

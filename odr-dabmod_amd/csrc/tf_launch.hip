@@ -17,11 +17,13 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
 {
     const size_t N = (size_t)1 << logN;
     const bool eq = flags & TF_EQ;
-    const bool dbuf = !(flags & TF_FIR);                     // two exchange buffers without FIR, one with (see tf_kernel)
-    // (the Mode I coded-bits CFR chain with the fused FIRFilter runs its transforms one after the other: CFR_SEQ in tf_kernel)
-    const unsigned seq_want = TF_CFR | TF_FIR | TF_FROM_BITS | TF_GUARD;
-    const bool cfr_seq = logN == 11 && nt == 45 && (flags & seq_want) == seq_want && !(flags & TF_WINDOW);
-    const bool dual = (flags & TF_FIR) && !eq && !cfr_seq;   // packed dual transform: 16-byte elements
+
+    // (the Mode I coded-bits CFR chains with the guard interval, without FIRFilter or with the default-length one: CFR_LEAN in
+    // tf_kernel -- one exchange buffer, plain transforms one after the other, the lanes' bit positions in LDS)
+    const unsigned lean_want = TF_CFR | TF_FROM_BITS | TF_GUARD;
+    const bool cfr_lean = logN == 11 && (flags & lean_want) == lean_want && !(flags & TF_WINDOW) && (!(flags & TF_FIR) || nt == 45);
+    const bool dbuf = !(flags & TF_FIR) && !cfr_lean;        // two exchange buffers without FIR, one with (see tf_kernel)
+    const bool dual = (flags & TF_FIR) && !eq && !cfr_lean;  // packed dual transform: 16-byte elements
     size_t b = dual ? (N + N / 8) * 2 * sizeof(float2) : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
     b += 16 * sizeof(double);
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
@@ -32,7 +34,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
     b += 56 * sizeof(float2);                                      // twiddles of the stride-8 stage
     if (flags & TF_CFR) b += 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red
-    if (cfr_seq) b += 3 * (N / 8) * 2 * sizeof(uint32_t);               // bit positions of the lanes' carriers
+    if (cfr_lean) b += 3 * (N / 8) * 2 * sizeof(uint32_t);               // bit positions of the lanes' carriers
     if (wf) {
         // behind the twiddle table: two stashes, the next symbol's samples, the windowed stream, the window
         const size_t C = (size_t)std::max(ntaps - 1, 0), W = (size_t)std::max(overlap, 0);
