@@ -196,6 +196,10 @@ void tf_kernel(const TfArgs a)
         for (int i = t; i < 3 * kEqW + kEqDLen; i += blockDim.x) eq_zp[i] = mk(0.f, 0.f);
     }
     const int W = WIN ? a.overlap : 0;
+    // (skipping the lane tests of the slots that cannot touch a seam: measured +10 % on the windowed default chain with s16 output,
+    // +0.8 % on the equalised windowed kernel -- and -5 % on the windowed default chain with complexf output, which keeps them)
+    constexpr bool kSkipTests = WIN && (FIR || OFMT != 0);
+    constexpr int kWm = WIN ? (EQ ? kEqWinMax : (kWinMax < G::sym_size - N ? kWinMax : G::sym_size - N)) : 0;   // W <= kWm (tf_has_window / tf_has_eq)
     // WIN with FIR: behind everything else, sized at run time (C = ntaps - 1): two stashes of a symbol's
     // [x[N-W-C .. N) | x[0 .. W)] (C + 2W each), the next symbol's x[N-cp-W .. N-cp+W+C) (2W + C), the windowed stream
     // U around the seam (2W + 2C), the window
@@ -1201,12 +1205,14 @@ void tf_kernel(const TfArgs a)
             // ---- seam between the previous symbol and this one -------------------------
             cf *pprev = wbuf + cur * 2 * kWinMax, *pnew = wbuf + (cur ^ 1) * 2 * kWinMax, *rise = wbuf + 4 * kWinMax;
             if (lane_on) {
+                // (W <= kWm: which register slots can hold a seam sample at all is known at compile time -- the lane tests of
+                // the other slots fold away)
 #pragma unroll
                 for (int m = 0; m < 8; ++m) {
                     const int n = t + T * m, r = n - (N - cpl - W);
-                    if (n >= N - W) pnew[n - (N - W)] = v[m];
-                    if (n < W) pnew[W + n] = v[m];
-                    if (r >= 0 && r < 2 * W) rise[r] = v[m];
+                    if ((!kSkipTests || (m + 1) * T > N - kWm) && n >= N - W) pnew[n - (N - W)] = v[m];
+                    if ((!kSkipTests || m * T < kWm) && n < W) pnew[W + n] = v[m];
+                    if ((!kSkipTests || ((m + 1) * T > N - cp - kWm && m * T < N - cp + kWm)) && r >= 0 && r < 2 * W) rise[r] = v[m];
                 }
             }
             lds_barrier();
@@ -1231,8 +1237,11 @@ void tf_kernel(const TfArgs a)
                 const int n = t + T * m;
                 const cf y = scaled(v[m]);
                 // FIR: the last C belong to `boundary`; WIN: the last W to the seam (with both: the last C + W)
-                if (FIR ? n < N - C - (keep_tail ? 0 : W) : (keep_tail || n < N - W)) put(pos + cpl + T * m, t, y);
-                if ((m > m_cp || (m == m_cp && n >= N - cpl)) && (!WIN || n - (N - cpl) >= W)) put(pos, n - (N - cpl), y);
+                // (WIN: slots that lie clear of the seam whatever the overlap -- known at compile time -- skip the lane tests)
+                const bool body_clear = kSkipTests && (m + 1) * T <= N - kWm - (FIR ? (NT ? NT - 1 : kBnd - 1) : 0);
+                const bool prefix_clear = !WIN || (kSkipTests && m * T - (N - cp) >= kWm);
+                if (body_clear || (FIR ? n < N - C - (keep_tail ? 0 : W) : (keep_tail || n < N - W))) put(pos + cpl + T * m, t, y);
+                if ((m > m_cp || (m == m_cp && n >= N - cpl)) && (prefix_clear || n - (N - cpl) >= W)) put(pos, n - (N - cpl), y);
             }
         }
         pt.stamp(PH_STORES);
