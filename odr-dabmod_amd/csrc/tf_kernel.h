@@ -95,7 +95,7 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // plain form.  Measured: 2.51 M frames/s against 1.91 M for the packed dual transform that served these settings before.
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
           bool ZONLY = false, int OFMT = 0, bool WIN = false, bool EQ = false>
-// Waves per SIMD asked of the register allocator: EQ 4 (128 VGPRs, 28 KB of LDS: four workgroups per CU); CFR 2; no
+// Waves per SIMD asked of the register allocator: EQ 4 (128 VGPRs, 29 KB of LDS: four workgroups per CU); CFR 2 ... 4 (4: CFR_LEAN); no
 // FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
 // 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
@@ -118,7 +118,7 @@ void tf_kernel(const TfArgs a)
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
     // exchange buffers: the variants without FIR alternate between two (one barrier per exchange); the FIR variants
-    // keep one (two barriers per exchange) -- 36 KB of LDS per workgroup and three workgroups per CU, EQ 28 KB and four
+    // keep one (two barriers per exchange) -- 36 KB of LDS per workgroup and three workgroups per CU, EQ 29 KB and four
     // CFR_LEAN (round 5: the Mode I coded-bits CFR chains with the guard interval -- no FIRFilter, or the default-length one): built
     // for FOUR waves per SIMD.  What kept these kernels above 128 registers were loop invariants, not the transforms; each went
     // where it costs an instruction or two per symbol instead of a register (see advance, fetch_block, cfr_symbol, boundary), and
