@@ -74,7 +74,7 @@ def _normalise(c):
 
 
 def _cases():
-    rs = np.random.RandomState(20250930)
+    rs = np.random.RandomState(int(os.environ.get("DABGPU_FUZZ_SEED", "20250930")))     # (another one-off hunt: another seed)
     return [_draw(rs) for _ in range(N_CASES)]
 
 
