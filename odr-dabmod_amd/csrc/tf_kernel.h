@@ -96,10 +96,10 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
           bool ZONLY = false, int OFMT = 0, bool WIN = false, bool EQ = false>
 // Waves per SIMD asked of the register allocator: EQ 4 (128 VGPRs, 29 KB of LDS: four workgroups per CU); CFR 2 ... 4 (4: CFR_LEAN); no
-// FIR 2; the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
+// FIR 2 (Mode I coded-bits default chain: 5, NOFIR_1BUF); the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
 // 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             EQ ? 4 : CFR ? ((LOGN == 11 && FROM_BITS && GUARD && !WIN && (!FIR || NT == 45)) ? 4 : (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2)) : !FIR ? 2 : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+                             EQ ? 4 : CFR ? ((LOGN == 11 && FROM_BITS && GUARD && !WIN && (!FIR || NT == 45)) ? 4 : (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2)) : !FIR ? ((LOGN == 11 && FROM_BITS && GUARD && !CFR && (!WIN || OFMT != 0)) ? ((WIN || (OFMT == 3 && !GAIN)) ? 4 : 5) : 2) : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
@@ -124,7 +124,13 @@ void tf_kernel(const TfArgs a)
     // where it costs an instruction or two per symbol instead of a register (see advance, fetch_block, cfr_symbol, boundary), and
     // one exchange buffer serves (two barriers per exchange; 24 kB of LDS per workgroup).
     constexpr bool CFR_LEAN = CFR && LOGN == 11 && FROM_BITS && GUARD && !WIN && (!FIR || NT == 45);
-    constexpr bool DBUF = !FIR && !CFR_LEAN;
+    // NOFIR_1BUF (round 5: the reference's default chain, Mode I from coded bits): ONE exchange buffer (two barriers per exchange)
+    // and 24 kB of LDS instead of 42 -- five workgroups per CU (<= 96 registers) instead of three.  Measured: complexf output
+    // unchanged (3.3 M frames/s: the board's power limit), s16 4.07 -> 4.29 M, u8 3.86 -> 4.13 M; four waves: 4.12 / 3.96 M.
+    // (the s8 store without GainControl spills 8 bytes at five waves: that one is built for four)
+    // (windowed: with the s16 store, 3.57 -> 3.82 M; the complexf form loses 2 % and keeps two buffers)
+    constexpr bool NOFIR_1BUF = LOGN == 11 && FROM_BITS && GUARD && !FIR && !CFR && (!WIN || OFMT != 0);
+    constexpr bool DBUF = !FIR && !CFR_LEAN && !NOFIR_1BUF;
     const int t = threadIdx.x;
     const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
     const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask

@@ -22,7 +22,9 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     // tf_kernel -- one exchange buffer, plain transforms one after the other, the lanes' bit positions in LDS)
     const unsigned lean_want = TF_CFR | TF_FROM_BITS | TF_GUARD;
     const bool cfr_lean = logN == 11 && (flags & lean_want) == lean_want && !(flags & TF_WINDOW) && (!(flags & TF_FIR) || nt == 45);
-    const bool dbuf = !(flags & TF_FIR) && !cfr_lean;        // two exchange buffers without FIR, one with (see tf_kernel)
+    const bool nofir_1buf = logN == 11 && (flags & (TF_FROM_BITS | TF_GUARD)) == (TF_FROM_BITS | TF_GUARD) &&
+                            !(flags & (TF_FIR | TF_CFR)) && (!(flags & TF_WINDOW) || tf_ofmt(flags));
+    const bool dbuf = !(flags & TF_FIR) && !cfr_lean && !nofir_1buf;        // two exchange buffers without FIR, one with (see tf_kernel)
     const bool dual = (flags & TF_FIR) && !eq && !cfr_lean;  // packed dual transform: 16-byte elements
     size_t b = dual ? (N + N / 8) * 2 * sizeof(float2) : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
     b += 16 * sizeof(double);
