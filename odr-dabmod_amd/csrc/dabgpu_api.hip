@@ -192,13 +192,20 @@ struct dabgpu_ctx {
         hipEvent_t ev = nullptr;
         DevBuf d_a, d_b, d_fmt, d_clip, d_gain1, d_cfr_counts, d_cfr_mer, d_cfr_papr, d_cfr_tmp;
     };
-    enum { kMaxLanes = 4, kLaneMaxFrames = 2048 };
+    enum { kMaxLanes = 4, kLaneMaxFrames = 2048, kLaneScratchBytes = 256 << 20 };
     Lane lane[kMaxLanes];                 // (entry 0: only `ev` is used)
     bool lane_own_queue[kMaxLanes] = {true, false, false, false};   // the probe found the lane a hardware queue of its own
     int n_lanes = 3;
     int call_lanes = 1;                   // lanes the CURRENT chain call rotates over (1: an explicit stream, lane 0 only)
     unsigned long long lane_seq = 0;
     int clip_lane = 0, cfr_last_lane = 0; // whose scratch holds the clip count / the CFR statistics of the most recent call
+    // Ordering between the lanes and the context's own stream for the NULL-stream entry points that do NOT rotate
+    // (dabgpu_format_process_dev, dabgpu_post_process_dev): they queue on `stream` behind everything the lanes hold
+    // (lane_dirty: the lane has work `stream` has not been ordered behind yet), and a later chain call that goes to
+    // another lane is ordered behind them (own_epoch / lane_seen_epoch).
+    bool lane_dirty[kMaxLanes] = {false, false, false, false};
+    unsigned long long own_epoch = 0, lane_seen_epoch[kMaxLanes] = {0, 0, 0, 0};
+    hipEvent_t own_ev = nullptr;
     // The native-rate stream between FIRFilter and Resampler (src/DabModulator.cpp:403-406) in pieces of this many frames
     // through a two-piece ring that stays cache-resident, produced on lane 1's stream while the consumer works on the
     // piece before (dabgpu_set_handover_frames; 0 = one piece, the whole batch through memory)
@@ -220,6 +227,7 @@ struct dabgpu_ctx {
         unsigned long long *h_clip = nullptr;          // pinned: this batch's clipped-component count (output formats)
         DevBuf d_in, d_out;
         hipEvent_t computed = nullptr, copied = nullptr;
+        hipStream_t stream = nullptr;                  // the lane this batch's kernels were queued on
         bool busy = false;
         int out_format = 0;                            // the output format this batch was submitted with
     } slot[2];
@@ -268,6 +276,42 @@ int lane_stream(dabgpu_ctx *c, int i, hipStream_t *out)
         HIPCHK(c, create_stream_apart(others.data(), (int)others.size(), &c->lane[k].stream, &c->lane_own_queue[k]));
     }
     *out = c->lane[i].stream;
+    return DABGPU_OK;
+}
+
+// A NULL-stream call that runs on the context's own stream: behind everything the other lanes have been given.
+int own_stream_joins_lanes(dabgpu_ctx *c)
+{
+    for (int i = 1; i < (int)dabgpu_ctx::kMaxLanes; ++i) {
+        if (!c->lane[i].stream || !c->lane_dirty[i]) continue;
+        if (!c->lane[i].ev) HIPCHK(c, hipEventCreateWithFlags(&c->lane[i].ev, hipEventDisableTiming));
+        HIPCHK(c, hipEventRecord(c->lane[i].ev, c->lane[i].stream));
+        HIPCHK(c, hipStreamWaitEvent(c->stream, c->lane[i].ev, 0));
+        c->lane_dirty[i] = false;
+    }
+    ++c->own_epoch;            // (what follows on `stream` is work the lanes have not been ordered behind)
+    return DABGPU_OK;
+}
+
+// ... and a chain call that goes to lane i: behind such work of the context's own stream
+int lane_joins_own_stream(dabgpu_ctx *c, int i)
+{
+    if (i == 0) return DABGPU_OK;
+    c->lane_dirty[i] = true;
+    if (c->lane_seen_epoch[i] == c->own_epoch) return DABGPU_OK;
+    if (!c->own_ev) HIPCHK(c, hipEventCreateWithFlags(&c->own_ev, hipEventDisableTiming));
+    HIPCHK(c, hipEventRecord(c->own_ev, c->stream));
+    HIPCHK(c, hipStreamWaitEvent(c->lane[i].stream, c->own_ev, 0));
+    c->lane_seen_epoch[i] = c->own_epoch;
+    return DABGPU_OK;
+}
+
+// every stream of the context idle (before a table that kernels in flight on ANY lane may read is rewritten)
+int drain_lanes(dabgpu_ctx *c)
+{
+    HIPCHK(c, hipStreamSynchronize(c->stream));
+    for (int i = 1; i < (int)dabgpu_ctx::kMaxLanes; ++i)
+        if (c->lane[i].stream) HIPCHK(c, hipStreamSynchronize(c->lane[i].stream));
     return DABGPU_OK;
 }
 
@@ -729,6 +773,7 @@ int run_resampler(dabgpu_ctx *c, const float2 *d_in, size_t total, float2 *d_out
     const size_t hin = (size_t)c->rs_nin / 2;
     if (total % hin) return fail(c, DABGPU_E_INVALID, "Resampler::process input size not valid!");
     const size_t nhops = total / hin;
+    if (nhops == 0) return DABGPU_OK;     // (nothing in, nothing out, the state -- halo buffers included -- as it was)
     ResamplerArgs a{};
     a.nin = c->rs_nin; a.nout = c->rs_nout; a.factor = c->rs_factor;
     a.window = (const float *)c->d_rs_window.p;
@@ -956,6 +1001,12 @@ int ensure_tii_segment(dabgpu_ctx *c, unsigned mask, bool windowed, size_t nativ
     std::vector<uint8_t> acp;
     if (tii_carrier_set(c->g.mode, c->cur.tii_comb, c->cur.tii_pattern, acp))
         return fail(c, DABGPU_E_INVALID, "TII::enable_carrier invalid k!");
+    // d_acp / d_tii_car / d_tii_frame are shared by the lanes: batches still in flight on ANOTHER lane read the old
+    // segment (in-kernel, or launch_tii_add) -- they finish before it is overwritten.  Once per TII / CFR setting or mask.
+    {
+        const int rc_drain = drain_lanes(c);
+        if (rc_drain) return rc_drain;
+    }
     HIPCHK(c, upload(c->d_acp, acp, s));
     HIPCHK(c, c->d_tii_car.reserve(car_bytes + K * sizeof(float2)));
     HIPCHK(c, c->d_tii_frame.reserve(native * sizeof(float2)));
@@ -987,7 +1038,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     int rc = apply_settings(c);
     if (rc) return rc;
     LaneScope scratch(c, lane);
-    if (c->cur.cfr_enable && apply_format) c->cfr_last_lane = lane;
+    if (c->cur.cfr_enable) c->cfr_last_lane = lane;   // (also the OfdmGenerator stage wrapper: ITS statistics are the most recent)
     if ((mask & DABGPU_STAGE_NOGUARD) && (mask & (DABGPU_STAGE_FIR | DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY)))
         return fail(c, DABGPU_E_INVALID, "NOGUARD cannot be combined with FIR/RESAMPLE/POLY");
     if ((mask & DABGPU_STAGE_FIR) && c->cur.taps.empty())
@@ -1306,7 +1357,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
         for (DevBuf *b : {&l.d_a, &l.d_b, &l.d_fmt, &l.d_clip, &l.d_gain1, &l.d_cfr_counts, &l.d_cfr_mer, &l.d_cfr_papr, &l.d_cfr_tmp})
             b->release();
     }
-    for (hipEvent_t e : {c->ho_prod[0], c->ho_prod[1], c->ho_cons[0], c->ho_cons[1], c->ho_start, c->ho_join})
+    for (hipEvent_t e : {c->ho_prod[0], c->ho_prod[1], c->ho_cons[0], c->ho_cons[1], c->ho_start, c->ho_join, c->own_ev})
         if (e) (void)hipEventDestroy(e);
     if (c->copy_stream) (void)hipStreamDestroy(c->copy_stream);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -1822,6 +1873,7 @@ int dabgpu_format_process_dev(dabgpu_ctx *c, const void *d_in, size_t n_floats, 
     int rc = check_out(c, n_floats * elem, out_cap, out_bytes);
     if (rc) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!stream && (rc = own_stream_joins_lanes(c))) return rc;     // (its input may be a chain call's output on any lane)
     if (!d_num_clipped) {
         HIPCHK(c, c->d_count.reserve(16));
         d_num_clipped = (unsigned long long *)c->d_count.p + 1;      // scratch slot, never read
@@ -1889,6 +1941,17 @@ int pick_lane(dabgpu_ctx *c, size_t n_frames, unsigned mask, bool *rotating)
         resample = (mask & DABGPU_STAGE_RESAMPLE) && c->set.rs_in != c->set.rs_out;
     }
     if (c->n_lanes <= 1 || resample || n_frames > (size_t)dabgpu_ctx::kLaneMaxFrames) return 0;
+    // Every lane owns a set of per-call scratch buffers that grow to the largest call they have seen and are never trimmed.
+    // The one-kernel chains need none; the others (a separate guard / FIRFilter / convert / predistorter kernel: up to two
+    // native-rate frames of 8 B per sample per frame) rotate only while that stays within kLaneScratchBytes per lane --
+    // the small batches the lanes exist for.
+    bool scratch;
+    {
+        std::lock_guard<std::mutex> lk(c->mu);
+        scratch = c->set.overlap > 0 || c->set.out_format != 0 || c->set.cfr_enable || c->set.tii_enable ||
+                  (mask & DABGPU_STAGE_POLY) || (int)c->set.taps.size() > tf_max_fused_taps();
+    }
+    if (scratch && n_frames * 2 * tf_samples(c->g) * sizeof(float2) > (size_t)dabgpu_ctx::kLaneScratchBytes) return 0;
     *rotating = true;
     return (int)(c->lane_seq++ % (unsigned long long)c->n_lanes);
 }
@@ -1902,8 +1965,9 @@ int chain_dev(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
     if (!s) {
         bool rotating = false;
         lane = pick_lane(c, n_frames, mask, &rotating);
-        const int rc = lane_stream(c, lane, &s);
+        int rc = lane_stream(c, lane, &s);
         if (rc) return rc;
+        if ((rc = lane_joins_own_stream(c, lane))) return rc;
         if (rotating) c->call_lanes = c->n_lanes;
     }
     c->clip_from_collect = false;
@@ -1939,6 +2003,7 @@ int dabgpu_post_process_dev(dabgpu_ctx *c, const void *d_native, size_t n_sample
     int rc = apply_settings(c);
     if (rc) return rc;
     hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    if (!stream && (rc = own_stream_joins_lanes(c))) return rc;     // (d_native: a chain call's output on any lane)
     if (mask & ~(unsigned)(DABGPU_STAGE_RESAMPLE | DABGPU_STAGE_POLY))
         return fail(c, DABGPU_E_INVALID, "post-processing: DABGPU_STAGE_RESAMPLE and / or DABGPU_STAGE_POLY");
     if ((mask & DABGPU_STAGE_RESAMPLE) && c->cur.rs_in == c->cur.rs_out) mask &= ~(unsigned)DABGPU_STAGE_RESAMPLE;
@@ -2085,6 +2150,7 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     const int lane = (c->n_lanes > 1 && !(m2 & DABGPU_STAGE_RESAMPLE)) ? slot_index : 0;
     hipStream_t ls;
     if ((rc = lane_stream(c, lane, &ls))) return rc;
+    if ((rc = lane_joins_own_stream(c, lane))) return rc;
     if (!c->copy_stream) {
         // the copy back must overlap with the kernels of BOTH batches in flight: apart from lanes 0 and 1
         hipStream_t l1 = nullptr;
@@ -2139,6 +2205,7 @@ int dabgpu_chain_submit(dabgpu_ctx *c, const uint8_t *bits, size_t n_frames, uns
     HIPCHK(c, hipEventRecord(sl.copied, c->copy_stream));
     sl.out_bytes = need;
     sl.h_out_index = ho;
+    sl.stream = ls;
     sl.busy = true;
     ++c->slot_count;
     ++c->submit_seq;
@@ -2152,6 +2219,12 @@ int dabgpu_chain_collect(dabgpu_ctx *c, const void **iq, size_t *out_bytes)
     if (c->slot_count == 0) return fail(c, DABGPU_E_INVALID, "no batch in flight");
     dabgpu_ctx::Slot &sl = c->slot[c->slot_head];
     HIPCHK(c, hipEventSynchronize(sl.copied));
+    // Nothing ever synchronises the lanes or the copy stream themselves (the events do the ordering), and the HIP runtime
+    // retires the commands of a stream -- their signals, kernel-argument blocks, command objects -- only when somebody asks
+    // about that stream: after ~800 one-frame batches it stopped for 48 ms inside one call to catch up
+    // (profiles/r06_async_series.txt).  Everything this batch queued is complete here; a query is the asking.
+    (void)hipStreamQuery(sl.stream);
+    (void)hipStreamQuery(c->copy_stream);
     *iq = c->h_out[sl.h_out_index];
     if (out_bytes) *out_bytes = sl.out_bytes;
     c->clip_from_collect = true;
@@ -2165,9 +2238,9 @@ int dabgpu_chain_collect(dabgpu_ctx *c, const void **iq, size_t *out_bytes)
 int dabgpu_synchronize(dabgpu_ctx *c)
 {
     CTXCHK(c);
-    HIPCHK(c, hipStreamSynchronize(c->stream));
-    for (int i = 1; i < (int)dabgpu_ctx::kMaxLanes; ++i)
-        if (c->lane[i].stream) HIPCHK(c, hipStreamSynchronize(c->lane[i].stream));
+    const int rc = drain_lanes(c);
+    if (rc) return rc;
+    for (bool &d : c->lane_dirty) d = false;
     return DABGPU_OK;
 }
 

@@ -72,6 +72,11 @@ template <typename Fn> int run_codec(const Context &c, Fn fn, Buffer *const in, 
     return static_cast<int>(n);
 }
 
+void check_dev(dabgpu_ctx *dev, int rc)
+{
+    if (rc != DABGPU_OK) throw std::runtime_error(dabgpu_last_error(dev));
+}
+
 [[noreturn]] void not_exported(const std::string &parameter, const std::string &rc_name)
 {
     throw ParameterError("Parameter '" + parameter + "' is not exported by controllable " + rc_name);
@@ -173,12 +178,28 @@ int OfdmGeneratorFixed::process(Buffer *const, Buffer *) { return 0; }
 
 OfdmGeneratorCF32::OfdmGeneratorCF32(size_t nbSymbols, size_t nbCarriers, size_t spacing,
                                      bool &enableCfr, float &cfrClip, float &cfrErrorClip, bool inverse)
-    : RemoteControllable("ofdm"), m_ctx(dabgpu_host::mode_from_spacing(spacing)),
-      m_nbSymbols(nbSymbols), m_nbCarriers(nbCarriers), m_spacing(spacing), m_cfr(enableCfr),
-      m_cfrClip(cfrClip), m_cfrErrorClip(cfrErrorClip), m_paprBlocks(nbSymbols * 50)
+    : OwnContext(dabgpu_host::mode_from_spacing(spacing)),
+      OfdmControl(m_ctx.get(), nbSymbols, enableCfr, cfrClip, cfrErrorClip),
+      m_nbSymbols(nbSymbols), m_nbCarriers(nbCarriers), m_spacing(spacing)
 {
     if (nbCarriers > spacing) throw std::runtime_error("OfdmGenerator nbCarriers > spacing!");
     if (!inverse) throw std::runtime_error("OfdmGenerator: forward transform is not offloaded");
+}
+
+int OfdmGeneratorCF32::process(Buffer *const dataIn, Buffer *dataOut)
+{
+    const bool cfr = push_settings();
+    const int n = run_codec(m_ctx, dabgpu_ofdm_process, dataIn, dataOut, m_nbSymbols * m_spacing * sizeof(complexf)) /
+                  static_cast<int>(sizeof(complexf));
+    if (cfr) collect_statistics();
+    return n;
+}
+
+namespace dabgpu_host {
+OfdmControl::OfdmControl(dabgpu_ctx *dev, size_t nbSymbols, bool &enableCfr, float &cfrClip, float &cfrErrorClip)
+    : RemoteControllable("ofdm"), m_dev(dev), m_cfr(enableCfr), m_cfrClip(cfrClip), m_cfrErrorClip(cfrErrorClip),
+      m_paprBlocks(nbSymbols * 50)
+{
     // reference src/OfdmGenerator.cpp:67-74
     RC_ADD_PARAMETER(cfr, "Enable crest factor reduction");
     RC_ADD_PARAMETER(clip, "CFR: Clip to amplitude");
@@ -187,24 +208,23 @@ OfdmGeneratorCF32::OfdmGeneratorCF32(size_t nbSymbols, size_t nbCarriers, size_t
     RC_ADD_PARAMETER(papr, "PAPR measurements (before CFR, after CFR)");
 }
 
-int OfdmGeneratorCF32::process(Buffer *const dataIn, Buffer *dataOut)
+bool OfdmControl::push_settings()
 {
-    bool cfr;
-    {
-        std::lock_guard<std::mutex> lock(m_mutex);
-        cfr = m_cfr;
-        m_ctx.check(dabgpu_set_cfr(m_ctx.get(), m_cfr ? 1 : 0, m_cfrClip, m_cfrErrorClip));
-    }
+    std::lock_guard<std::mutex> lock(m_mutex);
+    check_dev(m_dev, dabgpu_set_cfr(m_dev, m_cfr ? 1 : 0, m_cfrClip, m_cfrErrorClip));
     if (m_paprClearRequest.exchange(false)) {            // reference :202-205
         m_paprBefore.clear();
         m_paprAfter.clear();
     }
-    const int n = run_codec(m_ctx, dabgpu_ofdm_process, dataIn, dataOut, m_nbSymbols * m_spacing * sizeof(complexf)) /
-                  static_cast<int>(sizeof(complexf));
-    if (cfr) {
+    return m_cfr;
+}
+
+void OfdmControl::collect_statistics()
+{
+    {
         // the reference's running statistics (src/OfdmGenerator.cpp:232,246-306) from the raw per-frame figures
         dabgpu_cfr_stats st;
-        m_ctx.check(dabgpu_get_cfr_stats(m_ctx.get(), 0, &st));
+        check_dev(m_dev, dabgpu_get_cfr_stats(m_dev, 0, &st));
         std::lock_guard<std::mutex> lock(m_mutex);
         auto push = [](std::deque<double> &d, double v, size_t cap) {
             d.push_back(v);
@@ -226,11 +246,10 @@ int OfdmGeneratorCF32::process(Buffer *const dataIn, Buffer *dataOut)
             push(m_mers, st.mer_sum_delta > 0 ? 10.0 * std::log10(st.mer_sum_iq / st.mer_sum_delta) : 90.0,
                  MAX_CLIP_STATS);
     }
-    return n;
 }
 
 // PAPRStats::calculate_papr (reference src/PAPRStats.cpp:74-103) over stored (peak, mean) pairs
-double OfdmGeneratorCF32::papr_db(const std::deque<double> &pairs) const
+double OfdmControl::papr_db(const std::deque<double> &pairs) const
 {
     if (pairs.size() / 2 < m_paprBlocks) return 0;
     double peak = 0, rms2 = 0;
@@ -242,7 +261,7 @@ double OfdmGeneratorCF32::papr_db(const std::deque<double> &pairs) const
     return 10.0 * std::log10(peak / rms2);
 }
 
-void OfdmGeneratorCF32::set_parameter(const std::string &parameter, const std::string &value)
+void OfdmControl::set_parameter(const std::string &parameter, const std::string &value)
 {
     std::stringstream ss(value);
     ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
@@ -256,12 +275,12 @@ void OfdmGeneratorCF32::set_parameter(const std::string &parameter, const std::s
     } else if (parameter == "clip_stats" || parameter == "papr") {
         throw ParameterError("Parameter '" + parameter + "' is read-only");
     } else {
-        dabgpu_host::not_exported(parameter, get_rc_name());
+        not_exported(parameter, get_rc_name());
     }
     m_paprClearRequest.store(true);
 }
 
-const std::string OfdmGeneratorCF32::get_parameter(const std::string &parameter) const
+const std::string OfdmControl::get_parameter(const std::string &parameter) const
 {
     std::stringstream ss;
     std::lock_guard<std::mutex> lock(m_mutex);
@@ -286,32 +305,47 @@ const std::string OfdmGeneratorCF32::get_parameter(const std::string &parameter)
         ss << "PAPR [dB]: " << std::fixed << (before == 0 ? std::string("N/A") : std::to_string(before)) << ", "
            << (after == 0 ? std::string("N/A") : std::to_string(after));
     } else {
-        dabgpu_host::not_exported(parameter, get_rc_name());
+        not_exported(parameter, get_rc_name());
     }
     return ss.str();
 }
 
-const json::map_t OfdmGeneratorCF32::get_all_values() const
+const json::map_t OfdmControl::get_all_values() const
 {
     json::map_t m;   // (empty in the reference too: "TODO needs rework of the values", :453-458)
     return m;
 }
+}  // namespace dabgpu_host
 
 // ---------------------------------------------------------------- GainControl
 GainControl::GainControl(size_t framesize, GainMode &gainMode, float &digGain, float normalise,
                          float &varVariance)
-    : RemoteControllable("gain"), m_ctx(dabgpu_host::mode_from_spacing(framesize)), m_frameSize(framesize),
-      m_digGain(digGain), m_normalise(normalise), m_var_variance_rc(varVariance), m_gainmode(gainMode)
+    : OwnContext(dabgpu_host::mode_from_spacing(framesize)),
+      GainParameters(m_ctx.get(), gainMode, digGain, normalise, varVariance)
 {
-    RC_ADD_PARAMETER(digital, "Digital Gain");
-    RC_ADD_PARAMETER(mode, "Gainmode (fix|max|var)");
-    RC_ADD_PARAMETER(var, "Variance setting for gainmode var (default: 4)");
     start_pipeline_thread();
 }
 
 GainControl::~GainControl() { stop_pipeline_thread(); }
 
 int GainControl::internal_process(Buffer *const dataIn, Buffer *dataOut)
+{
+    push_settings();
+    return run_codec(m_ctx, dabgpu_gain_process, dataIn, dataOut, dataIn->getLength()) /
+           static_cast<int>(sizeof(complexf));
+}
+
+namespace dabgpu_host {
+GainParameters::GainParameters(dabgpu_ctx *dev, GainMode &gainMode, float &digGain, float normalise, float &varVariance)
+    : RemoteControllable("gain"), m_dev(dev), m_digGain(digGain), m_normalise(normalise),
+      m_var_variance_rc(varVariance), m_gainmode(gainMode)
+{
+    RC_ADD_PARAMETER(digital, "Digital Gain");
+    RC_ADD_PARAMETER(mode, "Gainmode (fix|max|var)");
+    RC_ADD_PARAMETER(var, "Variance setting for gainmode var (default: 4)");
+}
+
+void GainParameters::push_settings()
 {
     int mode;
     float dig, var;
@@ -321,12 +355,10 @@ int GainControl::internal_process(Buffer *const dataIn, Buffer *dataOut)
         dig = m_digGain;
         var = m_var_variance_rc;
     }
-    m_ctx.check(dabgpu_set_gain(m_ctx.get(), mode, dig, m_normalise, var));
-    return run_codec(m_ctx, dabgpu_gain_process, dataIn, dataOut, dataIn->getLength()) /
-           static_cast<int>(sizeof(complexf));
+    check_dev(m_dev, dabgpu_set_gain(m_dev, mode, dig, m_normalise, var));
 }
 
-void GainControl::set_parameter(const std::string &parameter, const std::string &value)
+void GainParameters::set_parameter(const std::string &parameter, const std::string &value)
 {
     std::stringstream ss(value);
     ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
@@ -352,11 +384,11 @@ void GainControl::set_parameter(const std::string &parameter, const std::string 
         std::lock_guard<std::mutex> lock(m_mutex);
         m_var_variance_rc = f;
     } else {
-        dabgpu_host::not_exported(parameter, get_rc_name());
+        not_exported(parameter, get_rc_name());
     }
 }
 
-const std::string GainControl::get_parameter(const std::string &parameter) const
+const std::string GainParameters::get_parameter(const std::string &parameter) const
 {
     std::stringstream ss;
     std::lock_guard<std::mutex> lock(m_mutex);
@@ -364,11 +396,11 @@ const std::string GainControl::get_parameter(const std::string &parameter) const
     else if (parameter == "mode")
         ss << (m_gainmode == GainMode::GAIN_FIX ? "fix" : m_gainmode == GainMode::GAIN_MAX ? "max" : "var");
     else if (parameter == "var") ss << std::fixed << m_var_variance_rc;
-    else dabgpu_host::not_exported(parameter, get_rc_name());
+    else not_exported(parameter, get_rc_name());
     return ss.str();
 }
 
-const json::map_t GainControl::get_all_values() const
+const json::map_t GainParameters::get_all_values() const
 {
     json::map_t m;
     std::lock_guard<std::mutex> lock(m_mutex);
@@ -378,12 +410,12 @@ const json::map_t GainControl::get_all_values() const
     m["var"].v = static_cast<double>(m_var_variance_rc);
     return m;
 }
+}  // namespace dabgpu_host
 
 // ---------------------------------------------------------------- GuardIntervalInserter
 GuardIntervalInserter::GuardIntervalInserter(size_t nbSymbols, size_t spacing, size_t nullSize,
                                              size_t symSize, size_t &windowOverlap, FFTEngine fftEngine)
-    : RemoteControllable("guardinterval"), m_ctx(dabgpu_host::mode_from_spacing(spacing)),
-      m_windowOverlap(windowOverlap)
+    : OwnContext(dabgpu_host::mode_from_spacing(spacing)), GuardParameters(m_ctx.get(), windowOverlap)
 {
     if (nullSize == 0) throw std::logic_error("NULL symbol must be present");
     if (static_cast<int>(fftEngine) != 0 /* FFTEngine::FFTW: the enumeration may be opaque here, GpuStages.h */) throw std::runtime_error("GuardIntervalInserter: only the float engine is offloaded");
@@ -391,8 +423,6 @@ GuardIntervalInserter::GuardIntervalInserter(size_t nbSymbols, size_t spacing, s
     m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
     if ((size_t)g.nb_symbols != nbSymbols || (size_t)g.null_size != nullSize || (size_t)g.sym_size != symSize)
         throw std::runtime_error("GuardIntervalInserter: geometry does not match the transmission mode");
-    RC_ADD_PARAMETER(windowlen, "Window length for OFDM windowng [0 to disable]");
-    m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), windowOverlap));
 }
 
 int GuardIntervalInserter::process(Buffer *const dataIn, Buffer *dataOut)
@@ -402,51 +432,70 @@ int GuardIntervalInserter::process(Buffer *const dataIn, Buffer *dataOut)
     return run_codec(m_ctx, dabgpu_guard_process, dataIn, dataOut, g.tf_samples * sizeof(complexf));
 }
 
-void GuardIntervalInserter::set_parameter(const std::string &parameter, const std::string &value)
+namespace dabgpu_host {
+GuardParameters::GuardParameters(dabgpu_ctx *dev, size_t &windowOverlap)
+    : RemoteControllable("guardinterval"), m_dev(dev), m_windowOverlap(windowOverlap)
 {
-    if (parameter != "windowlen") dabgpu_host::not_exported(parameter, get_rc_name());
+    RC_ADD_PARAMETER(windowlen, "Window length for OFDM windowng [0 to disable]");
+    check_dev(m_dev, dabgpu_set_window_overlap(m_dev, windowOverlap));
+}
+
+void GuardParameters::set_parameter(const std::string &parameter, const std::string &value)
+{
+    if (parameter != "windowlen") not_exported(parameter, get_rc_name());
     std::stringstream ss(value);
     ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
     size_t w = 0;
     ss >> w;
     std::lock_guard<std::mutex> lock(m_mutex);
     m_windowOverlap = w;
-    m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), w));
+    check_dev(m_dev, dabgpu_set_window_overlap(m_dev, w));
 }
 
-const std::string GuardIntervalInserter::get_parameter(const std::string &parameter) const
+const std::string GuardParameters::get_parameter(const std::string &parameter) const
 {
-    if (parameter != "windowlen") dabgpu_host::not_exported(parameter, get_rc_name());
+    if (parameter != "windowlen") not_exported(parameter, get_rc_name());
     std::lock_guard<std::mutex> lock(m_mutex);
     return std::to_string(m_windowOverlap);
 }
 
-const json::map_t GuardIntervalInserter::get_all_values() const
+const json::map_t GuardParameters::get_all_values() const
 {
     json::map_t m;
     std::lock_guard<std::mutex> lock(m_mutex);
     m["windowlen"].v = static_cast<uint64_t>(m_windowOverlap);
     return m;
 }
+}  // namespace dabgpu_host
 
 // ---------------------------------------------------------------- FIRFilter
-FIRFilter::FIRFilter(std::string &taps_file)
-    : RemoteControllable("firfilter"), m_ctx(1), m_taps_file(taps_file)
+FIRFilter::FIRFilter(std::string &taps_file) : OwnContext(1), FirParameters(m_ctx.get(), taps_file)
 {
-    RC_ADD_PARAMETER(ntaps, "(Read-only) number of filter taps.");
-    RC_ADD_PARAMETER(tapsfile, "Filename containing filter taps. When written to, the new file gets automatically loaded.");
-    load_filter_taps(m_taps_file);
     start_pipeline_thread();
 }
 
 FIRFilter::~FIRFilter() { stop_pipeline_thread(); }
 
+int FIRFilter::internal_process(Buffer *const dataIn, Buffer *dataOut)
+{
+    return run_codec(m_ctx, dabgpu_fir_process, dataIn, dataOut, dataIn->getLength());
+}
+
+namespace dabgpu_host {
+FirParameters::FirParameters(dabgpu_ctx *dev, std::string &taps_file)
+    : RemoteControllable("firfilter"), m_dev(dev), m_taps_file(taps_file)
+{
+    RC_ADD_PARAMETER(ntaps, "(Read-only) number of filter taps.");
+    RC_ADD_PARAMETER(tapsfile, "Filename containing filter taps. When written to, the new file gets automatically loaded.");
+    load_filter_taps(m_taps_file);
+}
+
 // taps file: number of taps, then one tap per line (reference src/FIRFilter.cpp:103-133)
-void FIRFilter::load_filter_taps(const std::string &tapsFile)
+void FirParameters::load_filter_taps(const std::string &tapsFile)
 {
     std::vector<float> taps;
     if (tapsFile == "default") {
-        m_ctx.check(dabgpu_set_fir_default_taps(m_ctx.get()));
+        check_dev(m_dev, dabgpu_set_fir_default_taps(m_dev));
         std::lock_guard<std::mutex> lock(m_taps_mutex);
         m_taps.assign(45, 0.f);
         return;
@@ -463,20 +512,15 @@ void FIRFilter::load_filter_taps(const std::string &tapsFile)
             throw std::runtime_error("FIRFilter: file " + tapsFile + " should contain " + std::to_string(n) +
                                      " taps, but EOF reached after " + std::to_string(i) + " taps!");
     }
-    m_ctx.check(dabgpu_set_fir_taps(m_ctx.get(), taps.data(), taps.size()));
+    check_dev(m_dev, dabgpu_set_fir_taps(m_dev, taps.data(), taps.size()));
     std::lock_guard<std::mutex> lock(m_taps_mutex);
     m_taps = taps;
 }
 
-int FIRFilter::internal_process(Buffer *const dataIn, Buffer *dataOut)
-{
-    return run_codec(m_ctx, dabgpu_fir_process, dataIn, dataOut, dataIn->getLength());
-}
-
-void FIRFilter::set_parameter(const std::string &parameter, const std::string &value)
+void FirParameters::set_parameter(const std::string &parameter, const std::string &value)
 {
     if (parameter == "ntaps") throw ParameterError("Parameter 'ntaps' is read-only");
-    if (parameter != "tapsfile") dabgpu_host::not_exported(parameter, get_rc_name());
+    if (parameter != "tapsfile") not_exported(parameter, get_rc_name());
     try {
         load_filter_taps(value);
         m_taps_file = value;
@@ -485,15 +529,15 @@ void FIRFilter::set_parameter(const std::string &parameter, const std::string &v
     }
 }
 
-const std::string FIRFilter::get_parameter(const std::string &parameter) const
+const std::string FirParameters::get_parameter(const std::string &parameter) const
 {
     std::lock_guard<std::mutex> lock(m_taps_mutex);
     if (parameter == "ntaps") return std::to_string(m_taps.size());
     if (parameter == "tapsfile") return m_taps_file;
-    dabgpu_host::not_exported(parameter, get_rc_name());
+    not_exported(parameter, get_rc_name());
 }
 
-const json::map_t FIRFilter::get_all_values() const
+const json::map_t FirParameters::get_all_values() const
 {
     json::map_t m;
     std::lock_guard<std::mutex> lock(m_taps_mutex);
@@ -501,6 +545,7 @@ const json::map_t FIRFilter::get_all_values() const
     m["tapsfile"].v = m_taps_file;
     return m;
 }
+}  // namespace dabgpu_host
 
 // ---------------------------------------------------------------- Resampler
 Resampler::Resampler(size_t inputRate, size_t outputRate, size_t resolution)
@@ -547,9 +592,15 @@ int tii_mode(unsigned int dabmode)
 }  // namespace
 
 TII::TII(unsigned int dabmode, tii_config_t &tii_config, bool fixedPoint)
-    : RemoteControllable("tii"), m_ctx(tii_mode(dabmode)), m_conf(tii_config)
+    : OwnContext(tii_mode(dabmode)), TiiParameters(m_ctx.get(), tii_config)
 {
     if (fixedPoint) throw std::runtime_error("TII: the fixed-point engine is not offloaded");
+}
+
+namespace dabgpu_host {
+TiiParameters::TiiParameters(dabgpu_ctx *dev, tii_config_t &tii_config)
+    : RemoteControllable("tii"), m_dev(dev), m_conf(tii_config)
+{
     RC_ADD_PARAMETER(enable, "enable TII [0-1]");
     RC_ADD_PARAMETER(comb, "TII comb number [0-23]");
     RC_ADD_PARAMETER(pattern, "TII pattern number [0-69]");
@@ -557,11 +608,12 @@ TII::TII(unsigned int dabmode, tii_config_t &tii_config, bool fixedPoint)
     push_settings();
 }
 
-void TII::push_settings()
+void TiiParameters::push_settings()
 {
-    if (dabgpu_set_tii(m_ctx.get(), m_conf.enable, m_conf.comb, m_conf.pattern, m_conf.old_variant) != DABGPU_OK)
-        throw TIIError(dabgpu_last_error(m_ctx.get()));
+    if (dabgpu_set_tii(m_dev, m_conf.enable, m_conf.comb, m_conf.pattern, m_conf.old_variant) != DABGPU_OK)
+        throw TIIError(dabgpu_last_error(m_dev));
 }
+}  // namespace dabgpu_host
 
 const char *TII::name()
 {
@@ -584,7 +636,8 @@ int TII::process(Buffer *dataIn, Buffer *dataOut)
     return 1;
 }
 
-void TII::set_parameter(const std::string &parameter, const std::string &value)
+namespace dabgpu_host {
+void TiiParameters::set_parameter(const std::string &parameter, const std::string &value)
 {
     std::stringstream ss(value);
     ss.exceptions(std::stringstream::failbit | std::stringstream::badbit);
@@ -604,23 +657,23 @@ void TII::set_parameter(const std::string &parameter, const std::string &value)
     } else if (parameter == "old_variant") {
         ss >> m_conf.old_variant;
     } else {
-        dabgpu_host::not_exported(parameter, get_rc_name());
+        not_exported(parameter, get_rc_name());
     }
     push_settings();
 }
 
-const std::string TII::get_parameter(const std::string &parameter) const
+const std::string TiiParameters::get_parameter(const std::string &parameter) const
 {
     std::lock_guard<std::mutex> lock(m_mutex);
     if (parameter == "enable") return m_conf.enable ? "1" : "0";
     if (parameter == "pattern") return std::to_string(m_conf.pattern);
     if (parameter == "comb") return std::to_string(m_conf.comb);
     if (parameter == "old_variant") return m_conf.old_variant ? "1" : "0";
-    dabgpu_host::not_exported(parameter, get_rc_name());
+    not_exported(parameter, get_rc_name());
     return "";
 }
 
-const json::map_t TII::get_all_values() const
+const json::map_t TiiParameters::get_all_values() const
 {
     json::map_t m;
     std::lock_guard<std::mutex> lock(m_mutex);
@@ -630,6 +683,7 @@ const json::map_t TII::get_all_values() const
     m["old_variant"].v = m_conf.old_variant;
     return m;
 }
+}  // namespace dabgpu_host
 
 // ---------------------------------------------------------------- FormatConverter
 namespace {
@@ -667,22 +721,43 @@ int FormatConverter::process(Buffer *const dataIn, Buffer *dataOut)
 }
 
 // ---------------------------------------------------------------- MemlessPoly
-MemlessPoly::MemlessPoly(std::string &coefs_file, unsigned int)
-    : RemoteControllable("memlesspoly"), m_ctx(1), m_coefs_file(coefs_file)
+MemlessPoly::MemlessPoly(std::string &coefs_file, unsigned int) : OwnContext(1), PolyParameters(m_ctx.get(), coefs_file)
+{
+    start_pipeline_thread();
+}
+
+MemlessPoly::~MemlessPoly() { stop_pipeline_thread(); }
+
+int MemlessPoly::internal_process(Buffer *const dataIn, Buffer *dataOut)
+{
+    if (!settings_valid()) {
+        // the reference passes the frame through when no valid settings are loaded
+        *dataOut = *dataIn;
+        return static_cast<int>(dataOut->getLength());
+    }
+    return run_codec(m_ctx, dabgpu_poly_process, dataIn, dataOut, dataIn->getLength());
+}
+
+namespace dabgpu_host {
+PolyParameters::PolyParameters(dabgpu_ctx *dev, std::string &coefs_file)
+    : RemoteControllable("memlesspoly"), m_dev(dev), m_coefs_file(coefs_file)
 {
     RC_ADD_PARAMETER(ncoefs, "(Read-only) number of coefficients.");
     RC_ADD_PARAMETER(coefs, "Predistortion coefficients, same format as file.");
     RC_ADD_PARAMETER(coeffile, "Filename containing coefficients. When set, the file gets loaded.");
     std::ifstream f(m_coefs_file);
     load_coefficients(f);
-    start_pipeline_thread();
 }
 
-MemlessPoly::~MemlessPoly() { stop_pipeline_thread(); }
+bool PolyParameters::settings_valid() const
+{
+    std::lock_guard<std::mutex> lock(m_coefs_mutex);
+    return m_valid;
+}
 
 // coefficient stream: format 1 = "1, 5, 5 AM values, 5 PM values"; format 2 = "2, scalefactor,
 // 32 LUT values" (reference src/MemlessPoly.cpp:145-232)
-void MemlessPoly::load_coefficients(std::istream &in)
+void PolyParameters::load_coefficients(std::istream &in)
 {
     if (!in) throw std::runtime_error("MemlessPoly: Could not open file with coefs!");
     uint32_t fmt = 0;
@@ -700,7 +775,7 @@ void MemlessPoly::load_coefficients(std::istream &in)
             (i < 5 ? am[i] : pm[i - 5]) = a;
             if (in.eof()) throw std::runtime_error("MemlessPoly: coefs file invalid !");
         }
-        m_ctx.check(dabgpu_set_poly(m_ctx.get(), am.data(), pm.data()));
+        check_dev(m_dev, dabgpu_set_poly(m_dev, am.data(), pm.data()));
         std::lock_guard<std::mutex> lock(m_coefs_mutex);
         m_am = am; m_pm = pm; m_is_lut = false; m_valid = true;
     } else if (fmt == 2) {
@@ -708,7 +783,7 @@ void MemlessPoly::load_coefficients(std::istream &in)
         in >> scale;
         std::vector<float> lut(32);
         for (auto &v : lut) in >> v;
-        m_ctx.check(dabgpu_set_lut(m_ctx.get(), scale, lut.data()));
+        check_dev(m_dev, dabgpu_set_lut(m_dev, scale, lut.data()));
         std::lock_guard<std::mutex> lock(m_coefs_mutex);
         m_lut = lut; m_lut_scale = scale; m_is_lut = true; m_valid = true;
     } else {
@@ -717,7 +792,7 @@ void MemlessPoly::load_coefficients(std::istream &in)
     }
 }
 
-std::string MemlessPoly::serialise_coefficients() const
+std::string PolyParameters::serialise_coefficients() const
 {
     std::stringstream ss;
     std::lock_guard<std::mutex> lock(m_coefs_mutex);
@@ -734,22 +809,7 @@ std::string MemlessPoly::serialise_coefficients() const
     return ss.str();
 }
 
-int MemlessPoly::internal_process(Buffer *const dataIn, Buffer *dataOut)
-{
-    bool valid;
-    {
-        std::lock_guard<std::mutex> lock(m_coefs_mutex);
-        valid = m_valid;
-    }
-    if (!valid) {
-        // the reference passes the frame through when no valid settings are loaded
-        *dataOut = *dataIn;
-        return static_cast<int>(dataOut->getLength());
-    }
-    return run_codec(m_ctx, dabgpu_poly_process, dataIn, dataOut, dataIn->getLength());
-}
-
-void MemlessPoly::set_parameter(const std::string &parameter, const std::string &value)
+void PolyParameters::set_parameter(const std::string &parameter, const std::string &value)
 {
     if (parameter == "ncoefs") throw ParameterError("Parameter 'ncoefs' is read-only");
     if (parameter == "coefs") {
@@ -772,11 +832,11 @@ void MemlessPoly::set_parameter(const std::string &parameter, const std::string 
             throw ParameterError(e.what());
         }
     } else {
-        dabgpu_host::not_exported(parameter, get_rc_name());
+        not_exported(parameter, get_rc_name());
     }
 }
 
-const std::string MemlessPoly::get_parameter(const std::string &parameter) const
+const std::string PolyParameters::get_parameter(const std::string &parameter) const
 {
     if (parameter == "ncoefs") {
         std::lock_guard<std::mutex> lock(m_coefs_mutex);
@@ -784,10 +844,10 @@ const std::string MemlessPoly::get_parameter(const std::string &parameter) const
     }
     if (parameter == "coefs") return serialise_coefficients();
     if (parameter == "coeffile") return m_coefs_file;
-    dabgpu_host::not_exported(parameter, get_rc_name());
+    not_exported(parameter, get_rc_name());
 }
 
-const json::map_t MemlessPoly::get_all_values() const
+const json::map_t PolyParameters::get_all_values() const
 {
     json::map_t m;
     {
@@ -798,72 +858,95 @@ const json::map_t MemlessPoly::get_all_values() const
     m["coeffile"].v = m_coefs_file;
     return m;
 }
+}  // namespace dabgpu_host
 
 // ---------------------------------------------------------------- DabGpuChain
-DabGpuChain::DabGpuChain(const Settings &s)
-    : m_ctx(static_cast<int>(s.dabMode), static_cast<int>(std::max<size_t>(1, s.maxBatchFrames)))
+DabGpuChain::DabGpuChain(const Settings &s) : DabGpuChain(s, LiveSettings()) {}
+
+DabGpuChain::~DabGpuChain() = default;
+
+DabGpuChain::DabGpuChain(const Settings &s, const LiveSettings &live)
+    : m_ctx(static_cast<int>(s.dabMode), static_cast<int>(std::max<size_t>(1, s.maxBatchFrames))), m_own(s)
 {
+    using namespace dabgpu_host;
+    dabgpu_ctx *dev = m_ctx.get();
     dabgpu_geometry g;
-    m_ctx.check(dabgpu_get_geometry(m_ctx.get(), &g));
+    m_ctx.check(dabgpu_get_geometry(dev, &g));
     m_in_bytes = g.tf_input_bytes;
     if (s.emulatePipelineDrops > 3) throw std::runtime_error("DabGpuChain: emulatePipelineDrops is 0 ... 3");
     m_drops = s.emulatePipelineDrops;
+    // each RC-mutable value lives in the caller's settings where LiveSettings points there, else in m_own -- the stage
+    // parameter objects hold references, like the reference's stage classes (src/DabModulator.cpp:195-260)
+    GainMode &gainMode = live.gainMode ? *live.gainMode : m_own.gainMode;
+    float &digitalGain = live.digitalGain ? *live.digitalGain : m_own.digitalGain;
+    float &variance = live.gainmodeVariance ? *live.gainmodeVariance : m_own.gainmodeVariance;
+    std::string &tapsFile = live.filterTapsFilename ? *live.filterTapsFilename : m_own.filterTapsFilename;
+    std::string &coefFile = live.polyCoefFilename ? *live.polyCoefFilename : m_own.polyCoefFilename;
+    size_t &overlap = live.ofdmWindowOverlap ? *live.ofdmWindowOverlap : m_own.ofdmWindowOverlap;
+    tii_config_t &tii = live.tiiConfig ? *live.tiiConfig : m_own.tiiConfig;
+    bool &cfr = live.enableCfr ? *live.enableCfr : m_own.enableCfr;
+    float &cfrClip = live.cfrClip ? *live.cfrClip : m_own.cfrClip;
+    float &cfrErrorClip = live.cfrErrorClip ? *live.cfrErrorClip : m_own.cfrErrorClip;
+
+    // the stages, in the reference's order of construction (src/DabModulator.cpp:178-268)
+    if (s.dabMode == 1 || s.dabMode == 2)       // TII::TII throws TIIError in the other modes (src/TII.cpp:144-149): no "tii"
+        m_rc_tii.reset(new TiiParameters(dev, tii));
+    else if (tii.enable)
+        throw TIIError("TII::TII DAB mode " + std::to_string(s.dabMode) + " not valid!");
+    m_rc_ofdm.reset(new OfdmControl(dev, static_cast<size_t>(g.nb_symbols) + 1, cfr, cfrClip, cfrErrorClip));
+    m_rc_ofdm->push_settings();
     if (s.enableGain) {
         m_mask |= DABGPU_STAGE_GAIN;
-        m_ctx.check(dabgpu_set_gain(m_ctx.get(), static_cast<int>(s.gainMode), s.digitalGain, s.normalise,
-                                    s.gainmodeVariance));
+        m_rc_gain.reset(new GainParameters(dev, gainMode, digitalGain, s.normalise, variance));
+        m_rc_gain->push_settings();
     }
-    m_ctx.check(dabgpu_set_window_overlap(m_ctx.get(), s.ofdmWindowOverlap));
-    if (s.enableCfr) m_ctx.check(dabgpu_set_cfr(m_ctx.get(), 1, s.cfrClip, s.cfrErrorClip));
-    if (s.tiiConfig.enable)
-        m_ctx.check(dabgpu_set_tii(m_ctx.get(), 1, s.tiiConfig.comb, s.tiiConfig.pattern, s.tiiConfig.old_variant));
-    if (!s.filterTapsFilename.empty()) {
+    m_rc_guard.reset(new GuardParameters(dev, overlap));
+    if (!tapsFile.empty()) {
         m_mask |= DABGPU_STAGE_FIR;
-        if (s.filterTapsFilename == "default") {
-            m_ctx.check(dabgpu_set_fir_default_taps(m_ctx.get()));
-        } else {
-            std::ifstream f(s.filterTapsFilename);
-            if (!f) throw std::runtime_error("FIRFilter: Could not open taps file " + s.filterTapsFilename);
-            int n = 0;
-            f >> n;
-            if (n <= 0) throw std::runtime_error("FIRFilter: taps file has invalid format.");
-            std::vector<float> taps(n);
-            for (auto &t : taps) f >> t;
-            m_ctx.check(dabgpu_set_fir_taps(m_ctx.get(), taps.data(), taps.size()));
-        }
+        m_rc_fir.reset(new FirParameters(dev, tapsFile));
     }
     if (s.outputFormat != "complexf") {
         const int code = format_code(s.outputFormat);
         if (!code) throw std::runtime_error("FormatConverter: Invalid format " + s.outputFormat);
-        m_ctx.check(dabgpu_set_output_format(m_ctx.get(), code));
+        m_ctx.check(dabgpu_set_output_format(dev, code));
     }
     if (s.outputRate != 2048000) {
         m_mask |= DABGPU_STAGE_RESAMPLE;
-        m_ctx.check(dabgpu_set_resampler(m_ctx.get(), 2048000, s.outputRate));
+        m_ctx.check(dabgpu_set_resampler(dev, 2048000, s.outputRate));
     }
-    if (!s.polyCoefFilename.empty()) {
-        m_mask |= DABGPU_STAGE_POLY;
-        std::ifstream f(s.polyCoefFilename);
-        if (!f) throw std::runtime_error("MemlessPoly: Could not open file with coefs!");
-        uint32_t fmt = 0;
-        f >> fmt;
-        if (fmt == 1) {
-            int n = 0;
-            f >> n;
-            if (n != 5) throw std::runtime_error("MemlessPoly: invalid number of coefs");
-            float am[5], pm[5];
-            for (float &v : am) f >> v;
-            for (float &v : pm) f >> v;
-            m_ctx.check(dabgpu_set_poly(m_ctx.get(), am, pm));
-        } else if (fmt == 2) {
-            float scale = 0, lut[32];
-            f >> scale;
-            for (float &v : lut) f >> v;
-            m_ctx.check(dabgpu_set_lut(m_ctx.get(), scale, lut));
-        } else {
-            throw std::runtime_error("MemlessPoly: coef file has unknown format");
-        }
-    }
+    if (!coefFile.empty()) m_rc_poly.reset(new PolyParameters(dev, coefFile));   // (in the mask while its settings are valid)
+}
+
+std::vector<RemoteControllable *> DabGpuChain::remote_controllables() const
+{
+    std::vector<RemoteControllable *> v;
+    for (RemoteControllable *p : {static_cast<RemoteControllable *>(m_rc_tii.get()),
+                                  static_cast<RemoteControllable *>(m_rc_ofdm.get()),
+                                  static_cast<RemoteControllable *>(m_rc_gain.get()),
+                                  static_cast<RemoteControllable *>(m_rc_guard.get()),
+                                  static_cast<RemoteControllable *>(m_rc_fir.get()),
+                                  static_cast<RemoteControllable *>(m_rc_poly.get())})
+        if (p) v.push_back(p);
+    return v;
+}
+
+unsigned DabGpuChain::stage_mask()
+{
+    // MemlessPoly passes frames through while no valid coefficients are loaded (src/MemlessPoly.cpp:397-409)
+    return m_mask | (m_rc_poly && m_rc_poly->settings_valid() ? static_cast<unsigned>(DABGPU_STAGE_POLY) : 0u);
+}
+
+void DabGpuChain::before_frames()
+{
+    // parameters whose home is a mod_settings_t field the remote control may also reach through another object are
+    // pushed every time (a setter that repeats the current value is free)
+    m_cfr_on = m_rc_ofdm->push_settings();
+    if (m_rc_gain) m_rc_gain->push_settings();
+}
+
+void DabGpuChain::after_frames()
+{
+    if (m_cfr_on) m_rc_ofdm->collect_statistics();
 }
 
 void DabGpuChain::submit(const void *bits, size_t n_frames)
@@ -872,7 +955,8 @@ void DabGpuChain::submit(const void *bits, size_t n_frames)
     // frames back itself, as dabmod_file --batch --reference-latency does -- never silently N frames where N - k were asked)
     if (m_drops)
         throw std::runtime_error("DabGpuChain::submit: Settings::emulatePipelineDrops applies to process() only");
-    m_ctx.check(dabgpu_chain_submit(m_ctx.get(), static_cast<const uint8_t *>(bits), n_frames, m_mask));
+    before_frames();
+    m_ctx.check(dabgpu_chain_submit(m_ctx.get(), static_cast<const uint8_t *>(bits), n_frames, stage_mask()));
 }
 
 size_t DabGpuChain::collect(const void **iq)
@@ -882,13 +966,29 @@ size_t DabGpuChain::collect(const void **iq)
     return n;
 }
 
-size_t DabGpuChain::output_bytes_per_frame() const { return dabgpu_chain_out_bytes_per_frame(m_ctx.get(), m_mask); }
+size_t DabGpuChain::output_bytes_per_frame() const
+{
+    return dabgpu_chain_out_bytes_per_frame(m_ctx.get(), const_cast<DabGpuChain *>(this)->stage_mask());
+}
 
 size_t DabGpuChain::get_num_clipped_samples() const
 {
     size_t n = 0;
     m_ctx.check(dabgpu_get_num_clipped(m_ctx.get(), &n));
     return n;
+}
+
+// The reference's pipelined stages delay the metadata with the frame, one call each (src/ModPlugin.cpp:117-128; a stage
+// behind one that returned 0 is not reached in that round, src/Flowgraph.cpp:334-336): k of them hand the metadata of
+// call i - k to the sink together with frame i - k.  Same here, as one FIFO k deep.
+meta_vec_t DabGpuChain::process_metadata(const meta_vec_t &metadataIn)
+{
+    if (!m_drops) return metadataIn;
+    m_delayed_meta.push_back(metadataIn);
+    if (m_delayed_meta.size() <= m_drops) return {};
+    meta_vec_t r = std::move(m_delayed_meta.front());
+    m_delayed_meta.pop_front();
+    return r;
 }
 
 int DabGpuChain::process(Buffer *const dataIn, Buffer *dataOut)
@@ -908,10 +1008,13 @@ int DabGpuChain::process(Buffer *const dataIn, Buffer *dataOut)
         m_delayed.pop_front();
         in = &oldest;
     }
-    dataOut->setLength(dabgpu_chain_out_bytes_per_frame(m_ctx.get(), m_mask));
+    before_frames();
+    const unsigned mask = stage_mask();
+    dataOut->setLength(dabgpu_chain_out_bytes_per_frame(m_ctx.get(), mask));
     size_t n = 0;
-    m_ctx.check(dabgpu_chain_process(m_ctx.get(), static_cast<const uint8_t *>(in->getData()), 1, m_mask,
+    m_ctx.check(dabgpu_chain_process(m_ctx.get(), static_cast<const uint8_t *>(in->getData()), 1, mask,
                                      dataOut->getData(), dataOut->getLength(), &n));
     dataOut->setLength(n);
+    after_frames();
     return static_cast<int>(n);
 }

@@ -24,6 +24,7 @@
 #include <cstring>
 #include <fstream>
 #include <iostream>
+#include <map>
 #include <memory>
 #include <sstream>
 #include <stdexcept>
@@ -640,6 +641,129 @@ int run_gpu(int argc, char **argv)
     return 0;
 }
 
+// ---- the production plugin's remote-control surface and metadata semantics
+//   host_selftest chainrc <bits file> <nframes> <out.iq> <drops> [NAME,PARAM,VALUE@FRAME]...
+// One DabGpuChain (gain var, "default" FIRFilter taps, predistorter from <dir of out.iq>/poly.coef when that file exists)
+// between a source that attaches the frame number as metadata and a sink that reports what arrives with each frame.
+// Each action is applied through the RemoteControllable of that NAME just before frame FRAME enters the graph.
+class NumberedSource : public ModInput, public ModMetadata {
+public:
+    NumberedSource(std::vector<uint8_t> data, size_t block) : m_data(std::move(data)), m_block(block) {}
+    int process(Buffer *out) override
+    {
+        if (m_pos + m_block > m_data.size()) return 0;
+        out->setData(m_data.data() + m_pos, m_block);
+        m_pos += m_block;
+        return static_cast<int>(m_block);
+    }
+    meta_vec_t process_metadata(const meta_vec_t &) override
+    {
+        flowgraph_metadata md;
+        md.ts.fct = m_next++;
+        return {md};
+    }
+    const char *name() override { return "NumberedSource"; }
+
+private:
+    std::vector<uint8_t> m_data;
+    size_t m_block, m_pos = 0;
+    int32_t m_next = 0;
+};
+
+class ReportingSink : public ModOutput, public ModMetadata {
+public:
+    explicit ReportingSink(const std::string &path) : m_f(path, std::ios::binary) {}
+    int process(Buffer *in) override
+    {
+        m_f.write(static_cast<const char *>(in->getData()), static_cast<std::streamsize>(in->getLength()));
+        return static_cast<int>(in->getLength());
+    }
+    meta_vec_t process_metadata(const meta_vec_t &in) override
+    {
+        std::printf("frame %d carries metadata of", frames++);
+        for (const auto &md : in) std::printf(" %d", static_cast<int>(md.ts.fct));
+        std::printf("\n");
+        return {};
+    }
+    const char *name() override { return "ReportingSink"; }
+    int frames = 0;
+
+private:
+    std::ofstream m_f;
+};
+
+int run_chainrc(int argc, char **argv)
+{
+    if (argc < 6) {
+        std::fprintf(stderr, "usage: host_selftest chainrc <bits file> <nframes> <out.iq> <drops> [NAME,PARAM,VALUE@FRAME]...\n");
+        return 2;
+    }
+    const std::vector<uint8_t> bits = read_all(argv[2]);
+    const size_t nframes = std::strtoul(argv[3], nullptr, 10);
+    const std::string out = argv[4];
+    DabGpuChain::Settings s;
+    s.dabMode = 1;
+    s.normalise = 1.0f / 50000.0f;
+    s.filterTapsFilename = "default";
+    s.emulatePipelineDrops = static_cast<unsigned>(std::strtoul(argv[5], nullptr, 10));
+    const std::string coef = out.substr(0, out.find_last_of('/') + 1) + "poly.coef";
+    if (std::ifstream(coef)) s.polyCoefFilename = coef;
+    // the RC-mutable values live OUTSIDE the plugin, as mod_settings_t does in the reference
+    GainMode gainMode = GainMode::GAIN_VAR;
+    float digital = 1.0f;
+    std::string taps = "default";
+    DabGpuChain::LiveSettings live;
+    live.gainMode = &gainMode;
+    live.digitalGain = &digital;
+    live.filterTapsFilename = &taps;
+    auto chain = std::make_shared<DabGpuChain>(s, live);
+    std::map<std::string, RemoteControllable *> rcs;
+    for (RemoteControllable *c : chain->remote_controllables()) rcs[c->get_rc_name()] = c;
+    std::string names;
+    for (const auto &kv : rcs) names += kv.first + " ";
+    std::printf("controllables: %s\n", names.c_str());
+    struct Action { size_t at; std::string name, param, value; };
+    std::vector<Action> actions;
+    for (int i = 6; i < argc; ++i) {
+        const std::string a = argv[i];
+        const size_t at = a.find_last_of('@'), c1 = a.find(','), c2 = a.find(',', c1 + 1);
+        if (at == std::string::npos || c1 == std::string::npos || c2 == std::string::npos) throw std::runtime_error("bad action " + a);
+        std::string value = a.substr(c2 + 1, at - c2 - 1);
+        if (!value.empty() && value[0] == '<') value = slurp(value.substr(1));         // "<file": the value is the file's text
+        actions.push_back({std::strtoul(a.c_str() + at + 1, nullptr, 10), a.substr(0, c1), a.substr(c1 + 1, c2 - c1 - 1), value});
+    }
+    auto source = std::make_shared<NumberedSource>(bits, chain->input_bytes_per_frame());
+    auto sink = std::make_shared<ReportingSink>(out);
+    Flowgraph fg;
+    fg.connect(source, chain);
+    fg.connect(chain, sink);
+    for (size_t i = 0; i < nframes; ++i) {
+        for (const auto &a : actions)
+            if (a.at == i) {
+                auto it = rcs.find(a.name);
+                if (it == rcs.end()) throw std::runtime_error("no controllable " + a.name);
+                it->second->set_parameter(a.param, a.value);
+            }
+        fg.run();
+    }
+    for (const auto &a : actions) {
+        std::string v = rcs[a.name]->get_parameter(a.param);
+        for (auto &c : v) if (c == '\n') c = ' ';
+        std::printf("rc %s %s = %s\n", a.name.c_str(), a.param.c_str(), v.c_str());
+    }
+    std::printf("settings now: digital=%g mode=%d taps=%s\n", digital, static_cast<int>(gainMode), taps.c_str());
+    // error conventions of the reference's controllables
+    bool threw = false;
+    try { rcs["gain"]->set_parameter("nonsense", "1"); } catch (const ParameterError &) { threw = true; }
+    CHECK(threw);
+    threw = false;
+    try { rcs["firfilter"]->set_parameter("ntaps", "3"); } catch (const ParameterError &) { threw = true; }
+    CHECK(threw);
+    CHECK(rcs.count("ofdm") && rcs.count("guardinterval") && rcs.count("tii"));
+    std::printf("chainrc: %d frames written\n", sink->frames);
+    return 0;
+}
+
 }  // namespace
 
 int main(int argc, char **argv)
@@ -649,6 +773,7 @@ int main(int argc, char **argv)
         if (argc >= 2 && std::string(argv[1]) == "gpu") return run_gpu(argc, argv);
         if (argc >= 2 && std::string(argv[1]) == "cfg4") return run_cfg4(argc, argv);
         if (argc >= 2 && std::string(argv[1]) == "memlesspoly") return run_memlesspoly(argc, argv);
+        if (argc >= 2 && std::string(argv[1]) == "chainrc") return run_chainrc(argc, argv);
         std::fprintf(stderr, "usage: host_selftest cpu | gpu ...\n");
         return 2;
     } catch (const std::exception &e) {

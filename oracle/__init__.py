@@ -30,7 +30,8 @@ def build(with_ref=None):
         # the reference's unmodified DabModulator.cpp linked with the MI355X drop-ins (needs libdabgpu.so: built first
         # by __graft_entry__.build()); a test binary for the GPU box, see dropin_harness.cpp
         if os.path.exists(os.path.join(_DIR, "..", "odr-dabmod_amd", "csrc", "libdabgpu.so")):
-            subprocess.check_call(["make", "-s", "-C", _DIR, "-j4", "dropin"])
+            # ... and `fused`: the same graph builder after install_fused.sh's scripted edit
+            subprocess.check_call(["make", "-s", "-C", _DIR, "-j4", "dropin", "fused"])
 
 
 class _Mode(C.Structure):
