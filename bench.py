@@ -157,6 +157,75 @@ def cpu_baseline(workload, seconds_budget=16.0):
                          O.fft_engine())}
 
 
+def host_tools(device_index=0, budget_s=45.0):
+    """The DELIVERABLE's own throughput (north_star: "stages drop into DabModulator.cpp") -- ETI file in,
+    IQ out to /dev/null, PCIe both ways inside the timed region -- of the four host programs, where they have been built:
+      cfg1_end_to_end            odr-dabmod_amd/host/dabmod_file (this repository's front-end + DabGpuChain): BASELINE config 1,
+                                 frame by frame (DabGpuChain::process) and --batch 32 (submit / collect), complexf and u8;
+      fused_in_reference_graph   oracle/_ref/dabmod_fused: the reference's own DabModulator.cpp / Flowgraph.cpp / front end
+                                 with ONE DabGpuChain node (INTEGRATION.md A), config 1 and config 3;
+      dropin_per_stage           oracle/_ref/dabmod_dropin: the reference's UNMODIFIED graph builder on the per-stage
+                                 drop-ins (PCIe both ways per stage), config 3.
+    Rates exclude process start-up: every case runs the same 2000-frame ETI file with --loop 1 and --loop L and reports
+    (L - 1) x 500 transmission frames over the difference of the two wall times.  The comparable CPU figure is
+    cpu_baseline.one_stream_reference_threading (one stream of the port in the reference's threading model, hot path
+    only).  A program that is not there (oracle/_ref exists only where the reference tree was at hand) is skipped."""
+    import subprocess
+    import tempfile
+    from tests.golden.synth import synth_eti
+    host = os.path.join(ROOT, "odr-dabmod_amd", "host")
+    ref = os.path.join(ROOT, "oracle", "_ref")
+    norm = repr(1.0 / 50000.0)
+    cases = [
+        ("cfg1_end_to_end", "frame_by_frame_complexf", os.path.join(host, "dabmod_file"), []),
+        ("cfg1_end_to_end", "batch32_complexf", os.path.join(host, "dabmod_file"), ["--batch", "32"]),
+        ("cfg1_end_to_end", "frame_by_frame_u8", os.path.join(host, "dabmod_file"), ["--format", "u8"]),
+        ("cfg1_end_to_end", "batch32_u8", os.path.join(host, "dabmod_file"), ["--format", "u8", "--batch", "32"]),
+        ("cfg1_end_to_end", "front_end_alone_no_gpu", os.path.join(host, "dabmod_file"), ["--bits-only"]),
+        ("fused_in_reference_graph", "cfg1_complexf", os.path.join(ref, "dabmod_fused"), []),
+        ("fused_in_reference_graph", "cfg3_complexf", os.path.join(ref, "dabmod_fused"), ["--fir", "default", "--normalise", norm]),
+        ("fused_in_reference_graph", "cfg3_s16", os.path.join(ref, "dabmod_fused"),
+         ["--fir", "default", "--normalise", "1.0", "--format", "s16"]),
+        ("dropin_per_stage", "cfg3_complexf", os.path.join(ref, "dabmod_dropin"), ["--fir", "default", "--normalise", norm]),
+    ]
+    out = {"timing": "(L - 1) x 500 transmission frames / (wall(--loop L) - wall(--loop 1)); output to /dev/null; one process, "
+                     "one context, the GPU this bench runs on", "unit": "transmission frames/s"}
+    env = dict(os.environ, DABGPU_DEVICE=str(device_index))
+    t_start = time.perf_counter()
+    with tempfile.TemporaryDirectory() as tmp:
+        fin = os.path.join(tmp, "in.eti")
+        synth_eti(2000).tofile(fin)              # a multiple of 1000 frames: looping keeps FCT / FP aligned (SURVEY 8(d))
+
+        def wall(tool, opts, loops):
+            t0 = time.perf_counter()
+            r = subprocess.run([tool, fin, "/dev/null"] + opts + ["--loop", str(loops)], env=env, capture_output=True,
+                               text=True, timeout=120)
+            if r.returncode != 0:
+                raise RuntimeError((r.stderr or r.stdout)[-160:])
+            return time.perf_counter() - t0
+
+        for group, name, tool, opts in cases:
+            grp = out.setdefault(group, {})
+            if not os.path.exists(tool):
+                grp[name] = {"skipped": os.path.relpath(tool, ROOT) + " is not built here"}
+                continue
+            if time.perf_counter() - t_start > budget_s:
+                grp[name] = {"skipped": "time budget of this leg spent"}
+                continue
+            try:
+                wall(tool, opts, 1)                              # (page the binary and the libraries in)
+                t1 = wall(tool, opts, 1)
+                t3 = wall(tool, opts, 3)
+                per_loop = max((t3 - t1) / 2, 1e-3)
+                L = int(max(3, min(40, 1 + 2.5 / per_loop)))
+                tl = wall(tool, opts, L) if L > 3 else t3
+                grp[name] = {"frames_per_s": round((L - 1) * 500 / max(tl - t1, 1e-6), 1), "loops": L,
+                             "startup_s": round(t1 - per_loop, 2), "options": " ".join(opts)}
+            except Exception as ex:
+                grp[name] = {"error": str(ex)[:200]}
+    return out
+
+
 def free_port():
     import socket
     sk = socket.socket()
@@ -493,7 +562,31 @@ def main():
                 "achieved_GBps": round(algo_b * fps / 1e9, 2), "roofline_frac": round(algo_b * fps / 1e9 / HBM_PEAK_GBPS, 4),
                 "frame_ms_of_air_time": {2: 24, 3: 24, 4: 48}[mode], "kernel": "generic tf_kernel<logn=%d>" % {2: 9, 3: 8, 4: 10}[mode]}
 
-    B = args.frames
+    # The batch every rank can hold.  32768 frames are 52.5 GB of input + output per GPU: a rank that cannot get them
+    # (another tenant on the GPU, a smaller part) halves its batch until the buffers fit, the ranks agree on the SMALLEST
+    # such batch (weak scaling: the same work on every GPU), and the line says so -- rather than one rank dying of
+    # hipErrorOutOfMemory and taking the job with it.
+    def frames_that_fit(b):
+        per_frame = 28800 + (4 if args.workload == "cfg4" else 1) * 196608 * 8 + \
+            (77 * 1536 * 8 if args.workload in ("cfg2", "ifft_fir_stage") else 0) + \
+            (196608 * 8 if args.workload == "cfg4" else 0)                       # (cfg 4: the native-rate scratch)
+        while b > 64:
+            try:
+                probe = torch.empty(int(b * per_frame * 1.02) + (256 << 20), dtype=torch.uint8, device=dev)
+                del probe
+                break
+            except RuntimeError:                   # torch.cuda.OutOfMemoryError is a RuntimeError
+                b //= 2
+            finally:
+                torch.cuda.empty_cache()
+        return grp.min_over_ranks(b)
+
+    B = frames_that_fit(args.frames)
+    frames_note = None
+    if B != args.frames:
+        frames_note = "--frames %d did not fit this GPU's free memory on every rank: %d frames per step per GPU" % (args.frames, B)
+        if rank == 0:
+            print("bench.py: " + frames_note, file=sys.stderr)
     gather_info = {}
     wall, kern_ms = run_workload(args.workload, B, args.steps, args.warmup,
                                  power_seconds=3.0 if (os.environ.get("WORLD_SIZE") is None and not args.no_extra) else 0.0)
@@ -662,7 +755,7 @@ def main():
                                 "cfg4": "Mode I cfg3 + Resampler 2.048->8.192 Msps + MemlessPoly "
                                         "(BASELINE config 4)"}[args.workload],
                    "frames_per_step_per_gpu": B, "mode": 1, "prewarm_steps": PREWARM, "parallelism": "%d independent streams" % world,
-                   "realtime_multiple": round(value / 10.4167, 1),
+                   "realtime_multiple": round(value / 10.4167, 1), **({"frames_note": frames_note} if frames_note else {}),
                    "residency": "input and output device-resident (no PCIe in the timed region); the host entry points "
                                 "are PCIe-bound, see DESIGN.md section 6"},
         # "bound": the roofline the fraction is priced against (HBM).  "limiter": what the counters say
@@ -760,6 +853,10 @@ def main():
                         extra["cfg3_mode%d" % mode] = other_mode(mode, min(B, 16384) * (2 if mode == 4 else 4), max(3, args.steps // 4))
                     except Exception as ex:
                         extra["cfg3_mode%d" % mode] = {"error": str(ex)[:200]}
+            try:
+                extra["host_tools"] = host_tools(device_index)
+            except Exception as ex:
+                extra["host_tools"] = {"error": str(ex)[:200]}
             line["other_workloads"] = extra
         if not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(args.workload)

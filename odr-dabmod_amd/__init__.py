@@ -515,6 +515,23 @@ class Modulator:
                      d_out.numel() * d_out.element_size(), C.byref(ob), None))
         return ob.value
 
+    def post_process_dev_queued(self, d_native, stages, d_out):
+        """dabgpu_post_process_dev on the context's OWN stream (stream argument NULL), returning at once: ordered behind every
+        chain call queued on the context before it, whichever lane that call went to."""
+        ob = C.c_size_t()
+        self._chk(self._lib.dabgpu_post_process_dev(self._h, d_native.data_ptr(), d_native.numel(), stages,
+                                                    d_out.data_ptr(), d_out.numel() * d_out.element_size(), C.byref(ob), None))
+        return ob.value
+
+    def format_convert_dev_queued(self, d_in, fmt, d_out):
+        """dabgpu_format_process_dev on the context's OWN stream, returning at once (same ordering as above)."""
+        code = FORMATS.get(fmt, (0, None))[0]
+        n = d_in.numel() * (2 if d_in.is_complex() else 1)
+        ob = C.c_size_t()
+        self._chk(self._lib.dabgpu_format_process_dev(self._h, d_in.data_ptr(), n, code, d_out.data_ptr(),
+                                                      d_out.numel() * d_out.element_size(), C.byref(ob), None, None))
+        return ob.value
+
     def post_process_dev(self, d_native, stages, d_out, stream=None):
         """cifRes -> cifPoly on a native-rate stream in device memory (stages: STAGE_RESAMPLE and / or STAGE_POLY)."""
         s = self._stream_handle(d_native, stream)

@@ -61,6 +61,15 @@ class StreamGroup:
         self._dist.all_reduce(t, op=self._dist.ReduceOp.MAX)
         return float(t.item())
 
+    def min_over_ranks(self, value):
+        """The smallest of the ranks' integers (the batch every rank can hold: weak scaling keeps per-GPU work equal)."""
+        if not self._collective:
+            return int(value)
+        dev = "cuda:%d" % self.device_index if self.backend == "nccl" else "cpu"
+        t = self._torch.tensor([int(value)], dtype=self._torch.int64, device=dev)
+        self._dist.all_reduce(t, op=self._dist.ReduceOp.MIN)
+        return int(t.item())
+
     def stream_seed(self, base=42):
         """Every rank modulates a different stream (different synthetic input)."""
         return base + self.rank

@@ -15,7 +15,7 @@
  *
  *   dabmod_dropin in.eti out.iq [--fir default|FILE] [--rate HZ] [--poly FILE] [--gainmode fix|max|var] [--normalise X]
  *                               [--window N] [--format s16|u8|s8] [--engine fftw|kiss] [--mode 1..4] [--digital X] [--var X]
- *                               [--tii COMB,PATTERN] [--cfr CLIP,ERRORCLIP]
+ *                               [--tii COMB,PATTERN] [--cfr CLIP,ERRORCLIP] [--loop N]
  *                               [--rc N,NAME,PARAM,VALUE]...  [--show-metadata 1] [--reference-latency 1]
  *
  * The same main() built with -DDABGPU_FUSED_BUILD over the tree install_fused.sh has edited is oracle/_ref/dabmod_fused
@@ -87,6 +87,7 @@ int main(int argc, char **argv)
     std::string format;
     std::vector<RcAction> rc_actions;
     bool show_metadata = false;
+    int loops = 1;
     for (int i = 3; i + 1 < argc; i += 2) {
         const std::string k = argv[i], v = argv[i + 1];
         if (k == "--fir") s.filterTapsFilename = v;
@@ -101,6 +102,7 @@ int main(int argc, char **argv)
         else if (k == "--var") s.gainmodeVariance = strtof(v.c_str(), nullptr);
         else if (k == "--mode") s.dabMode = strtoul(v.c_str(), nullptr, 10);
         else if (k == "--show-metadata") show_metadata = v != "0";
+        else if (k == "--loop") loops = atoi(v.c_str());        // the file again and again (src/DabMod.cpp:695-706, `loop`)
         else if (k == "--tii") { s.tiiConfig.enable = true; sscanf(v.c_str(), "%d,%d", &s.tiiConfig.comb, &s.tiiConfig.pattern); }
         else if (k == "--cfr") { s.enableCfr = true; sscanf(v.c_str(), "%f,%f", &s.cfrClip, &s.cfrErrorClip); }
 #ifdef DABGPU_FUSED_BUILD
@@ -137,9 +139,12 @@ int main(int argc, char **argv)
         data.setLength(6144);
         int last_fct = -1;
         unsigned long frames = 0;
-        for (;;) {
+        for (int pass = 0;;) {
             const int framesize = reader.GetNextFrame(data.getData());
-            if (framesize <= 0) break;
+            if (framesize <= 0) {
+                if (++pass >= loops || reader.Open(s.inputName, false) != 0) break;
+                continue;
+            }
             if ((size_t)eti.loadEtiData(data) != data.getLength()) throw std::runtime_error("ETI read error");
             if (last_fct == -1 && eti.getFp() != 0) continue;              // :684-693
             last_fct = (int)eti.getFct();

@@ -27,15 +27,37 @@ def pkg():
     return load_pkg()
 
 
-def record_bound(name, measured, limit):
+# Integer outputs of the fused chain (FormatConverter inside the last kernel) against the reference's: truncations of two
+# float streams that agree to rel-RMS 2.4e-7 (bar 1e-6).  They are NEVER more than one step apart, and they differ exactly
+# where an integer lies between the two floats: a share of the components equal to the mean absolute difference in steps,
+# about 0.8 x 2.4e-7 x the RMS of the output in steps -- 1.2e-4 at 600 steps RMS (profiles/r05_dispatch_matrix.txt), 2e-3
+# for a file output at normalise 1.0 (10 000 steps RMS).  The limit is 2.5 x that expectation plus a floor for short
+# outputs; a kernel that gets 1 % of the samples wrong by a step fails at every amplitude a test uses.
+def int_off_by_one_limit(want):
+    import numpy as np
+    rms = float(np.sqrt(np.mean(np.asarray(want, dtype=np.float64) ** 2)))
+    return 5e-7 * rms + 2e-5
+
+
+def record_bound(name, measured, limit, warn_at=None):
     """Log a measured worst case next to the bound it is held to (gpurun_out/measured_bounds.jsonl, one JSON
-    object per line; copied to profiles/ when a bound is (re)derived from it) and return measured <= limit."""
+    object per line; copied to profiles/ when a bound is (re)derived from it) and return measured <= limit.
+    warn_at: a tighter, warning-level bound -- a measured value beyond it still passes but is reported
+    (warnings.warn -> pytest's warnings summary, and "warned" in the log), so that a drift towards `limit` is seen
+    before it is reached."""
     import json
+    import warnings
+    warned = warn_at is not None and float(measured) > float(warn_at)
     try:
         d = os.path.join(ROOT, "gpurun_out")
         os.makedirs(d, exist_ok=True)
+        rec = {"name": name, "measured": float(measured), "limit": float(limit)}
+        if warn_at is not None:
+            rec.update(warn_at=float(warn_at), warned=bool(warned))
         with open(os.path.join(d, "measured_bounds.jsonl"), "a") as f:
-            f.write(json.dumps({"name": name, "measured": float(measured), "limit": float(limit)}) + "\n")
+            f.write(json.dumps(rec) + "\n")
     except OSError:
         pass
+    if warned and float(measured) <= float(limit):
+        warnings.warn("%s: measured %.3g is beyond the warning level %.3g (limit %.3g)" % (name, measured, warn_at, limit))
     return float(measured) <= float(limit)

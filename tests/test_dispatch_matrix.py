@@ -17,7 +17,7 @@ import numpy as np
 import pytest
 
 import oracle as O
-from tests.conftest import ROOT
+from tests.conftest import int_off_by_one_limit, ROOT, record_bound
 from tests.golden.synth import synth_bits
 
 pytestmark = pytest.mark.gpu
@@ -207,7 +207,10 @@ def test_dispatch_cell(pkg, mods, cell):
         wantq, _ = O.format_convert(ref, fmt)
         d = np.abs(y.reshape(-1).astype(np.int32) - wantq.reshape(-1).astype(np.int32))
         err = float((d != 0).mean())
-        ok = d.max() <= 1 and err < 2e-2                    # the integers of two fp32 chains: at most one step apart, rarely
+        # the integers of two fp32 chains: at most one step apart, and as rarely as tests/conftest.py::int_off_by_one_limit says
+        ok = d.max() <= 1 and record_bound("dispatch matrix: integer components one step from the reference's, %s" %
+                                           "mode %d %s %s ov %d cfr %d tii %d %s" % (mode, gain, fir, overlap, cfr, tii_on, fmt),
+                                           err, int_off_by_one_limit(wantq))
         shown = "%.1e of the components one step off" % err
     _rows.append("%d %-4s %-5s %3d %d %d %-4s | %s | %s" % (mode, gain, fir, overlap, cfr, tii_on, fmt or "cf32", shown, "; ".join(got)))
     assert got == want, "kernels launched %s, the rule book says %s" % (got, want)

@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from tests.conftest import ROOT
+from tests.conftest import ROOT, int_off_by_one_limit
 
 HOST = os.path.join(ROOT, "odr-dabmod_amd", "host")
 BIN = os.path.join(HOST, "host_selftest")
@@ -227,9 +227,9 @@ def test_fused_plugin_inside_the_reference_graph_builder(tmp_path, cfg):
         assert np.array_equal(lat, got[:lat.size])
         for other in (want.reshape(-1), ):
             d = np.abs(got.astype(np.int32) - other.astype(np.int32))
-            assert d.max() <= 1 and (d != 0).mean() < 1e-3
+            assert d.max() <= 1 and (d != 0).mean() < int_off_by_one_limit(want)
         d = np.abs(got[:per_stage.size].astype(np.int32) - per_stage.astype(np.int32))
-        assert d.max() <= 1 and (d != 0).mean() < 1e-3
+        assert d.max() <= 1 and (d != 0).mean() < int_off_by_one_limit(want)
 
 
 @pytest.mark.gpu
@@ -238,7 +238,7 @@ def test_fused_plugin_remote_control_through_the_reference_registry(tmp_path):
     """rcs.set_param("gain", "digital", ...) etc. -- the reference's own RemoteControllers (lib/RemoteControl.cpp) on
     the controllables DabGpuChain enrolled -- between two transmission frames: the frames before the change are byte
     for byte those of a run that never changed anything, the frames from the change on byte for byte those of a run
-    STARTED with the new values (a fresh context).  gain digital / mode / var, firfilter tapsfile, memlesspoly coefs and
+    STARTED with the new values (a fresh context; with the Resampler in the chain, from the third output hop on).  gain digital / mode / var, firfilter tapsfile, memlesspoly coefs and
     coeffile, guardinterval windowlen, ofdm cfr / clip / errorclip, tii enable / comb / pattern."""
     import oracle as O
     fin, bits = _eti(tmp_path, 40)
@@ -284,7 +284,15 @@ def test_fused_plugin_remote_control_through_the_reference_registry(tmp_path):
         k = at // 4
         assert np.array_equal(changed[:k * per], old[:k * per]), name
         assert not np.array_equal(old[k * per:], new[k * per:]), name            # (the change is a change)
-        assert np.array_equal(changed[k * per:], new[k * per:]), name
+        # The Resampler carries two hops of its INPUT from frame to frame (src/Resampler.cpp:142-192: prevIn and the overlap
+        # tail), here as in the reference: the first two output hops of the first frame after the change still see the old
+        # stream.  Everything behind them is the fresh run's, byte for byte.
+        skip = 3 * 8192 * 8 if "--rate" in opts0 else 0
+        assert np.array_equal(changed[k * per + skip:], new[k * per + skip:]), name
+        if skip:
+            a = changed[k * per:k * per + skip].view(np.complex64)
+            b = new[k * per:k * per + skip].view(np.complex64)
+            assert np.array_equal(a[2 * 8192:], b[2 * 8192:]), name
 
 
 @pytest.mark.gpu

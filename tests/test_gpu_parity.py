@@ -432,6 +432,7 @@ def _split_gain_scalar(y, ref, mode, bits=None, gain_mode=None, normalise=1.0, h
 
 
 VAR_TOTAL_LIMIT = 8e-7   # chains with GainControl in mode var: total max-abs / |out|_inf against the reference (measured <= 6.3e-7)
+VAR_TOTAL_WARN = 7e-7    # ... and the warning level: beyond it the test still passes but says so (a drift towards the limit is seen)
 
 
 def _hold_gain_bars(tag, y, ref, mode, bits, gain_mode, normalise, residual_limit, total_limit, head=0, tail=0):
@@ -455,7 +456,8 @@ def _hold_gain_bars(tag, y, ref, mode, bits, gain_mode, normalise, residual_limi
     # reference": exact variance here, an fp32 recurrence up to 6e-7 away from it there) -- and is held to that scalar's own
     # reference-relative bar, VAR_TOTAL_LIMIT.  No limit in this file changes without a line in that section.
     ok &= record_bound("chain total max-abs / |out|_inf against the reference (gain mode %s), " % gain_mode + tag,
-                       np.abs(y - ref).max() / np.abs(ref).max(), VAR_TOTAL_LIMIT if gain_mode == 2 else total_limit)
+                       np.abs(y - ref).max() / np.abs(ref).max(), VAR_TOTAL_LIMIT if gain_mode == 2 else total_limit,
+                       warn_at=VAR_TOTAL_WARN if gain_mode == 2 else None)
     return ok
 
 
@@ -720,7 +722,7 @@ def test_chain_windowed_guard_with_fir_narrow_overlaps_run_the_equalised_kernel(
             assert rel_rms(y[f][seam], ref[f][seam]) < REL_RMS                   # (the seams on their own, not diluted by the interiors)
             assert rel_rms(y[f], y2[f].astype(np.complex128)) < 3e-7
         assert record_bound("chain total max-abs / |out|_inf on the seam outputs of the equalised windowed kernel (gain mode 2), " + tag,
-                            np.abs(y[:, seam] - ref[:, seam]).max() / np.abs(ref).max(), VAR_TOTAL_LIMIT)
+                            np.abs(y[:, seam] - ref[:, seam]).max() / np.abs(ref).max(), VAR_TOTAL_LIMIT, warn_at=VAR_TOTAL_WARN)
 
 
 def test_chain_windowed_guard_with_a_short_and_a_long_filter(pkg):

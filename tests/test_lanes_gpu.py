@@ -500,3 +500,146 @@ def test_three_threads_three_contexts_each_on_its_own_lanes(pkg):
         for o in outs:
             for f in range(B):
                 assert rel_rms(o[f], refs[k][f]) < 1e-6, (k, f)
+
+
+# ---- advisor findings of round 5: ordering and shared state between the lanes --------------------------------------------
+def test_null_stream_tail_calls_are_ordered_behind_the_lanes(pkg):
+    """C-ABI callers (no Python wrapper that synchronises in between): chain_process_dev(GAIN | FIR -> native, NULL) rotates
+    over the lanes, post_process_dev(native, NULL) / format_process_dev(native, NULL) run on the context's own stream --
+    they must start after the chain call that produced `native`, whichever lane it went to, and a later chain call that
+    reuses the buffer must start after them.  Same bytes as one lane."""
+    import torch
+    B, R = 16, 9
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=5100 + i) for i in range(R * B)]).reshape(R, B, per)
+    d_bits = torch.from_numpy(bits).cuda()
+
+    def run(lanes):
+        md = pkg.Modulator(mode=1, max_frames=B)
+        try:
+            md.set_lanes(lanes)
+            md.set_gain(pkg.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_resampler(2048000, 8192000)
+            md.set_poly(POLY_AM, POLY_PM)
+            native = torch.zeros((B, 196608), dtype=torch.complex64, device="cuda")       # ONE buffer, reused by every round
+            outs = [torch.zeros((B, 4 * 196608), dtype=torch.complex64, device="cuda") for _ in range(R)]
+            ints = [torch.zeros((B, 2 * 196608), dtype=torch.int16, device="cuda") for _ in range(R)]
+            torch.cuda.synchronize()
+            for i in range(R):
+                md.chain_dev_queued(d_bits[i], B, pkg.STAGE_GAIN | pkg.STAGE_FIR, native)
+                md.post_process_dev_queued(native, pkg.STAGE_RESAMPLE | pkg.STAGE_POLY, outs[i])
+                md.format_convert_dev_queued(native, "s16", ints[i])
+            md.synchronize()
+            return [o.clone() for o in outs], [o.clone() for o in ints]
+        finally:
+            md.close()
+    want_o, want_i = run(1)
+    got_o, got_i = run(3)
+    for i in range(R):
+        assert bool((_u32(want_o[i]) == _u32(got_o[i])).all()), i
+        assert bool((want_i[i] == got_i[i]).all()), i
+    # ... and the one-lane result is the oracle's
+    ref = O.Chain(mode=1, stages=O.STAGE_GAIN | O.STAGE_FIR | O.STAGE_RESAMPLE | O.STAGE_POLY, normalise=1.0 / 50000.0,
+                  out_rate=8192000, am=POLY_AM, pm=POLY_PM).process(bits[0][:2])
+    y = want_o[0][:2].cpu().numpy()
+    for f in range(2):
+        assert rel_rms(y[f], ref[f]) < 1e-6
+
+
+def test_tii_settings_toggled_while_batches_are_in_flight(pkg):
+    """The TII segment (d_acp / d_tii_car / d_tii_frame) is ONE set of buffers shared by the lanes; a new comb / pattern
+    rebuilds it.  While a thread toggles the pattern, every TII-carrying frame must be the frame of ONE of the two
+    patterns -- never a torn segment."""
+    import threading
+    import torch
+    md = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+        per = md.geometry["tf_input_bytes"]
+        bits = np.stack([synth_bits(per, seed=5200), synth_bits(per, seed=5201)])
+        cands = [O.Chain(mode=1, stages=3, gain_mode=2, normalise=1.0 / 50000.0, tii=(3, p, False)).process(bits) for p in (5, 44)]
+        assert rel_rms(cands[0][0], cands[1][0]) > 1e-3          # (the two patterns differ in the TII frame)
+        ns = md.out_samples_per_frame(3)
+        d_bits = torch.from_numpy(bits).cuda()
+        outs = [torch.zeros((2, ns), dtype=torch.complex64, device="cuda") for _ in range(6)]
+        md.set_tii(True, 3, 5)
+        stop = threading.Event()
+
+        def rc_thread():
+            i = 0
+            while not stop.is_set():
+                md.set_tii(True, 3, 44 if i & 1 else 5)
+                i += 1
+
+        t = threading.Thread(target=rc_thread)
+        t.start()
+        seen = set()
+        try:
+            for _ in range(40):
+                for o in outs:
+                    md.chain_dev_queued(d_bits, 2, 3, o)          # two frames per call: the TII parity is the same for every call
+                md.synchronize()
+                for o in outs:
+                    y = o.cpu().numpy()
+                    errs = [rel_rms(y[0], c[0]) for c in cands]
+                    assert min(errs) < 2e-6, errs
+                    seen.add(int(np.argmin(errs)))
+                    assert rel_rms(y[1], cands[0][1]) < 2e-6      # (the frame without TII)
+        finally:
+            stop.set()
+            t.join()
+        assert seen == {0, 1}
+    finally:
+        md.close()
+
+
+def test_zero_length_resampler_call_leaves_the_stream_state_alone(pkg):
+    """Resampler::process on an empty buffer (src/Resampler.cpp:131-140: nothing in, nothing out): the halo of the next
+    call is still the one of the call before."""
+    rng = np.random.RandomState(53)
+    x = (rng.randn(3, 8 * 2048) + 1j * rng.randn(3, 8 * 2048)).astype(np.complex64) * np.float32(0.1)
+    def run(with_empty):
+        md = pkg.Modulator(mode=1, max_frames=1)
+        try:
+            md.set_resampler(2048000, 8192000)
+            ys = []
+            for i in range(3):
+                ys.append(md.resample(x[i]).copy())
+                if with_empty:
+                    assert md.resample(np.zeros(0, np.complex64)).size == 0
+            return np.concatenate(ys)
+        finally:
+            md.close()
+    assert np.array_equal(run(False).view(np.uint32), run(True).view(np.uint32))
+
+
+def test_cfr_statistics_are_those_of_the_most_recent_call_whichever_lane(pkg):
+    """dabgpu_get_cfr_stats after the OfdmGenerator stage wrapper (lane 0) that follows chain calls on lanes 1 and 2: the
+    wrapper's statistics, not the stale lane's."""
+    import torch
+    per = O.tf_input_bytes(1)
+    bits = np.stack([synth_bits(per, seed=5400 + i) for i in range(2)])
+    rng = np.random.RandomState(54)
+    car = np.exp(1j * (np.pi / 4) * (2 * rng.randint(0, 4, size=(77, 1536)) + 1)).astype(np.complex64)
+    car[0] = 0
+    def stats(after_chain_calls):
+        md = pkg.Modulator(mode=1, max_frames=2)
+        try:
+            md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0)
+            md.set_cfr(True, 45.0, 0.15)
+            if after_chain_calls:
+                d_bits = torch.from_numpy(bits).cuda()
+                out = [torch.zeros((2, 196608), dtype=torch.complex64, device="cuda") for _ in range(2)]
+                md.chain_dev_queued(d_bits, 2, 3, out[0])     # lane 0
+                md.chain_dev_queued(d_bits, 2, 3, out[1])     # lane 1: the most recent chain call
+                md.synchronize()
+            md.ofdm(car)
+            return md.cfr_stats(0)
+        finally:
+            md.close()
+    a, b = stats(False), stats(True)
+    assert a["num_clip"] > 0 and a["num_clip"] == b["num_clip"] and a["num_error_clip"] == b["num_error_clip"]
+    assert np.array_equal(a["papr_before"], b["papr_before"]) and np.array_equal(a["papr_after"], b["papr_after"])
+    # (the MER symbol rotates with the frames a context has seen, src/OfdmGenerator.cpp:198,250: another symbol of the same
+    # frame after four chain frames -- the same power to a few ulps, not the same sum)
+    assert abs(a["mer_sum_iq"] - b["mer_sum_iq"]) < 1e-5 * a["mer_sum_iq"]

@@ -20,7 +20,8 @@ WORKER = textwrap.dedent("""
     calls = []
     el = g.timed(lambda: (calls.append(1), time.sleep(delay)), steps=3, sync=lambda: None)
     fps = g.job_frames_per_second(frames_per_step_per_gpu=100, steps=3, seconds=el)
-    g.emit(json.dumps({"rank": g.rank, "elapsed": el, "fps": fps, "seed": g.stream_seed(), "calls": len(calls)}))
+    fit = g.min_over_ranks(32768 if g.rank == 0 else 8192)     # rank 1's GPU holds a quarter of the batch: everybody takes 8192
+    g.emit(json.dumps({"rank": g.rank, "elapsed": el, "fps": fps, "seed": g.stream_seed(), "calls": len(calls), "fit": fit}))
     g.close()
 """) % ROOT
 
@@ -57,6 +58,7 @@ def test_two_rank_harness_over_gloo(tmp_path):
     assert abs(outs[0]["fps"] - 600 / outs[0]["elapsed"]) < 1e-6
     assert outs[0]["seed"] != outs[1]["seed"]
     assert outs[0]["calls"] == outs[1]["calls"] == 3
+    assert outs[0]["fit"] == outs[1]["fit"] == 8192
 
 
 WORKER2 = textwrap.dedent("""

@@ -19,11 +19,12 @@ sys.path.insert(0, %(root)r)
 import numpy as np, torch
 P = importlib.import_module("odr-dabmod_amd")
 B = %(B)d
-md = P.Modulator(mode=1, max_frames=B)
+MODE = %(mode)d
+md = P.Modulator(mode=MODE, max_frames=B)
 md.set_gain(2, 1.0, 1 / 50000., 4.0)
 torch.manual_seed(1234)            # (the same input in the product run and the timing run: their samples are compared)
-d_in = torch.randint(0, 256, (B, 28800), dtype=torch.uint8, device="cuda")
-out = torch.empty((B, 196608), dtype=torch.complex64, device="cuda")
+d_in = torch.randint(0, 256, (B, md.geometry["tf_input_bytes"]), dtype=torch.uint8, device="cuda")
+out = torch.empty((B, md.geometry["tf_samples"]), dtype=torch.complex64, device="cuda")
 st = torch.cuda.Stream()
 lib = P.load_library()
 timed = hasattr(lib, "dabgpu_debug_phase_cycles")
@@ -46,19 +47,26 @@ print(json.dumps({"ms_per_launch": ms, "counters": list(buf), "timed": timed,
 '''
 
 
+MODE = 1
+
+
 def run(lib, B, iters):
     env = dict(os.environ)
     if lib:
         env["DABGPU_LIB"] = lib
-    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "B": B, "iters": iters}], env=env, capture_output=True, text=True)
+    r = subprocess.run([sys.executable, "-c", CHILD % {"root": ROOT, "B": B, "iters": iters, "mode": MODE}], env=env, capture_output=True, text=True)
     if r.returncode:
         sys.exit(r.stderr[-3000:])
     return json.loads(r.stdout.strip().splitlines()[-1])
 
 
 def main():
+    global MODE
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 32768
+    MODE = int(sys.argv[2]) if len(sys.argv) > 2 else 1          # (modes II - IV: the generic packed-dual-transform kernel)
     iters = 5
+    wpg = {1: 4, 2: 1, 3: 1, 4: 2}[MODE]                           # waves per workgroup
+    nsym = 154 if MODE == 3 else 77
     variant = os.path.join(ROOT, "tools", "_variants", "libdabgpu_phase.so")
     if not os.path.exists(variant):
         sys.exit("build the tool library first: tools/variants.sh phase \"-DDABGPU_PHASE_TIMING\"")
@@ -68,11 +76,13 @@ def main():
     c = tim["counters"]
     n_iter = c[15]
     tot = sum(c[:len(PHASES)])
-    print("cfg 3 (coded bits -> gain var -> guard -> 45-tap FIR, equalised boundaries), %d frames per launch" % B)
+    print("cfg 3 (coded bits -> gain var -> guard -> 45-tap FIR%s), mode %d, %d frames per launch"
+          % (", equalised boundaries" if MODE == 1 else ", packed dual transform", MODE, B))
     print("product library: %.3f ms per launch;  timing build: %.3f ms (+%.1f %%);  same samples: %s"
           % (prod["ms_per_launch"], tim["ms_per_launch"], 100 * (tim["ms_per_launch"] / prod["ms_per_launch"] - 1),
              "yes" if prod["sha"] == tim["sha"] else "NO"))
-    print("wave-iterations timed: %d (= launches x frames x 77 symbols x 4 waves: %d)" % (n_iter, iters * B * 77 * 4))
+    print("wave-iterations timed: %d (launches x frames x %d symbols x %d waves = %d, plus one look-ahead symbol per run)"
+          % (n_iter, nsym, wpg, iters * B * nsym * wpg))
     print("%-78s %14s %8s %12s" % ("phase of one symbol iteration", "cycles/wave", "share", "ms of launch"))
     for name, v in zip(PHASES, c):
         print("%-78s %14.1f %7.1f%% %12.3f" % (name, v / n_iter, 100.0 * v / tot, prod["ms_per_launch"] * v / tot))
