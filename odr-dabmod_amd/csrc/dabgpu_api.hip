@@ -577,7 +577,7 @@ int apply_settings_groups(dabgpu_ctx *c)
         // the equalised-boundary variant of the frame kernel (Mode I, up to 45 taps: a shorter filter is the same filter with
         // zero taps behind it -- fused_ntaps): the taps' inverse on the occupied bins
         c->eq_ok = false;
-        if (c->g.logN == 11 && !c->cur.taps.empty() && c->cur.taps.size() <= 45) {
+        if (!c->cur.taps.empty() && c->cur.taps.size() <= 45) {
             std::vector<float> g;
             c->eq_ok = cached_inverse_filter(c->cur.taps, N, c->g.K, g, &c->eq_fit);
             if (c->eq_ok) HIPCHK(c, upload(c->d_eqg, g, s));
@@ -833,13 +833,13 @@ size_t bytes_per_sample(int fmt) { return fmt ? dabgpu_format_size(fmt) : sizeof
 // into native_out (`native` samples per frame).
 // tii_seg / tii_done: the caller's cached TII segment; *tii_done says whether the frame kernel added it itself (else the caller
 // runs launch_tii_add on the result)
-// Tap count the frame kernel is given.  Mode I: a filter of fewer than 45 taps runs as a 45-tap filter whose last taps are zero
+// Tap count the frame kernel is given.  A filter of fewer than 45 taps runs as a 45-tap filter whose last taps are zero
 // (out[n] = sum_j taps[j] in[n + j]: zero taps add nothing; the device table is zero padded) -- the kernels with the compile-time
 // tap count, the equalised-boundary variant among them, then serve every filter up to the default length.
 int fused_ntaps(const dabgpu_ctx *c)
 {
     const size_t n = c->cur.taps.size();
-    return (c->g.logN == 11 && n >= 1 && n < 45) ? 45 : (int)n;
+    return (n >= 1 && n < 45) ? 45 : (int)n;
 }
 
 int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,

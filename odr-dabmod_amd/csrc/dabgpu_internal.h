@@ -105,6 +105,7 @@ hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s);
 size_t tf_lds_bytes(int logN, unsigned flags, int nt = 0, int overlap = 0, int ntaps = 0);
 int tf_max_fused_taps();   // longest FIR the fused kernel handles (longer ones take the unfused path)
 bool tf_has_eq(const TfArgs &a, unsigned flags);     // the equalised-boundary variant exists for this chain (TF_EQ; needs t.eq_g)
+bool tf_small45(const TfArgs &a, unsigned flags);    // modes II - IV: the chain is one of those built with the compile-time tap count
 bool tf_has_window(const TfArgs &a, unsigned flags); // a frame-kernel variant windows the guard interval itself (TF_WINDOW)
 bool tf_has_fmt(const TfArgs &a, unsigned flags);   // a frame-kernel variant stores the format of flags' TF_OUT_* bit itself
 bool tf_has_tii(const TfArgs &a, unsigned flags);   // the variant these flags select adds the TII null symbol itself (a.tii_seg)

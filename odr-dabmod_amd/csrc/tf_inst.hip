@@ -10,5 +10,9 @@
 #define TF_CAT(a, b) TF_CAT2(a, b, )
 
 namespace dabgpu {
+#if TF_LOGN != 11 && TF_NT == 45
+hipError_t TF_CAT(TF_LOGN, TF_NT)(const TfArgs &a, unsigned flags, hipStream_t s) { return launch_tf_small45<TF_LOGN>(a, flags, s); }
+#else
 hipError_t TF_CAT(TF_LOGN, TF_NT)(const TfArgs &a, unsigned flags, hipStream_t s) { return launch_tf_n<TF_LOGN, TF_NT>(a, flags, s); }
+#endif
 }  // namespace dabgpu

@@ -95,11 +95,9 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 // plain form.  Measured: 2.51 M frames/s against 1.91 M for the packed dual transform that served these settings before.
 template <int LOGN, bool FROM_BITS, bool GAIN, bool GUARD, bool FIR, int NT, bool CFR = false, bool GVAR = false,
           bool ZONLY = false, int OFMT = 0, bool WIN = false, bool EQ = false>
-// Waves per SIMD asked of the register allocator: EQ 4 (128 VGPRs, 29 KB of LDS: four workgroups per CU); CFR 2 ... 4 (4: CFR_LEAN); no
-// FIR 2 (Mode I coded-bits default chain: 5, NOFIR_1BUF); the carriers-input FIR variants WITH time-domain gain statistics 2 (both transforms of a symbol stay live:
-// 256 VGPRs instead of spilling at 168); every other FIR variant 3 (<= 168 VGPRs, 42 KB of LDS).
+// (waves per SIMD, buffer scheme: tf_layout.h, tf_variant -- the one table the host's LDS size reads too)
 __global__ __launch_bounds__((1 << LOGN) / 8 < 64 ? 64 : (1 << LOGN) / 8,
-                             EQ ? 4 : CFR ? ((LOGN == 11 && FROM_BITS && GUARD && !WIN && (!FIR || NT == 45)) ? 4 : (FROM_BITS && GUARD && !(WIN && FIR) ? 3 : 2)) : !FIR ? ((LOGN == 11 && FROM_BITS && GUARD && !CFR && (!WIN || OFMT != 0)) ? ((WIN || (OFMT == 3 && !GAIN)) ? 4 : 5) : 2) : (GVAR ? 3 : ((GAIN && !FROM_BITS) ? 2 : 3)))
+                             tf_variant(LOGN, FROM_BITS, GAIN, GUARD, FIR, NT, CFR, GVAR, OFMT, WIN, EQ).waves_per_simd)
 void tf_kernel(const TfArgs a)
 {
     static_assert(!GVAR || (GAIN && !FROM_BITS && !CFR), "GVAR is a specialisation of the carriers path with gain");
@@ -112,8 +110,10 @@ void tf_kernel(const TfArgs a)
                   "WIN: coded-bits chain with guard interval (integer store: every format with EQ, s16 without FIRFilter)");
     static_assert(!(WIN && FIR) || (!ZONLY && (NT == 0 || (NT == 45 && !CFR)) && !GVAR),
                   "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count -- or EQ");
-    static_assert(!EQ || (LOGN == 11 && FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY),
-                  "EQ: the Mode I coded-bits chain with the 45-tap filter (WIN: overlap <= kEqWinMax)");
+    static_assert(!EQ || (FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY),
+                  "EQ: the coded-bits chain with the 45-tap filter");
+    static_assert(!EQ || LOGN == 11 || (!WIN && OFMT == 0),
+                  "EQ in transmission modes II - IV (round 6): complexf output, no windowing (Mode I: WIN with overlap <= kEqWinMax, every format)");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
@@ -123,14 +123,14 @@ void tf_kernel(const TfArgs a)
     // for FOUR waves per SIMD.  What kept these kernels above 128 registers were loop invariants, not the transforms; each went
     // where it costs an instruction or two per symbol instead of a register (see advance, fetch_block, cfr_symbol, boundary), and
     // one exchange buffer serves (two barriers per exchange; 24 kB of LDS per workgroup).
-    constexpr bool CFR_LEAN = CFR && LOGN == 11 && FROM_BITS && GUARD && !WIN && (!FIR || NT == 45);
     // NOFIR_1BUF (round 5: the reference's default chain, Mode I from coded bits): ONE exchange buffer (two barriers per exchange)
     // and 24 kB of LDS instead of 42 -- five workgroups per CU (<= 96 registers) instead of three.  Measured: complexf output
     // unchanged (3.3 M frames/s: the board's power limit), s16 4.07 -> 4.29 M, u8 3.86 -> 4.13 M; four waves: 4.12 / 3.96 M.
     // (the s8 store without GainControl spills 8 bytes at five waves: that one is built for four)
     // (windowed: with the s16 store, 3.57 -> 3.82 M; the complexf form loses 2 % and keeps two buffers)
-    constexpr bool NOFIR_1BUF = LOGN == 11 && FROM_BITS && GUARD && !FIR && !CFR && (!WIN || OFMT != 0);
-    constexpr bool DBUF = !FIR && !CFR_LEAN && !NOFIR_1BUF;
+    constexpr TfVariant VAR = tf_variant(LOGN, FROM_BITS, GAIN, GUARD, FIR, NT, CFR, GVAR, OFMT, WIN, EQ);
+    constexpr bool CFR_LEAN = VAR.cfr_lean, NOFIR_1BUF = VAR.nofir_1buf, DBUF = VAR.dbuf;
+    (void)NOFIR_1BUF;
     const int t = threadIdx.x;
     const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
     const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
@@ -144,8 +144,8 @@ void tf_kernel(const TfArgs a)
     // after the other as plain transforms instead of one packed pair -- the same instruction count (a packed fp32 instruction
     // occupies the SIMD twice as long), 8-byte exchanges, and registers for a fourth wave per SIMD
     // (the default filter length only: the run-time tap count's boundary loop does not fit the 128 registers)
-    constexpr bool CFR_SEQ = CFR_LEAN && FIR;
-    constexpr int kXElems = (FIR && !EQ && !CFR_SEQ) ? 2 * F::LDS_ELEMS : (DBUF ? 2 : 1) * F::LDS_ELEMS;
+    constexpr bool CFR_SEQ = VAR.cfr_seq;
+    constexpr int kXElems = VAR.dual ? 2 * F::LDS_ELEMS : (DBUF ? 2 : 1) * F::LDS_ELEMS;
     double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
     // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
     // that the boundary outputs read in[i + j] without a tail/head case split
@@ -792,7 +792,13 @@ void tf_kernel(const TfArgs a)
         // (four outputs per lane over 176 lanes measured 2 % faster than three over 240)
         constexpr int kEqOut = 44 + 2 * kEqWm;
         constexpr int kEqR = 4, kEqLanes = 16 * ((kEqOut + kEqR - 1) / kEqR);
-        static_assert(!EQ || kEqLanes <= T, "EQ: outputs per lane");
+        // Transmission modes II - IV (round 6): the workgroup has 128 or 64 lanes (Mode III: all 64 of its wave work here, the
+        // transform's idle half included), the 176 lane-jobs of either step are done in passes of blockDim.x.  Mode I: one pass.
+        constexpr int kEqThreads = T < 64 ? 64 : T;
+        static_assert(!(EQ && WIN) || kEqLanes <= T, "EQ with WIN: one pass");
+#pragma unroll
+        for (int eq_base = 0; eq_base < kEqLanes; eq_base += kEqThreads) {
+        const int t = eq_base + (int)threadIdx.x;             // (shadows the lane index: the lane-job of this pass)
         cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
         if (t < kEqLanes) {
             const int m0 = kEqR * (t >> 4), j0 = 10 * (t & 15);
@@ -844,6 +850,7 @@ void tf_kernel(const TfArgs a)
                 }
             }
         }
+        }   // eq_base
         lds_barrier();
         if constexpr (WIN) {
             // output i of 64 (2W + 44 of them wanted): terms jd = max(i - 44, 0) ... i of (omega d), tap 44 - i + jd; four lanes
@@ -871,7 +878,9 @@ void tf_kernel(const TfArgs a)
         }
         // y[N-44+i] = z_prev[N-44+i] + sum_{jd <= i} taps[44-i+jd] d[jd]: four lanes (one DPP quad) per output, lane q
         // taking jd = q, q+4, ...; past jd = i the tap index runs into the table's zero padding
-        {
+#pragma unroll
+        for (int eq_base = 0; eq_base < 4 * 44; eq_base += kEqThreads) {
+            const int t = eq_base + (int)threadIdx.x;
             const int i = min(t >> 2, C - 1), q = t & 3;
             const float *tq = taps_l + (C - i) + q;
             const cf *dq = eq_d + q;
@@ -1120,12 +1129,31 @@ void tf_kernel(const TfArgs a)
             // z_cur[N - cp + q] (slots 5 and 6); the symbol's own windows around its start (slots 7 and 0) are parked
             // for the next symbol.  Index of q everywhere: q + kEqQL.
             cf *zp_prev = eq_zp + cur * kEqW, *zp_new = eq_zp + (cur ^ 1) * kEqW;
-            constexpr int n0 = (N - cp) - kEqQL;              // first sample of the window in z_cur (1441)
-            static_assert(!EQ || (n0 >= 5 * T && n0 + kEqQL + kEqQH < 7 * T && kEqQL < T && kEqQH < T), "EQ windows: slots 5, 6, 7, 0");
-            if (t >= n0 - 5 * T) { const int iw = t - (n0 - 5 * T); eq_w[iw] = csub(v[5], zp_prev[iw]); }
-            if (t <= n0 + kEqQL + kEqQH - 6 * T) { const int iw = t + (6 * T - n0); eq_w[iw] = csub(v[6], zp_prev[iw]); }
-            if (t >= T - kEqQL) zp_new[t - (T - kEqQL)] = v[7];
-            if (t <= kEqQH) zp_new[kEqQL + t] = v[0];
+            [[maybe_unused]] constexpr int n0 = (N - cp) - kEqQL;              // first sample of the window in z_cur (1441)
+            if constexpr (LOGN == 11) {
+                static_assert(LOGN != 11 || (n0 >= 5 * T && n0 + kEqQL + kEqQH < 7 * T && kEqQL < T && kEqQH < T), "EQ windows: slots 5, 6, 7, 0");
+                if (t >= n0 - 5 * T) { const int iw = t - (n0 - 5 * T); eq_w[iw] = csub(v[5], zp_prev[iw]); }
+                if (t <= n0 + kEqQL + kEqQH - 6 * T) { const int iw = t + (6 * T - n0); eq_w[iw] = csub(v[6], zp_prev[iw]); }
+                if (t >= T - kEqQL) zp_new[t - (T - kEqQL)] = v[7];
+                if (t <= kEqQH) zp_new[kEqQL + t] = v[0];
+            } else if (lane_on) {
+                // Transmission modes II - IV: the windows are wider than a register slot (T = 128, 64, 32 lanes), and in Mode III
+                // wider than the cyclic prefix -- q runs past it into the symbol's body, sample (N - cp + q) mod N: the two symbols
+                // are compared as the N-periodic sequences the cyclic filtering makes of them, which is all the derivation uses.
+                // Which slots can hold a sample of either window is known at compile time; the lane tests are vector work.
+                static_assert(kEqQL + kEqQH + 1 <= N && kEqQH < N - kEqQL, "EQ windows: one period holds them");
+#pragma unroll
+                for (int m = 0; m < 8; ++m) {
+                    const int n = t + T * m;
+                    // q of sample n in the window around N - cp: the representative of n - (N - cp) mod N in [-kEqQL, kEqQH]
+                    int q = n - (N - cp);
+                    if (q > kEqQH) q -= N;
+                    if (q < -kEqQL) q += N;
+                    if (q >= -kEqQL && q <= kEqQH) eq_w[q + kEqQL] = csub(v[m], zp_prev[q + kEqQL]);
+                    if (m * T <= kEqQH && n <= kEqQH) zp_new[kEqQL + n] = v[m];
+                    if ((m + 1) * T > N - kEqQL && n >= N - kEqQL) zp_new[n - (N - kEqQL)] = v[m];
+                }
+            }
             lds_barrier();
             pt.stamp(PH_GAIN_WINDOWS);
             // (the boundary outputs follow the symbol's own stores, below: its samples are dead registers by then)
@@ -1483,6 +1511,31 @@ template <int LOGN, int NT> hipError_t launch_tf_n(const TfArgs &a, unsigned fla
     return hipGetLastError();
 }
 
+
+// Transmission modes II - IV with the default-length filter (round 6): the two plain coded-bits chains with the compile-time tap
+// count (tf_inst_<8|9|10>_45.o) -- the equalised-boundary variant (Mode IV: its 160-tap inverse and 44 x 45 correction cost less
+// than the second half of a packed 1024-point transform; at 512 and 256 points they cost MORE, tf_has_eq) and the packed dual
+// transform with the boundary loops unrolled.  Every other chain of those modes runs the generic kernels (NT = 0).
+template <int LOGN> hipError_t launch_tf_small45(const TfArgs &a, unsigned flags, hipStream_t s)
+{
+    constexpr int T = (1 << LOGN) / 8;
+    typedef ModeGeom<LOGN> G;
+    if (a.g.K != G::K || a.g.nb_symbols != G::nb_symbols || a.g.null_size != G::null_size || a.g.sym_size != G::sym_size)
+        return hipErrorInvalidValue;
+    if (!tf_small45(a, flags)) return hipErrorInvalidValue;
+    const dim3 block(T < 64 ? 64 : T);
+    const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
+    const size_t lds = tf_lds_bytes(LOGN, flags, 45, a.overlap, a.ntaps);
+    if (flags & TF_EQ) {
+        if (!tf_has_eq(a, flags) || !a.t.eq_g) return hipErrorInvalidValue;
+        if (flags & TF_GAIN) tf_go<LOGN, true, true, true, true, 45, false, false, false, 0, false, true>(grid, block, lds, s, a);
+        else tf_go<LOGN, true, false, true, true, 45, false, false, false, 0, false, true>(grid, block, lds, s, a);
+    } else {
+        if (flags & TF_GAIN) tf_go<LOGN, true, true, true, true, 45>(grid, block, lds, s, a);
+        else tf_go<LOGN, true, false, true, true, 45>(grid, block, lds, s, a);
+    }
+    return hipGetLastError();
+}
 
 }  // namespace
 }  // namespace dabgpu

@@ -12,20 +12,19 @@ hipError_t launch_tf_9_0(const TfArgs &a, unsigned flags, hipStream_t s);
 hipError_t launch_tf_10_0(const TfArgs &a, unsigned flags, hipStream_t s);
 hipError_t launch_tf_11_0(const TfArgs &a, unsigned flags, hipStream_t s);
 hipError_t launch_tf_11_45(const TfArgs &a, unsigned flags, hipStream_t s);
+hipError_t launch_tf_8_45(const TfArgs &a, unsigned flags, hipStream_t s);       // (modes II - IV: the equalised-boundary variant alone)
+hipError_t launch_tf_9_45(const TfArgs &a, unsigned flags, hipStream_t s);
+hipError_t launch_tf_10_45(const TfArgs &a, unsigned flags, hipStream_t s);
 
 size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
 {
     const size_t N = (size_t)1 << logN;
     const bool eq = flags & TF_EQ;
 
-    // (the Mode I coded-bits CFR chains with the guard interval, without FIRFilter or with the default-length one: CFR_LEAN in
-    // tf_kernel -- one exchange buffer, plain transforms one after the other, the lanes' bit positions in LDS)
-    const unsigned lean_want = TF_CFR | TF_FROM_BITS | TF_GUARD;
-    const bool cfr_lean = logN == 11 && (flags & lean_want) == lean_want && !(flags & TF_WINDOW) && (!(flags & TF_FIR) || nt == 45);
-    const bool nofir_1buf = logN == 11 && (flags & (TF_FROM_BITS | TF_GUARD)) == (TF_FROM_BITS | TF_GUARD) &&
-                            !(flags & (TF_FIR | TF_CFR)) && (!(flags & TF_WINDOW) || tf_ofmt(flags));
-    const bool dbuf = !(flags & TF_FIR) && !cfr_lean && !nofir_1buf;        // two exchange buffers without FIR, one with (see tf_kernel)
-    const bool dual = (flags & TF_FIR) && !eq && !cfr_lean;  // packed dual transform: 16-byte elements
+    // the buffer scheme of the variant (tf_layout.h: the table the kernel itself reads)
+    const TfVariant v = tf_variant(logN, flags & TF_FROM_BITS, flags & TF_GAIN, flags & TF_GUARD, flags & TF_FIR, nt, flags & TF_CFR,
+                                   flags & TF_GVAR, tf_ofmt(flags), flags & TF_WINDOW, eq);
+    const bool cfr_lean = v.cfr_lean, dbuf = v.dbuf, dual = v.dual;
     size_t b = dual ? (N + N / 8) * 2 * sizeof(float2) : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
     b += 16 * sizeof(double);
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
@@ -63,13 +62,26 @@ bool tf_has_window(const TfArgs &a, unsigned flags)
 
 int tf_max_fused_taps() { return kBnd < kMaxTaps ? kBnd : kMaxTaps; }
 
+// modes II - IV: the chains built with the compile-time tap count (tf_kernel.h: launch_tf_small45) -- coded bits, guard interval,
+// the 45-tap filter, complexf output, no CFR, no windowing; with or without GainControl, equalised (TF_EQ) or not
+bool tf_small45(const TfArgs &a, unsigned flags)
+{
+    const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
+    return a.g.logN >= 8 && a.g.logN <= 10 && a.ntaps == 45 && (flags & ~(unsigned)(TF_GAIN | TF_EQ)) == want;
+}
+
 // the equalised-boundary variant: the chains of the pruned-dual-transform variant, given the inverse of the taps; with OFDM
 // windowing (TF_WINDOW) for overlaps up to kEqWinMax
 bool tf_has_eq(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
     if ((flags & TF_WINDOW) && (a.overlap < 1 || a.overlap > kEqWinMax)) return false;
-    return a.t.eq_g != nullptr && a.g.logN == 11 && a.ntaps == 45 && (flags & want) == want && !(flags & TF_CFR) &&
+    // Mode IV (round 6): complexf output, no windowing -- the form tf_inst_10_45.o holds.  Not modes II and III: the inverse
+    // filter (44 x 160) and the correction (44 x 45 / 2) are the same work per symbol whatever its length, 16 k multiply-adds,
+    // and the second half of a packed transform of 512 or 256 points plus the direct boundary filter is LESS than that
+    // (measured, Mode II: 2.70 ms per 16384 frames equalised, 2.58 ms as a packed pair; profiles/r06_small_modes.txt).
+    if (a.g.logN != 11 && ((flags & TF_WINDOW) || tf_ofmt(flags))) return false;
+    return a.t.eq_g != nullptr && a.g.logN >= 10 && a.g.logN <= 11 && a.ntaps == 45 && (flags & want) == want && !(flags & TF_CFR) &&
            (!(flags & TF_GAIN) || a.gain.mode != 1);
 }
 
@@ -117,9 +129,9 @@ hipError_t launch_tf(const TfArgs &a, unsigned flags, hipStream_t s)
     }
     switch (a.g.logN) {
         // Mode I with the default filter length gets the compile-time tap count
-        case 8: return launch_tf_8_0(a, flags, s);
-        case 9: return launch_tf_9_0(a, flags, s);
-        case 10: return launch_tf_10_0(a, flags, s);
+        case 8: return tf_small45(a, flags) ? launch_tf_8_45(a, flags, s) : launch_tf_8_0(a, flags, s);
+        case 9: return tf_small45(a, flags) ? launch_tf_9_45(a, flags, s) : launch_tf_9_0(a, flags, s);
+        case 10: return tf_small45(a, flags) ? launch_tf_10_45(a, flags, s) : launch_tf_10_0(a, flags, s);
         case 11:
             return ((flags & TF_FIR) && a.ntaps == 45 && !((flags & TF_CFR) && (flags & TF_WINDOW))) ? launch_tf_11_45(a, flags, s)
                                                        : launch_tf_11_0(a, flags, s);

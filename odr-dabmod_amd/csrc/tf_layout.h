@@ -12,4 +12,39 @@ constexpr int kEqWLen = 240, kEqDLen = 80;
 constexpr int kEqElems = 3 * kEqWLen + kEqDLen + (kEqTaps + 8) / 2 + 16;
 constexpr int kWinMax = 128;       // widest raised-cosine overlap the frame kernel applies itself (TF_WINDOW)
 constexpr int kBnd = 128;          // LDS slots per boundary buffer; the fused FIR handles ntaps <= kBnd
+
+// ---- ONE place for what a frame-kernel variant is built like --------------------------------------------------------------
+// The kernel's __launch_bounds__ and buffer layout (tf_kernel.h) and the host's LDS size (tf_launch.hip: tf_lds_bytes) read
+// the same table; nothing else restates these conditions.  Arguments: the kernel's template arguments (nt = the COMPILE-TIME
+// tap count of the instantiation, 0 = run-time).
+struct TfVariant {
+    bool cfr_lean;      // Mode I coded-bits CFR chains with the guard interval (no FIRFilter, or the default-length one): built for
+                        // four waves per SIMD -- one exchange buffer, loop invariants re-derived or parked in LDS
+    bool cfr_seq;       // ... with FIRFilter: the corrected spectrum's two inverse transforms one after the other, not as a packed pair
+    bool nofir_1buf;    // the reference's default chain (Mode I from coded bits, no FIRFilter): one exchange buffer, five waves per SIMD
+    bool dbuf;          // two exchange buffers (one barrier per exchange) -- the variants without FIRFilter that are not one of the above
+    bool dual;          // unfiltered + filtered transform of a symbol as ONE packed transform: 16-byte exchange elements
+    int waves_per_simd; // asked of the register allocator (HIP: the second __launch_bounds__ argument)
+};
+constexpr TfVariant tf_variant(int logn, bool from_bits, bool gain, bool guard, bool fir, int nt, bool cfr, bool gvar,
+                               int ofmt, bool win, bool eq)
+{
+    TfVariant v{};
+    v.cfr_lean = cfr && logn == 11 && from_bits && guard && !win && (!fir || nt == 45);
+    v.cfr_seq = v.cfr_lean && fir;
+    v.nofir_1buf = logn == 11 && from_bits && guard && !fir && !cfr && (!win || ofmt != 0);
+    v.dbuf = !fir && !v.cfr_lean && !v.nofir_1buf;
+    v.dual = fir && !eq && !v.cfr_seq;
+    // EQ: 4 (128 VGPRs, 29 KB of LDS: four workgroups per CU); modes II - IV: 3 (their one- and two-wave workgroups are limited by
+    //   the windows' LDS before that, and at 128 registers they spill)
+    // CFR: 4 where it is built lean, 3 on the other coded-bits chains with the guard interval that keep one transform live, else 2
+    // no FIRFilter: the default chain 5 (windowed, or the s8 store without GainControl: 4), everything else 2
+    // FIRFilter: 3 (<= 168 VGPRs, 42 KB of LDS) -- except the carriers-input variants with time-domain gain statistics: 2 (both
+    //   transforms of a symbol stay live: 256 VGPRs instead of spilling at 168)
+    v.waves_per_simd = eq ? (logn == 11 ? 4 : 3)
+                       : cfr ? (v.cfr_lean ? 4 : ((from_bits && guard && !(win && fir)) ? 3 : 2))
+                       : !fir ? (v.nofir_1buf ? ((win || (ofmt == 3 && !gain)) ? 4 : 5) : 2)
+                       : (gvar ? 3 : ((gain && !from_bits) ? 2 : 3));
+    return v;
+}
 }  // namespace dabgpu

@@ -44,11 +44,15 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
     out = []
     if overlap == 0 and fits:
         # ---- ONE frame kernel: bits -> ... -> guard interval (-> FIRFilter)
-        # Mode I runs every filter of up to 45 taps as a 45-tap filter (compile-time length); CFR variants keep the run-time count
-        ntaps = T if (not F or cfr) else (45 if mode == 1 and T < 45 else T)
-        nt = 45 if (mode == 1 and F and ntaps == 45) else 0
-        default_len = mode == 1 and F and ntaps == 45 and not cfr and gain != 1      # (gain max needs the unfiltered samples)
-        eq = default_len and fir != "notch"              # boundary outputs through the taps' inverse
+        # every filter of up to 45 taps runs as a 45-tap filter; CFR variants keep the run-time count
+        ntaps = T if (not F or cfr) else (45 if T < 45 else T)
+        default_len = F and ntaps == 45 and not cfr and gain != 1      # (gain max needs the unfiltered samples)
+        # boundary outputs through the taps' inverse: Mode I, and (round 6) Mode IV -- at 512 and 256 points the inverse costs
+        # more than the second half of the packed transform it saves
+        eq = default_len and fir != "notch" and mode in (1, 4)
+        # the compile-time tap count: Mode I every form with 45 taps; modes II - IV (round 6) the plain chains without CFR
+        nt = 45 if (F and ntaps == 45 and (mode == 1 or not cfr)) else 0
+        default_len = default_len and (mode == 1 or eq)
         tii_inside = tii                                  # (round 5: every form of the one frame kernel adds the TII null symbol itself)
         # integer output stored by the frame kernel itself (Mode I): s16 on every form (round 5: also CFR, gain mode max, other tap
         # counts); u8 / s8 (round 5) on the no-FIRFilter and the equalised-boundary variants
@@ -58,7 +62,7 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
         if cfr:
             out.append(tf(logn, G, 1, F, nt if F else 0, cfr=1, ofmt=of))
         elif default_len:
-            out.append(tf(11, G, 1, 1, 45, ofmt=of, eq=1) if eq else tf(11, G, 1, 1, 45, zonly=1, ofmt=of))
+            out.append(tf(logn, G, 1, 1, 45, ofmt=of, eq=1) if eq else tf(11, G, 1, 1, 45, zonly=1, ofmt=of))
         else:
             out.append(tf(logn, G, 1, F, nt if F else 0, ofmt=of))
         if tii and not tii_inside:
@@ -210,7 +214,7 @@ def test_dispatch_cell(pkg, mods, cell):
         # the integers of two fp32 chains: at most one step apart, and as rarely as tests/conftest.py::int_off_by_one_limit says
         ok = d.max() <= 1 and record_bound("dispatch matrix: integer components one step from the reference's, %s" %
                                            "mode %d %s %s ov %d cfr %d tii %d %s" % (mode, gain, fir, overlap, cfr, tii_on, fmt),
-                                           err, int_off_by_one_limit(wantq))
+                                           err, int_off_by_one_limit(wantq, 1 << LOGN[mode], fmt))
         shown = "%.1e of the components one step off" % err
     _rows.append("%d %-4s %-5s %3d %d %d %-4s | %s | %s" % (mode, gain, fir, overlap, cfr, tii_on, fmt or "cf32", shown, "; ".join(got)))
     assert got == want, "kernels launched %s, the rule book says %s" % (got, want)

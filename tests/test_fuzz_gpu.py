@@ -165,7 +165,7 @@ def test_random_configuration_against_the_oracle(pkg, c):
                 # (tests/conftest.py::int_off_by_one_limit: the share the float agreement implies at this amplitude)
                 off = float((d != 0).mean())
                 assert d.max() <= 1 and record_bound("fuzz: integer components one step from the reference's, case %s" % (c,),
-                                                     off, int_off_by_one_limit(want)), \
+                                                     off, int_off_by_one_limit(want, {1: 2048, 2: 512, 3: 256, 4: 1024}[mode], c["fmt"])), \
                     "call %d: max step %d, %.2g of the components off" % (i, d.max(), off)
     finally:
         md.close()
