@@ -730,6 +730,23 @@ DEV void quad_sum2_dpp(float &x, float &y)
                  "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf"
                  : "+v"(x), "+v"(y));
 }
+// x, y summed over the sixteen lanes of every DPP row (every lane of the row ends up with the sum)
+DEV void row16_sum2_dpp(float &x, float &y)
+{
+    asm volatile("s_nop 1\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[1,0,3,2] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 quad_perm:[2,3,0,1] row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_ror:4 row_mask:0xf bank_mask:0xf\n\t"
+                 "s_nop 0\n\t"
+                 "v_add_f32_dpp %0, %0, %0 row_ror:8 row_mask:0xf bank_mask:0xf\n\t"
+                 "v_add_f32_dpp %1, %1, %1 row_ror:8 row_mask:0xf bank_mask:0xf"
+                 : "+v"(x), "+v"(y));
+}
 // two values (one wait state between the steps left to pad)
 #define DABGPU_RED2_STEP(OP0, CTRL)                                                              \
     "s_nop 0\n\t" OP0 " %0, %0, %0 " CTRL "\n\tv_add_f32_dpp %1, %1, %1 " CTRL "\n\t"

@@ -112,8 +112,8 @@ void tf_kernel(const TfArgs a)
                   "WIN with FIR: the generic packed dual transform (all unfiltered samples at hand), run-time tap count -- or EQ");
     static_assert(!EQ || (FROM_BITS && GUARD && FIR && NT == 45 && !CFR && !GVAR && !ZONLY),
                   "EQ: the coded-bits chain with the 45-tap filter");
-    static_assert(!EQ || LOGN == 11 || (!WIN && OFMT == 0),
-                  "EQ in transmission modes II - IV (round 6): complexf output, no windowing (Mode I: WIN with overlap <= kEqWinMax, every format)");
+    static_assert(!EQ || LOGN == 11 || (LOGN == 10 && !WIN && OFMT == 0),
+                  "EQ in transmission mode IV (round 6): complexf output, no windowing (Mode I: WIN with overlap <= kEqWinMax, every format)");
     typedef ModeGeom<LOGN> G;
     typedef Fft<LOGN> F;
     constexpr int N = F::N, T = F::T;
@@ -131,10 +131,21 @@ void tf_kernel(const TfArgs a)
     constexpr TfVariant VAR = tf_variant(LOGN, FROM_BITS, GAIN, GUARD, FIR, NT, CFR, GVAR, OFMT, WIN, EQ);
     constexpr bool CFR_LEAN = VAR.cfr_lean, NOFIR_1BUF = VAR.nofir_1buf, DBUF = VAR.dbuf;
     (void)NOFIR_1BUF;
-    const int t = threadIdx.x;
-    const bool lane_on = T >= 64 ? true : t < T;  // only N=256 (T=32) runs with idle lanes (the block is max(T, 64) lanes)
-    const unsigned long long on_mask = T >= 64 ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
+    // HALVES (round 6; Mode III, the plain coded-bits chain with the default-length filter): a 256-point symbol is 32 lanes of
+    // eight points, half a wave -- so the two halves of the workgroup's one wave work on TWO FRAMES (2 p and 2 p + 1, the same run
+    // of symbols in each): every lane quantity is the frame's own as it is, every LDS buffer that belongs to a frame exists
+    // twice, and the few wave-uniform quantities that differ between the frames (the frame's address, the gain statistic, the
+    // store offset) become lane quantities.  `t` below is the lane's index INSIDE ITS FRAME (0 .. 31), t_wg the lane of the
+    // workgroup.  Every other variant: one frame per workgroup, t == t_wg, NH == 1 -- the same instructions as before.
+    constexpr bool HALVES = VAR.halves;
+    constexpr int NH = HALVES ? 2 : 1;
+    const int t_wg = threadIdx.x;
+    const int half = HALVES ? (t_wg >> 5) : 0;
+    const int t = HALVES ? (t_wg & 31) : t_wg;
+    const bool lane_on = (HALVES || T >= 64) ? true : t < T;  // only N=256 (T=32) without HALVES runs with idle lanes (the block is max(T, 64) lanes)
+    const unsigned long long on_mask = (HALVES || T >= 64) ? ~0ull : ((1ull << (T & 63)) - 1ull);   // the same as a wave mask
     const int tt = lane_on ? t : 0;
+    auto hoff = [&](int n) __attribute__((always_inline)) -> int { return HALVES ? half * n : 0; };   // the frame's copy of a buffer
 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     cf *fbuf = reinterpret_cast<cf *>(smem);                            // 2 x (N + N/8) complex
@@ -146,13 +157,16 @@ void tf_kernel(const TfArgs a)
     // (the default filter length only: the run-time tap count's boundary loop does not fit the 128 registers)
     constexpr bool CFR_SEQ = VAR.cfr_seq;
     constexpr int kXElems = VAR.dual ? 2 * F::LDS_ELEMS : (DBUF ? 2 : 1) * F::LDS_ELEMS;
-    double *red = reinterpret_cast<double *>(fbuf + kXElems);  // 16 doubles
+    double *red = reinterpret_cast<double *>(fbuf + NH * kXElems);  // 16 doubles
+    fbuf += hoff(kXElems);
     // FIR boundary samples: two buffers [tail of symbol s (C) | head of symbol s+1 (C)], contiguous so
     // that the boundary outputs read in[i + j] without a tail/head case split
     // frequency-domain gain statistics (coded-bits path): one packed word of phases per lane
-    uint32_t *phw = reinterpret_cast<uint32_t *>(red + 16);          // [T]
+    uint32_t *phw = reinterpret_cast<uint32_t *>(red + NH * 16);          // [T]
+    red += hoff(16);
     // (carriers path: three complex bins per lane instead -- the general form of the same statistic)
-    cf *bnd = reinterpret_cast<cf *>(phw + (GAIN ? (FROM_BITS ? T : 6 * T) : 0));
+    cf *bnd = reinterpret_cast<cf *>(phw + NH * (GAIN ? (FROM_BITS ? T : 6 * T) : 0));
+    phw += hoff(T);
     // coded bits of one OFDM symbol (K/4 bytes), double buffered, behind the FIR buffers
     constexpr int KB = NT ? NT - 1 : kBnd;      // slots per half buffer: the look-ahead C when it is a compile-time constant
     // WIN: two seam buffers [last W | first W samples of a symbol], the rising 2W samples of the next one, the window
@@ -170,13 +184,15 @@ void tf_kernel(const TfArgs a)
                   "LDS share of the EQ variants (tf_lds_bytes)");
     cf *eq_zp = bnd, *eq_w = bnd + 2 * kEqW, *eq_d = eq_w + kEqW;
     float *g_l = reinterpret_cast<float *>(eq_d + kEqDLen);
-    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + (EQ ? kEqElems : (FIR && !WIN) ? 4 * KB : ((WIN && !FIR) ? 7 * kWinMax : 0)));
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + NH * (EQ ? kEqElems : (FIR && !WIN) ? 4 * KB : ((WIN && !FIR) ? 7 * kWinMax : 0)));
+    bnd += hoff(4 * KB);
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 2;     // + one dummy slot per half (and one more: the halves stay 8-byte aligned)
     // small read-only tables copied to LDS once: read through global memory they compile to
     // vector loads (the output stores may alias them), and every such load drags an
     // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
-    float *taps_l = reinterpret_cast<float *>(bitbuf + (FROM_BITS ? 2 * kBitStride : 0));
+    float *taps_l = reinterpret_cast<float *>(bitbuf + NH * (FROM_BITS ? 2 * kBitStride : 0));
+    bitbuf += hoff(2 * kBitStride);
     constexpr int kTapsL = kMaxTaps, kMagL = 160;
     float *mag_l = taps_l + kTapsL;
     // exp(i p pi/4) with exact 0 / +-1 entries, in 8 rotated copies: entry [rot * 8 + p] = exp(i (p + rot) pi/4).
@@ -184,17 +200,17 @@ void tf_kernel(const TfArgs a)
     // unreduced (see advance); the rotation is the symbol's share, picked through the table's base address.
     cf *unit8 = reinterpret_cast<cf *>(mag_l + kMagL);
     cf *tw8_l = unit8 + 64;                             // 7 x 8 twiddles of the stride-8 stage (Fft::fill_tw8)
-    F::fill_tw8(a.t.twiddle, tw8_l, t);
+    F::fill_tw8(a.t.twiddle, tw8_l, t_wg);
     // CFR statistics: per-wave partials (2 + 4 floats per wave), behind everything else
     float *cfr_red = reinterpret_cast<float *>(tw8_l + 56);
     uint2 *bsh_l = reinterpret_cast<uint2 *>(cfr_red + 6 * ((T + 63) / 64));     // CFR_LEAN: [3][T] bit positions of the lane's six carriers
-    if (t < 64) {
-        const unsigned p = ((unsigned)t + ((unsigned)t >> 3)) & 7u;
+    if (t_wg < 64) {
+        const unsigned p = ((unsigned)t_wg + ((unsigned)t_wg >> 3)) & 7u;
         const float cx = (float)((int)((kCX >> (2u * p)) & 3u) - 1);
         const float cy = (float)((int)((kCX >> (2u * ((p + 6u) & 7u))) & 3u) - 1);
-        unit8[t] = mk(cx, cy);
+        unit8[t_wg] = mk(cx, cy);
     }
-    for (int i = t; i < kTapsL; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
+    for (int i = t_wg; i < kTapsL; i += blockDim.x) taps_l[i] = FIR ? a.t.taps[i] : 0.f;
     if (EQ)
         for (int i = t; i < kEqTaps + 8; i += blockDim.x) g_l[i] = i < kEqTaps ? a.t.eq_g[i] : 0.f;
     if (EQ) {
@@ -216,12 +232,17 @@ void tf_kernel(const TfArgs a)
     if (WIN)
         for (int i = t; i < 2 * W; i += blockDim.x) win_l[i] = a.t.window[i];
     if (FROM_BITS)
-        for (int i = t; i < G::nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
+        for (int i = t_wg; i < G::nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
     lds_barrier();
 
     constexpr int K = G::K, nsym = G::nb_symbols + 1;
-    const int frame = blockIdx.x / a.chunks_per_frame;
-    const int chunk = blockIdx.x - frame * a.chunks_per_frame;
+    // (HALVES: blockIdx.x counts PAIRS of frames; frame0 = the pair's first frame, wave-uniform)
+    const int frame0 = NH * (int)(blockIdx.x / a.chunks_per_frame);
+    const int chunk = blockIdx.x - (frame0 / NH) * a.chunks_per_frame;
+    // the lane's frame; a pair's second frame may lie behind the batch's last one: it is computed like the first (its input read
+    // from the last frame again) and none of its stores leaves (put)
+    const bool frame_ok = !HALVES || frame0 + half < a.n_frames;
+    const int frame = HALVES ? min(frame0 + half, a.n_frames - 1) : frame0;
     const int s_begin = chunk * a.syms_per_chunk;
     // (the frame's last run takes whatever is left: run_symbols, dabgpu_api.hip)
     const int s_end = chunk == a.chunks_per_frame - 1 ? nsym : min(nsym, s_begin + a.syms_per_chunk);
@@ -229,10 +250,10 @@ void tf_kernel(const TfArgs a)
     // so on a frame that carries TII the null symbol's segment is g_1 times a constant segment (a.tii_seg, computed once per
     // setting) instead of zeros: stored by the workgroup that owns symbols 0 and 1 when its run is over, its last C
     // samples added to the boundary outputs that symbol 1 completes.
-    constexpr bool TII_IN = FROM_BITS && GUARD && (EQ || !WIN);
+    constexpr bool TII_IN = FROM_BITS && GUARD && (EQ || !WIN) && !HALVES;    // (Mode III has no TII: src/TII.cpp:144-149)
     const bool tii_on = TII_IN && a.tii_seg != nullptr && s_begin == 0 && (((frame & 1) == 0) == (a.tii_insert0 != 0));
     float g1s = 1.0f;            // the multiplier of symbol 1 (wave-uniform: a scalar register)
-    if (frame >= a.n_frames || s_begin >= nsym) return;
+    if (frame0 >= a.n_frames || s_begin >= nsym) return;
 
     const int ntaps = NT ? NT : a.ntaps;
     const int C = FIR ? ntaps - 1 : 0;  // FIR look-ahead
@@ -295,7 +316,10 @@ void tf_kernel(const TfArgs a)
     // lane's; out-of-range lanes are exec-masked by the callers (the hardware would drop them as well).
     constexpr int kOutBytes = OFMT == 0 ? 8 : (OFMT == 1 ? 4 : 2);
     const __amdgpu_buffer_rsrc_t orsrc = __builtin_amdgcn_make_buffer_rsrc(
-        reinterpret_cast<char *>(a.out) + (size_t)frame * a.out_stride * kOutBytes, 0, (int)(a.out_stride * kOutBytes), 0x00020000);
+        reinterpret_cast<char *>(a.out) + (size_t)frame0 * a.out_stride * kOutBytes, 0, (int)(NH * a.out_stride * kOutBytes), 0x00020000);
+    // HALVES: the lane's frame inside the pair's two-frame window; a frame behind the batch's end gets an offset no buffer has
+    // (the hardware drops what lies outside the resource: nothing of it is stored)
+    const int hvoff = HALVES ? (frame_ok ? half * (int)a.out_stride : 0x07ffffff) : 0;
     unsigned nclip = 0;
     typedef unsigned v2u_ __attribute__((ext_vector_type(2)));
     // NON-TEMPORAL output stores on the coded-bits chain (round 4; aux bit 1 = nt).  In a pure bandwidth test a non-temporal
@@ -320,7 +344,7 @@ void tf_kernel(const TfArgs a)
             __builtin_amdgcn_raw_buffer_store_b16(b8_pack<(OFMT == 3 ? 3 : 2)>(y, nclip), orsrc, voff * 2, soff * 2, kStoreAux);
         } else {
             const v2u_ d = {__builtin_bit_cast(unsigned, y.x), __builtin_bit_cast(unsigned, y.y)};
-            __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, voff * 8, soff * 8, kStoreAux);
+            __builtin_amdgcn_raw_buffer_store_b64(d, orsrc, (voff + hvoff) * 8, soff * 8, kStoreAux);
         }
     };
 
@@ -429,7 +453,7 @@ void tf_kernel(const TfArgs a)
         {
             const int nblk = s_begin - 2;                        // blocks 0 .. s_begin - 3
             constexpr int W = K / 32;                            // dwords per half block
-            constexpr int kThreadsTf = T < 64 ? 64 : T;          // == blockDim.x
+            constexpr int kThreadsTf = HALVES ? 32 : (T < 64 ? 64 : T);          // == blockDim.x (HALVES: the lanes of one frame)
             constexpr int NG = kThreadsTf / W;                   // block-parallel groups of W lanes
             static_assert(K % 32 == 0 && NG >= 1 && (2 * NG + 2) * W * 4 <= kXElems * (int)sizeof(cf), "bit-sliced prefix");
             if (nblk > 0) {                                      // (workgroup-uniform)
@@ -746,7 +770,7 @@ void tf_kernel(const TfArgs a)
     };
 
     // boundary outputs of the previous segment: 4 lanes per output, shuffle-reduced
-    constexpr int kThreads = T < 64 ? 64 : T;      // == blockDim.x (a compile-time constant keeps it out of the loop)
+    constexpr int kThreads = HALVES ? 32 : (T < 64 ? 64 : T);      // == blockDim.x (a compile-time constant keeps it out of the loop; HALVES: the lanes of one frame)
     auto boundary = [&](const cf *src) __attribute__((always_inline)) {
         // src = [tail (C) | head (C)]; output i of the C boundary outputs = sum_j taps[j] src[i + j].
         // Four lanes (one DPP quad) share an output, lane q taking taps q, q+4, ...
@@ -792,13 +816,7 @@ void tf_kernel(const TfArgs a)
         // (four outputs per lane over 176 lanes measured 2 % faster than three over 240)
         constexpr int kEqOut = 44 + 2 * kEqWm;
         constexpr int kEqR = 4, kEqLanes = 16 * ((kEqOut + kEqR - 1) / kEqR);
-        // Transmission modes II - IV (round 6): the workgroup has 128 or 64 lanes (Mode III: all 64 of its wave work here, the
-        // transform's idle half included), the 176 lane-jobs of either step are done in passes of blockDim.x.  Mode I: one pass.
-        constexpr int kEqThreads = T < 64 ? 64 : T;
-        static_assert(!(EQ && WIN) || kEqLanes <= T, "EQ with WIN: one pass");
-#pragma unroll
-        for (int eq_base = 0; eq_base < kEqLanes; eq_base += kEqThreads) {
-        const int t = eq_base + (int)threadIdx.x;             // (shadows the lane index: the lane-job of this pass)
+        static_assert(!EQ || LOGN != 11 || kEqLanes <= T, "EQ: outputs per lane");
         cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
         if (t < kEqLanes) {
             const int m0 = kEqR * (t >> 4), j0 = 10 * (t & 15);
@@ -850,7 +868,6 @@ void tf_kernel(const TfArgs a)
                 }
             }
         }
-        }   // eq_base
         lds_barrier();
         if constexpr (WIN) {
             // output i of 64 (2W + 44 of them wanted): terms jd = max(i - 44, 0) ... i of (omega d), tap 44 - i + jd; four lanes
@@ -878,9 +895,7 @@ void tf_kernel(const TfArgs a)
         }
         // y[N-44+i] = z_prev[N-44+i] + sum_{jd <= i} taps[44-i+jd] d[jd]: four lanes (one DPP quad) per output, lane q
         // taking jd = q, q+4, ...; past jd = i the tap index runs into the table's zero padding
-#pragma unroll
-        for (int eq_base = 0; eq_base < 4 * 44; eq_base += kEqThreads) {
-            const int t = eq_base + (int)threadIdx.x;
+        {
             const int i = min(t >> 2, C - 1), q = t & 3;
             const float *tq = taps_l + (C - i) + q;
             const cf *dq = eq_d + q;
@@ -894,6 +909,54 @@ void tf_kernel(const TfArgs a)
                 y = mk(fmaf(g1s, ts.x, y.x), fmaf(g1s, ts.y, y.y));
             }
             if (t < 4 * C && q == 0) put(prev_pos + prev_seg - C, t >> 2, y);
+        }
+    };
+
+    // The same for transmission mode IV (round 6; no windowing, no TII -- modes III and IV have none --, complexf output): the
+    // workgroup has 128 lanes, the 176 lane-jobs of either step are done in two passes.  (Kept apart from the Mode I form above so
+    // that the headline kernel's instruction stream is exactly what it was.)
+    auto eq_boundary_small = [&](const cf *zp) __attribute__((always_inline)) {
+        constexpr int kEqR = 4, kEqLanes = 16 * ((44 + kEqR - 1) / kEqR);      // 176
+        constexpr int kEqThreads = T < 64 ? 64 : T;
+#pragma unroll
+        for (int eq_base = 0; eq_base < kEqLanes; eq_base += kEqThreads) {
+            const int tj = eq_base + t;
+            cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+            if (tj < kEqLanes) {
+                const int m0 = kEqR * (tj >> 4), j0 = 10 * (tj & 15);
+                const cf *wp = eq_w + (m0 + (kEqTaps - 1 - 9) - j0);
+                const float2 *g2 = reinterpret_cast<const float2 *>(g_l + j0);
+                cf wv[kEqR + 9];
+                float gg[10];
+#pragma unroll
+                for (int i = 0; i < kEqR + 9; ++i) wv[i] = wp[i];
+#pragma unroll
+                for (int u = 0; u < 5; ++u) { const float2 g = g2[u]; gg[2 * u] = g.x; gg[2 * u + 1] = g.y; }
+#pragma unroll
+                for (int u = 0; u < 10; ++u)
+#pragma unroll
+                    for (int r = 0; r < kEqR; ++r) acc[r] = axpy(acc[r], gg[u], wv[r + 9 - u]);
+            }
+#pragma unroll
+            for (int r = 0; r < kEqR; ++r) row16_sum2_dpp(acc[r].x, acc[r].y);
+            if (tj < kEqLanes && (tj & 15) == 0) {
+#pragma unroll
+                for (int r = 0; r < kEqR; ++r) eq_d[kEqR * (tj >> 4) + r] = acc[r];
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int eq_base = 0; eq_base < 4 * 44; eq_base += kEqThreads) {
+            const int tj = eq_base + t;
+            const int i = min(tj >> 2, C - 1), q = tj & 3;
+            const float *tq = taps_l + (C - i) + q;
+            const cf *dq = eq_d + q;
+            cf y = mk(0.f, 0.f);
+#pragma unroll
+            for (int k = 0; k < 11; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
+            quad_sum2_dpp(y.x, y.y);
+            y = cadd(y, zp[kEqQL - C + i]);
+            if (tj < 4 * C && q == 0) put(prev_pos + prev_seg - C, tj >> 2, y);
         }
     };
 
@@ -916,7 +979,7 @@ void tf_kernel(const TfArgs a)
         if (EQ) {
             for (int i = t; i < kEqW; i += (int)blockDim.x) eq_zp[cur * kEqW + i] = mk(0.f, 0.f);
         } else if (FIR && !WIN) {
-            for (int i = t; i < KB; i += (int)blockDim.x) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
+            for (int i = t; i < KB; i += (HALVES ? 32 : (int)blockDim.x)) bnd[cur * 2 * KB + i] = mk(0.f, 0.f);
         }
         if (FIR) {
             have_prev = true;
@@ -965,19 +1028,25 @@ void tf_kernel(const TfArgs a)
                 // rotation, s - 1 quarter turns in all.  The three sums in one addition (fields cannot carry into each
                 // other: 3 + 3 + 3 < 16); counted per wave with ballots -- the additions run on the scalar unit.
                 const unsigned sums = P + o + (((unsigned)(s - 1) & 3u) * 0x111u);
-                int cnt = 0;
+                int cnt = 0, cnt_hi = 0;          // (HALVES: the counts of lanes 0 .. 31 and of lanes 32 .. 63 -- two frames)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) {
                     const unsigned f = sums & (3u << (4 * j));
                     // (v_cmp_eq_u32 straight into an SGPR pair: 32 = ICMP_EQ)
-                    cnt += __builtin_popcountll(__builtin_amdgcn_uicmp(f, 0u, 32) & on_mask);
-                    cnt -= __builtin_popcountll(__builtin_amdgcn_uicmp(f, 2u << (4 * j), 32) & on_mask);
+                    const unsigned long long b0 = __builtin_amdgcn_uicmp(f, 0u, 32), b2 = __builtin_amdgcn_uicmp(f, 2u << (4 * j), 32);
+                    if constexpr (HALVES) {
+                        cnt += __builtin_popcount((unsigned)b0) - __builtin_popcount((unsigned)b2);
+                        cnt_hi += __builtin_popcount((unsigned)(b0 >> 32)) - __builtin_popcount((unsigned)(b2 >> 32));
+                    } else {
+                        cnt += __builtin_popcountll(b0 & on_mask);
+                        cnt -= __builtin_popcountll(b2 & on_mask);
+                    }
                 }
-                const float part = (float)cnt;
+                const float part = (float)((HALVES && half) ? cnt_hi : cnt);
                 float *redf = reinterpret_cast<float *>(red + 8 * (s & 1));
                 // (WIN, at the register limit: the wave's index as a scalar -- the slot's address is scalar arithmetic and a
                 // move, not a lane register that stays live across the transform and gets spilled)
-                if ((t & 63) == 0) redf[WIN ? __builtin_amdgcn_readfirstlane(t >> 6) : t >> 6] = part;      // combined after the transform's barriers
+                if ((t & 63) == 0) redf[WIN ? __builtin_amdgcn_readfirstlane(t >> 6) : t >> 6] = part;      // combined after the transform's barriers (HALVES: lane 0 of each frame, into the frame's own slot)
             }
         } else {
 #pragma unroll
@@ -1280,7 +1349,7 @@ void tf_kernel(const TfArgs a)
         }
         pt.stamp(PH_STORES);
         if constexpr (EQ) {
-            if (have_prev) eq_boundary(eq_zp + cur * kEqW, false);
+            if (have_prev) { if constexpr (LOGN == 11) eq_boundary(eq_zp + cur * kEqW, false); else eq_boundary_small(eq_zp + cur * kEqW); }
             cur ^= 1;
             pt.stamp(PH_BOUNDARY);
             if (lookahead) break;
@@ -1305,7 +1374,7 @@ void tf_kernel(const TfArgs a)
         lds_barrier();
         for (int i = t; i < kEqW; i += (int)blockDim.x) eq_w[i] = mk(-zp[i].x, -zp[i].y);
         lds_barrier();
-        eq_boundary(zp, true);
+        if constexpr (LOGN == 11) eq_boundary(zp, true); else eq_boundary_small(zp);
     } else if (WIN && FIR && s_end == nsym && have_prev) {
         // end of the frame: the last symbol keeps its (unwindowed) tail, nothing follows it
         const cf *stash = wfb + cur * wfLP;
@@ -1317,7 +1386,7 @@ void tf_kernel(const TfArgs a)
         // end of the frame: the look-ahead runs off the buffer, missing terms are
         // dropped (reference src/FIRFilter.cpp:186-191)
         lds_barrier();
-        for (int i = t; i < C; i += (int)blockDim.x) bnd[cur * 2 * KB + C + i] = mk(0.f, 0.f);   // zero head
+        for (int i = t; i < C; i += (HALVES ? 32 : (int)blockDim.x)) bnd[cur * 2 * KB + C + i] = mk(0.f, 0.f);   // zero head
         lds_barrier();
         boundary(bnd + cur * 2 * KB);
     }
@@ -1524,12 +1593,18 @@ template <int LOGN> hipError_t launch_tf_small45(const TfArgs &a, unsigned flags
         return hipErrorInvalidValue;
     if (!tf_small45(a, flags)) return hipErrorInvalidValue;
     const dim3 block(T < 64 ? 64 : T);
-    const dim3 grid((unsigned)(a.n_frames * a.chunks_per_frame));
+    // (Mode III: two frames per workgroup -- tf_variant(...).halves --, the grid counts pairs of frames)
+    constexpr bool halves = tf_variant(LOGN, true, true, true, true, 45, false, false, 0, false, false).halves;
+    const dim3 grid((unsigned)((halves ? (a.n_frames + 1) / 2 : a.n_frames) * a.chunks_per_frame));
     const size_t lds = tf_lds_bytes(LOGN, flags, 45, a.overlap, a.ntaps);
     if (flags & TF_EQ) {
         if (!tf_has_eq(a, flags) || !a.t.eq_g) return hipErrorInvalidValue;
-        if (flags & TF_GAIN) tf_go<LOGN, true, true, true, true, 45, false, false, false, 0, false, true>(grid, block, lds, s, a);
-        else tf_go<LOGN, true, false, true, true, 45, false, false, false, 0, false, true>(grid, block, lds, s, a);
+        if constexpr (LOGN == 10) {
+            if (flags & TF_GAIN) tf_go<10, true, true, true, true, 45, false, false, false, 0, false, true>(grid, block, lds, s, a);
+            else tf_go<10, true, false, true, true, 45, false, false, false, 0, false, true>(grid, block, lds, s, a);
+        } else {
+            return hipErrorInvalidValue;          // (tf_has_eq: Modes I and IV)
+        }
     } else {
         if (flags & TF_GAIN) tf_go<LOGN, true, true, true, true, 45>(grid, block, lds, s, a);
         else tf_go<LOGN, true, false, true, true, 45>(grid, block, lds, s, a);

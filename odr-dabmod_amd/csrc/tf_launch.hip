@@ -25,6 +25,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     const TfVariant v = tf_variant(logN, flags & TF_FROM_BITS, flags & TF_GAIN, flags & TF_GUARD, flags & TF_FIR, nt, flags & TF_CFR,
                                    flags & TF_GVAR, tf_ofmt(flags), flags & TF_WINDOW, eq);
     const bool cfr_lean = v.cfr_lean, dbuf = v.dbuf, dual = v.dual;
+    const size_t nh = v.halves ? 2 : 1;          // (two frames per workgroup: every per-frame buffer twice)
     size_t b = dual ? (N + N / 8) * 2 * sizeof(float2) : (dbuf ? 2 : 1) * (N + N / 8) * sizeof(float2);
     b += 16 * sizeof(double);
     if (flags & TF_GAIN) b += ((flags & TF_FROM_BITS) ? 1 : 6) * (N / 8) * sizeof(uint32_t);   // phase words / paired bins
@@ -32,6 +33,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter, window factors
     else if ((flags & TF_FIR) && !wf) b += 4 * (nt ? nt - 1 : kBnd) * sizeof(float2);  // 2 x [tail | next head]
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 2) * sizeof(uint32_t);  // staged coded bits (kBitStride)
+    b *= nh;                                                                      // (everything so far belongs to a frame)
     b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
     b += 56 * sizeof(float2);                                      // twiddles of the stride-8 stage
     if (flags & TF_CFR) b += 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red
@@ -67,6 +69,8 @@ int tf_max_fused_taps() { return kBnd < kMaxTaps ? kBnd : kMaxTaps; }
 bool tf_small45(const TfArgs &a, unsigned flags)
 {
     const unsigned want = TF_FROM_BITS | TF_GUARD | TF_FIR;
+    // (Mode III runs two frames per wave there, with the gain statistic per half-wave: not the wave-wide maximum of gain mode max)
+    if (a.g.logN == 8 && (flags & TF_GAIN) && a.gain.mode == 1) return false;
     return a.g.logN >= 8 && a.g.logN <= 10 && a.ntaps == 45 && (flags & ~(unsigned)(TF_GAIN | TF_EQ)) == want;
 }
 

@@ -51,7 +51,7 @@ def expected_kernels(mode, gain, fir, overlap, cfr, tii, fmt):
         # more than the second half of the packed transform it saves
         eq = default_len and fir != "notch" and mode in (1, 4)
         # the compile-time tap count: Mode I every form with 45 taps; modes II - IV (round 6) the plain chains without CFR
-        nt = 45 if (F and ntaps == 45 and (mode == 1 or not cfr)) else 0
+        nt = 45 if (F and ntaps == 45 and (mode == 1 or not cfr) and not (mode == 3 and gain == 1)) else 0
         default_len = default_len and (mode == 1 or eq)
         tii_inside = tii                                  # (round 5: every form of the one frame kernel adds the TII null symbol itself)
         # integer output stored by the frame kernel itself (Mode I): s16 on every form (round 5: also CFR, gain mode max, other tap

@@ -1950,3 +1950,60 @@ def test_num_clipped_never_answers_for_an_earlier_call(pkg):
         assert md.num_clipped() == 0
     finally:
         md.close()
+
+
+# ---- round 6: the compile-time-tap kernels of modes II - IV (Mode IV equalised, Mode III two frames per wave) -------------------
+@pytest.mark.parametrize("mode,kernel", [(2, "logn=9 bits=1 gain=%d guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=0 win=0 eq=0"),
+                                         (3, "logn=8 bits=1 gain=%d guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=0 win=0 eq=0"),
+                                         (4, "logn=10 bits=1 gain=%d guard=1 fir=1 nt=45 cfr=0 gvar=0 zonly=0 ofmt=0 win=0 eq=1")])
+@pytest.mark.parametrize("gain_mode", [None, 0, 2])
+@pytest.mark.parametrize("n_frames,chunks", [(1, 0), (2, 1), (3, 3), (5, 0), (8, 7)])
+def test_small_mode_default_filter_kernels(pkg, mode, kernel, gain_mode, n_frames, chunks):
+    """Modes II - IV, coded bits -> [gain] -> guard -> 45-tap FIRFilter (`src/DabModulator.cpp:84-122` geometries): the kernels with
+    the compile-time tap count.  Mode III runs TWO frames per wave (the halves of its one wave: an odd batch leaves the last
+    workgroup's second half without a frame -- it must store nothing, also not behind the caller's buffer); Mode IV the
+    equalised-boundary variant.  Every frame against the oracle at rel-RMS < 1e-6, frames behind the batch untouched."""
+    import torch
+    per = O.tf_input_bytes(mode)
+    bits = np.stack([synth_bits(per, seed=6100 + 17 * mode + i) for i in range(n_frames)])
+    md = pkg.Modulator(mode=mode, max_frames=n_frames, chunks_per_frame=chunks)
+    try:
+        stages = pkg.STAGE_FIR | (pkg.STAGE_GAIN if gain_mode is not None else 0)
+        norm = 1.0 / 50000.0 if gain_mode == 2 else 1.0
+        kw = dict(mode=mode, stages=stages, normalise=norm)
+        if gain_mode is not None:
+            md.set_gain(gain_mode, 1.0, norm, 4.0)
+            kw.update(gain_mode=gain_mode)
+        md.trace(True)
+        ns = md.out_samples_per_frame(stages)
+        d_bits = torch.from_numpy(bits).cuda()
+        # two guard frames behind the batch, filled with a pattern no kernel writes
+        d_out = torch.full((n_frames + 2, ns), 12345.0 + 6789.0j, dtype=torch.complex64, device="cuda")
+        md.chain_dev(d_bits, n_frames, stages, d_out[:n_frames])
+        torch.cuda.synchronize()
+        assert md.last_variant() == ["tf_kernel<%s>" % (kernel % int(gain_mode is not None))]
+        y = d_out.cpu().numpy()
+        assert np.all(y[n_frames:] == np.complex64(12345.0 + 6789.0j)), "stores behind the batch"
+        ref = O.Chain(**kw).process(bits)
+        for f in range(n_frames):
+            assert rel_rms(y[f], ref[f]) < 1e-6, (f, rel_rms(y[f], ref[f]))
+    finally:
+        md.close()
+
+
+def test_mode3_gain_max_keeps_the_generic_kernel(pkg):
+    """Gain mode max needs a maximum over the WAVE's samples (`src/GainControl.cpp:196-250`): not the two-frames-per-wave kernel."""
+    import torch
+    per = O.tf_input_bytes(3)
+    bits = np.stack([synth_bits(per, seed=6200 + i) for i in range(3)])
+    md = pkg.Modulator(mode=3, max_frames=3)
+    try:
+        md.set_gain(1, 1.0, 1.0, 4.0)
+        md.trace(True)
+        y = md.chain(bits, 3)
+        assert md.last_variant() == ["tf_kernel<logn=8 bits=1 gain=1 guard=1 fir=1 nt=0 cfr=0 gvar=0 zonly=0 ofmt=0 win=0 eq=0>"]
+        ref = O.Chain(mode=3, stages=3, gain_mode=1, normalise=1.0).process(bits)
+        for f in range(3):
+            assert rel_rms(y[f], ref[f]) < 1e-6
+    finally:
+        md.close()

@@ -13,6 +13,8 @@ for mode in modes:
     B = base * {1: 1, 2: 4, 3: 4, 4: 2}[mode]
     md = P.Modulator(mode=mode, max_frames=B)
     md.set_gain(2, 1.0, 1 / 50000., 4.0)
+    if os.environ.get("DABGPU_DIRECT_BOUNDARY") == "1":
+        md.set_fir_boundary_mode(True)          # (the packed dual transform in place of the equalised-boundary variant)
     md.trace(True)
     g = md.geometry
     with torch.cuda.stream(st):
