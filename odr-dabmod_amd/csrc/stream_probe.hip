@@ -1,5 +1,5 @@
 // stream_probe.hip -- streams that really overlap: HIP streams are multiplexed onto a few hardware queues, and the
-// library's lanes (dabgpu_api.hip: batches in flight inside one context) need a queue each.
+// library's lanes (api_lanes.hip: batches in flight inside one context) need a queue each.
 //
 // The HIP runtime keeps GPU_MAX_HW_QUEUES hardware queues (four by default); a new stream joins the one that holds the
 // fewest streams at that moment, and streams on one queue run IN ORDER.  So whether three streams created in a row end

@@ -84,7 +84,7 @@ template <> struct ModeGeom<10> { static constexpr int nb_symbols = 76, K = 768,
 //     y[N-44+i] = z_prev[N-44+i] + sum_{j >= 44-i} taps[j] d[i+j-44],   d[m] = x_cur[N-cp+m] - x_prev[m]
 // (the cyclic result looked into x_prev's own start where the stream continues with x_cur's prefix), and the
 // unfiltered difference d comes out of a short inverse filter g of the taps (G H = 1 on the occupied bins -- the only
-// ones a symbol has energy in; designed on the host, dabgpu_api.hip design_inverse_filter):
+// ones a symbol has energy in; designed on the host, api_context.hip design_inverse_filter):
 //     d[m] = sum_j g[j] w[m - (j - c)],   w[q] = z_cur[N-cp+q] - z_prev[q mod N],   q in [-103, 99].
 // 44 x 160 + 990 real-by-complex multiply-adds per symbol replace half of a packed 2048-point transform, its 16-byte
 // exchanges and the pack / unpack around it.
@@ -184,8 +184,12 @@ void tf_kernel(const TfArgs a)
                   "LDS share of the EQ variants (tf_lds_bytes)");
     cf *eq_zp = bnd, *eq_w = bnd + 2 * kEqW, *eq_d = eq_w + kEqW;
     float *g_l = reinterpret_cast<float *>(eq_d + kEqDLen);
-    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + NH * (EQ ? kEqElems : (FIR && !WIN) ? 4 * KB : ((WIN && !FIR) ? 7 * kWinMax : 0)));
-    bnd += hoff(4 * KB);
+    // BWIN (round 6; modes II - IV, packed dual transform, 45 taps): the boundary filter reads a register window of fifteen samples
+    // per lane; the last tap group's window runs up to three slots past the buffers (under zero taps): four slots of zeros there
+    constexpr bool BWIN = VAR.bwin;
+    constexpr int kBndElems = 4 * KB + (BWIN ? 4 : 0);
+    uint32_t *bitbuf = reinterpret_cast<uint32_t *>(bnd + NH * (EQ ? kEqElems : (FIR && !WIN) ? kBndElems : ((WIN && !FIR) ? 7 * kWinMax : 0)));
+    bnd += hoff(kBndElems);
     constexpr int kBitWords = (3 * N / 4) / 16;  // K/4 bytes = K/16 dwords, K = 3N/4
     constexpr int kBitStride = kBitWords + 2;     // + one dummy slot per half (and one more: the halves stay 8-byte aligned)
     // small read-only tables copied to LDS once: read through global memory they compile to
@@ -233,7 +237,16 @@ void tf_kernel(const TfArgs a)
         for (int i = t; i < 2 * W; i += blockDim.x) win_l[i] = a.t.window[i];
     if (FROM_BITS)
         for (int i = t_wg; i < G::nb_symbols; i += blockDim.x) mag_l[i] = a.t.mag[i];
+    if (BWIN && t < 4) bnd[4 * KB + t] = mk(0.f, 0.f);
     lds_barrier();
+    // BWIN: the lane's twelve taps (tap group t & 3: taps 12 q ... 12 q + 11; the table is zero behind tap 44), held in registers
+    // (three float4 variables, not an array: an array captured by the boundary lambda stays in scratch memory)
+    float4 tapa = make_float4(0.f, 0.f, 0.f, 0.f), tapb = tapa, tapc = tapa;
+    if constexpr (BWIN) {
+        const float4 *tp = reinterpret_cast<const float4 *>(taps_l + 12 * (t & 3));
+        tapa = tp[0]; tapb = tp[1]; tapc = tp[2];
+    }
+    const float4 tapm = make_float4((t & 3) == 0 ? 1.f : 0.f, (t & 3) == 1 ? 1.f : 0.f, (t & 3) == 2 ? 1.f : 0.f, (t & 3) == 3 ? 1.f : 0.f);
 
     constexpr int K = G::K, nsym = G::nb_symbols + 1;
     // (HALVES: blockIdx.x counts PAIRS of frames; frame0 = the pair's first frame, wave-uniform)
@@ -244,7 +257,7 @@ void tf_kernel(const TfArgs a)
     const bool frame_ok = !HALVES || frame0 + half < a.n_frames;
     const int frame = HALVES ? min(frame0 + half, a.n_frames - 1) : frame0;
     const int s_begin = chunk * a.syms_per_chunk;
-    // (the frame's last run takes whatever is left: run_symbols, dabgpu_api.hip)
+    // (the frame's last run takes whatever is left: run_symbols, api_chain.hip)
     const int s_end = chunk == a.chunks_per_frame - 1 ? nsym : min(nsym, s_begin + a.syms_per_chunk);
     // TII (f-4) inside the kernel: everything after the IFFT is linear and the null symbol takes the multiplier of symbol 1,
     // so on a frame that carries TII the null symbol's segment is g_1 times a constant segment (a.tii_seg, computed once per
@@ -774,6 +787,48 @@ void tf_kernel(const TfArgs a)
     auto boundary = [&](const cf *src) __attribute__((always_inline)) {
         // src = [tail (C) | head (C)]; output i of the C boundary outputs = sum_j taps[j] src[i + j].
         // Four lanes (one DPP quad) share an output, lane q taking taps q, q+4, ...
+        if constexpr (BWIN) {
+            // Register-window form: a quad of lanes owns FOUR consecutive outputs (11 quads = 44 lanes), lane q of it the twelve taps
+            // 12 q ... 12 q + 11 -- it reads the fifteen samples src[4 g + 12 q ... + 14], forms its share of all four outputs
+            // from them (48 multiply-adds for 21 LDS reads; the one-output-per-quad form below: 12 for 24, taps included) and the
+            // quad's shares are added by DPP.  In the small transmission modes the boundary filter's reads were as much LDS traffic
+            // as the transform's exchanges (Mode III) or a third of it (Mode II).
+            static_assert(!BWIN || NT == 45, "eleven quads of four outputs, four groups of twelve taps");
+            for (int g0 = 0; g0 < 11; g0 += kThreads / 4) {
+                const int g = g0 + (t >> 2), q = t & 3;
+                const bool on = g < 11;
+                const cf *wp = src + (4 * (on ? g : 0) + 12 * q);
+                cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+                // (in three steps of four taps: a window of seven samples is live at a time, not fifteen -- the filtered symbol's
+                // sixteen registers are still waiting for their stores here)
+#pragma unroll
+                for (int c4 = 0; c4 < 3; ++c4) {
+                    cf w[7];
+#pragma unroll
+                    for (int k = 0; k < 7; ++k) w[k] = wp[4 * c4 + k];
+                    const float4 tp = c4 == 0 ? tapa : (c4 == 1 ? tapb : tapc);
+                    const float tk[4] = {tp.x, tp.y, tp.z, tp.w};
+#pragma unroll
+                    for (int k = 0; k < 4; ++k)
+#pragma unroll
+                        for (int r = 0; r < 4; ++r) acc[r] = axpy(acc[r], tk[k], w[r + k]);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; ++r) quad_sum2_dpp(acc[r].x, acc[r].y);
+                // lane q stores output 4 g + q: picked with 0 / 1 factors (a select chain over the array index makes the compiler park
+                // the four sums in scratch memory and load one back by address)
+                cf y = cscale(acc[0], tapm.x);
+                y = axpy(y, tapm.y, acc[1]);
+                y = axpy(y, tapm.z, acc[2]);
+                y = axpy(y, tapm.w, acc[3]);
+                if (TII_IN && tii_on && prev_pos == 0 && on) {          // (the null symbol's boundary outputs: plus the TII segment's)
+                    const cf ts = a.tii_seg[len0 - C + 4 * g + q];
+                    y = mk(fmaf(g1s, ts.x, y.x), fmaf(g1s, ts.y, y.y));
+                }
+                if (on) put(prev_pos + prev_seg - C + 4 * g0, t, y);
+            }
+            return;
+        }
         int tb = t;
         if constexpr (CFR_SEQ) asm volatile("" : "+v"(tb));    // (at the register limit: lane indices re-derived, not held)
         for (int i0 = 0; i0 < C; i0 += kThreads / 4) {

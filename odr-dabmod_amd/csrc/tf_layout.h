@@ -26,6 +26,8 @@ struct TfVariant {
     bool dual;          // unfiltered + filtered transform of a symbol as ONE packed transform: 16-byte exchange elements
     bool halves;        // Mode III, the plain coded-bits chain with the default-length filter (round 6): the two halves of the one wave
                         // work on two frames -- every per-frame LDS buffer twice, blockIdx counts pairs of frames
+    bool bwin;          // modes II - IV, the packed dual transform with the default-length filter (round 6): the boundary filter works
+                        // from a register window (four outputs x twelve taps per lane); its sample buffers carry four slots of padding
     int waves_per_simd; // asked of the register allocator (HIP: the second __launch_bounds__ argument)
 };
 constexpr TfVariant tf_variant(int logn, bool from_bits, bool gain, bool guard, bool fir, int nt, bool cfr, bool gvar,
@@ -37,6 +39,7 @@ constexpr TfVariant tf_variant(int logn, bool from_bits, bool gain, bool guard, 
     v.nofir_1buf = logn == 11 && from_bits && guard && !fir && !cfr && (!win || ofmt != 0);
     v.dbuf = !fir && !v.cfr_lean && !v.nofir_1buf;
     v.dual = fir && !eq && !v.cfr_seq;
+    v.bwin = logn != 11 && fir && nt == 45 && !cfr && !win && !eq;
     v.halves = logn == 8 && from_bits && guard && fir && nt == 45 && !cfr && !gvar && ofmt == 0 && !win && !eq;
     // EQ: 4 (128 VGPRs, 29 KB of LDS: four workgroups per CU); modes II - IV: 3 (their one- and two-wave workgroups are limited by
     //   the windows' LDS before that, and at 128 registers they spill)

@@ -1126,7 +1126,7 @@ def test_chain_tii_setting_change_rebuilds_the_segment(pkg):
 # Every remote-control setter, toggled between two chain calls of ONE context, must leave the context in the state a
 # fresh context configured with the second value is in: the tables a setting feeds (tap table + frequency response +
 # inverse filter, guard window, predistorter block, resampler geometry, cached TII segment) are re-uploaded exactly
-# when their key changes (Settings::*_key in dabgpu_api.hip).  (value A, value B) per setter; stages = the full chain.
+# when their key changes (Settings::*_key in dabgpu_ctx.h).  (value A, value B) per setter; stages = the full chain.
 _TOGGLES = {
     "gain": (lambda md: md.set_gain(2, 1.0, 1.0 / 50000.0, 4.0), lambda md: md.set_gain(0, 0.8, 1.0 / 400000.0, 3.0)),
     "fir_taps": (lambda md: md.set_fir_taps(None),

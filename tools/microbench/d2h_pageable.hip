@@ -1,6 +1,6 @@
 // d2h_pageable.hip -- how fast does a device buffer reach PAGEABLE host memory (what a ModPlugin's Buffer is), as a
 // function of the size of one hipMemcpyAsync and of the way a large copy is cut into pieces?  Decides the piece size of
-// HostIO::out (dabgpu_api.hip).   hipcc --offload-arch=gfx950 -O2 d2h_pageable.hip -o d2h_pageable
+// HostIO::out (dabgpu_ctx.h).   hipcc --offload-arch=gfx950 -O2 d2h_pageable.hip -o d2h_pageable
 #include <hip/hip_runtime.h>
 
 #include <chrono>
