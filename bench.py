@@ -532,11 +532,13 @@ def main():
 
     def other_mode(mode, b, steps):
         """The cfg 3 chain (coded bits -> ... -> GainControl(var) -> guard -> FIRFilter) in transmission mode II / III / IV
-        (src/DabModulator.cpp:84-122): these run the generic frame kernels (radix-8 stages + a radix-4/2 tail for N = 512 /
-        256 / 1024), not the Mode I specialisations.  Frames per second of THAT mode's frames (24 / 24 / 48 ms of air time),
-        and its own algorithmic bytes per frame."""
+        (src/DabModulator.cpp:84-122; N = 512 / 256 / 1024).  Round 6: kernels with the compile-time tap count -- Mode IV the
+        equalised-boundary variant, modes II and III the packed dual transform with the boundary filter from a register window,
+        Mode III two frames per wave; `kernel` is what the launch trace says ran.  Frames per second of THAT mode's frames
+        (24 / 24 / 48 ms of air time), and its own algorithmic bytes per frame."""
         md = P.Modulator(mode=mode, device=local_rank, max_frames=b, chunks_per_frame=args.chunks)
         md.set_gain(P.GAIN_VAR, 1.0, 1.0 / 50000.0, 4.0)
+        md.trace(True)
         stages = P.STAGE_GAIN | P.STAGE_FIR
         nin, ns = md.geometry["tf_input_bytes"], md.out_samples_per_frame(stages)
         st = torch.cuda.Stream(device=dev)
@@ -553,6 +555,7 @@ def main():
             e1.record(st)
             st.synchronize()
         ms = e0.elapsed_time(e1) / steps
+        ran = "; ".join(md.last_variant())
         md.close()
         del d_bits, d_out
         torch.cuda.empty_cache()
@@ -560,7 +563,7 @@ def main():
         fps = b / (ms * 1e-3)
         return {"frames_per_s": round(fps, 2), "frames_per_step": b, "algorithmic_bytes_per_frame": algo_b,
                 "achieved_GBps": round(algo_b * fps / 1e9, 2), "roofline_frac": round(algo_b * fps / 1e9 / HBM_PEAK_GBPS, 4),
-                "frame_ms_of_air_time": {2: 24, 3: 24, 4: 48}[mode], "kernel": "generic tf_kernel<logn=%d>" % {2: 9, 3: 8, 4: 10}[mode]}
+                "frame_ms_of_air_time": {2: 24, 3: 24, 4: 48}[mode], "kernel": ran}
 
     # The batch every rank can hold.  32768 frames are 52.5 GB of input + output per GPU: a rank that cannot get them
     # (another tenant on the GPU, a smaller part) halves its batch until the buffers fit, the ranks agree on the SMALLEST
