@@ -197,7 +197,9 @@ void tf_kernel(const TfArgs a)
     // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
     float *taps_l = reinterpret_cast<float *>(bitbuf + NH * (FROM_BITS ? 2 * kBitStride : 0));
     bitbuf += hoff(2 * kBitStride);
-    constexpr int kTapsL = kMaxTaps, kMagL = 160;
+    // (BWIN, HALVES: the boundary filter holds its taps in registers -- no tap table; the 512 bytes are what lets an eleventh
+    // Mode III workgroup onto a CU)
+    constexpr int kTapsL = VAR.bwin ? 0 : kMaxTaps, kMagL = 160;
     float *mag_l = taps_l + kTapsL;
     // exp(i p pi/4) with exact 0 / +-1 entries, in 8 rotated copies: entry [rot * 8 + p] = exp(i (p + rot) pi/4).
     // The coded-bits path keeps its differential phases without the common "+1 eighth per symbol" term and
@@ -243,7 +245,7 @@ void tf_kernel(const TfArgs a)
     // (three float4 variables, not an array: an array captured by the boundary lambda stays in scratch memory)
     float4 tapa = make_float4(0.f, 0.f, 0.f, 0.f), tapb = tapa, tapc = tapa;
     if constexpr (BWIN) {
-        const float4 *tp = reinterpret_cast<const float4 *>(taps_l + 12 * (t & 3));
+        const float4 *tp = reinterpret_cast<const float4 *>(a.t.taps + 12 * (t & 3));      // (kMaxTaps floats, zero behind tap 44)
         tapa = tp[0]; tapb = tp[1]; tapc = tp[2];
     }
     const float4 tapm = make_float4((t & 3) == 0 ? 1.f : 0.f, (t & 3) == 1 ? 1.f : 0.f, (t & 3) == 2 ? 1.f : 0.f, (t & 3) == 3 ? 1.f : 0.f);

@@ -34,7 +34,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     else if ((flags & TF_FIR) && !wf) b += (4 * (nt ? nt - 1 : kBnd) + (v.bwin ? 4 : 0)) * sizeof(float2);  // 2 x [tail | next head] (+ padding)
     if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 2) * sizeof(uint32_t);  // staged coded bits (kBitStride)
     b *= nh;                                                                      // (everything so far belongs to a frame)
-    b += (kMaxTaps + 160) * sizeof(float) + 64 * sizeof(float2);  // taps, |y_s| table, unit vectors (8 rotations)
+    b += ((v.bwin ? 0 : kMaxTaps) + 160) * sizeof(float) + 64 * sizeof(float2);  // taps (not where they live in registers), |y_s| table, unit vectors (8 rotations)
     b += 56 * sizeof(float2);                                      // twiddles of the stride-8 stage
     if (flags & TF_CFR) b += 6 * ((N / 8 + 63) / 64) * sizeof(float);   // cfr_red
     if (cfr_lean) b += 3 * (N / 8) * 2 * sizeof(uint32_t);               // bit positions of the lanes' carriers
