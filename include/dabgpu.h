@@ -287,7 +287,7 @@ DABGPU_API int dabgpu_post_process_dev(dabgpu_ctx *ctx, const void *d_native, si
  *     stay on lane 0, in call order;
  *   - a call with an explicit stream argument is what it always was: asynchronous on that stream, the context's scratch.
  *     Do not mix the two on one context without a dabgpu_synchronize in between.
- * dabgpu_set_lanes: 1 ... 4 (default 3: measured best at 1 ... 64 frames per call, tools/exp_r05.py lanes; 1 = every call on the one context stream, in order).  Waits for the context. */
+ * dabgpu_set_lanes: 1 ... 4 (default 3: measured best at 1 ... 64 frames per call, tools/experiments/exp_r05.py lanes; 1 = every call on the one context stream, in order).  Waits for the context. */
 DABGPU_API int dabgpu_set_lanes(dabgpu_ctx *ctx, int lanes);
 /* Diagnostic: how many lanes exist so far (lane 0 = the context's stream, the others are created on first use), and in
  * *own_queue_mask, bit i: lane i was found a hardware queue of its own.  (The HIP runtime multiplexes streams onto a few

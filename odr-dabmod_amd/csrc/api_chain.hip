@@ -17,7 +17,7 @@ int auto_chunks(const dabgpu_ctx *c, size_t n_frames)
     // efficiency, counts there: 10 us per Mode-I frame).
     // With the call rotating over L lanes (section 4.5 of DESIGN.md), L launches are in flight and the chip is filled by
     // FEWER, LONGER runs per launch -- and every run saved is a prologue and a look-ahead transform saved: measured optimum
-    // with three lanes (tools/exp_r05.py chunks, profiles/r05_exp_chunks.jsonl) 26 runs per frame at 16 frames (416 workgroups;
+    // with three lanes (tools/experiments/exp_r05.py chunks, profiles/r05_exp_chunks.jsonl) 26 runs per frame at 16 frames (416 workgroups;
     // +10 % over 624), 6 ... 8 at 64 (+14 % over 1024), 2 at 256 (+4 %): about 1280 / L workgroups per launch.
     const int nsym = c->g.nb_symbols + 1;
     const size_t n = n_frames;

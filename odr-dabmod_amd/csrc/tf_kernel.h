@@ -341,11 +341,11 @@ void tf_kernel(const TfArgs a)
     // store is the SLOWER one (-10 %), but these kernels do not run at a bandwidth limit: they run at the
     // board's 1400 W power limit, where the stores are a third of a frame's energy (tools/microbench/energy_cost.hip) and the
     // cheaper path wins -- cfg 3 +2.5 ... 3.8 %, 16 frames per launch +10 %, 256 +4 %, cfg 4 +0.5 %, the default chain, CFR and
-    // windowing unchanged (tools/exp_store_policy.sh, exp_store_policy2.sh; same-box A/B).  (16-byte stores, which the same
+    // windowing unchanged (tools/experiments/exp_store_policy.sh, exp_store_policy2.sh; same-box A/B).  (16-byte stores, which the same
     // microbenchmark prices a third cheaper per byte, were tried too: neighbouring lanes swap half of their samples by DPP and
     // store pairs -- parity green, -2 % with either policy: the 40 instructions of the swap and two 512-byte halves per store.)  The chains from carriers (cfg 2, the
     // IFFT + FIR stage) ARE bandwidth-bound, at the nominal clock with power to spare, and lose 0 ... 1.5 %: they keep plain stores.
-    // (tool builds only, tools/exp_store_policy.sh: -DDABGPU_STORE_AUX=n forces the policy bits of every variant's stores --
+    // (tool builds only, tools/experiments/exp_store_policy.sh: -DDABGPU_STORE_AUX=n forces the policy bits of every variant's stores --
     // 0 plain, 1 sc0, 2 nt, 16 sc1 and their sums -- so that the A/B behind the figures above can be re-run from the tree)
 #ifdef DABGPU_STORE_AUX
     constexpr int kStoreAux = DABGPU_STORE_AUX;

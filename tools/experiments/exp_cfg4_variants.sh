@@ -2,7 +2,7 @@
 # cfg 4 A/B builds (scratch copies, git-ignored): wave priority around the resampler's exchanges, run lengths.
 # Time with: python tools/time_cfg4.py 4096
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 mk() {   # name, python patch body operating on resampler.hip text `s`
   name=$1; d="$ROOT/tools/_variants/src_$name"
   rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"

@@ -4,9 +4,9 @@
 # hops + the frame kernel's 10 kB): ONE workgroup per CU where today's resampler runs two.  Here the
 # product resampler simply asks for 100 kB of dynamic LDS, so that one workgroup fits a CU.
 # Builds tools/_variants/libdabgpu_{base,rs1wg}.so; time with
-#   DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/exp_r05.py parts
+#   DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/experiments/exp_r05.py parts
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 d="$ROOT/tools/_variants/src_rs1wg"
 rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"

@@ -5,7 +5,7 @@ power probe, after six contexts with lanes have come and gone.  Before the lanes
 own (stream_probe.hip) the answer depended on the history: profiles/r05_lane_queues.txt.  Run on the GPU box, from the
 repository root; GPU_MAX_HW_QUEUES=2 / 8 in the environment shows the runtime's side of it."""
 import importlib, os, sys, time, json
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tools"))
 import torch
 P = importlib.import_module("odr-dabmod_amd")

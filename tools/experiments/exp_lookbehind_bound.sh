@@ -4,9 +4,9 @@
 # of the cfg 3 kernel transforms the symbol AFTER its last one as well (the look-ahead that its last 44 boundary outputs need):
 # 3 transforms for 2 symbols at 16 frames per call on one lane, 4 for 3 on three lanes, 2 for 1 when a single frame is cut
 # into 77 runs.  The scratch copy simply drops the look-ahead iteration of the equalised-boundary variant.
-# Builds tools/_variants/libdabgpu_{base,nolook}.so; time with tools/exp_r05.py lanes (DABGPU_LIB=...).
+# Builds tools/_variants/libdabgpu_{base,nolook}.so; time with tools/experiments/exp_r05.py lanes (DABGPU_LIB=...).
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 d="$ROOT/tools/_variants/src_nolook"
 rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"

@@ -1,13 +1,13 @@
 #!/bin/bash
 # TIMING EXPERIMENT (same samples, same instruction stream): what the cfg 3 frame kernel loses when fewer of its workgroups fit
 # a CU.  A 16-points-per-lane variant (16 . 16 . 8 on 128 lanes: the two-exchange transform whose upper bound is
-# tools/exp_two_exchanges_bound.sh) keeps one 16.6 KB exchange buffer per TWO waves instead of per four, i.e. ~27.5 KB of LDS per
+# tools/experiments/exp_two_exchanges_bound.sh) keeps one 16.6 KB exchange buffer per TWO waves instead of per four, i.e. ~27.5 KB of LDS per
 # 128-lane workgroup: five per CU = 10 waves where today's kernel has 16.  Here the product kernel simply asks for more dynamic
 # LDS than it uses (41 KB -> three workgroups = 12 waves per CU; 54 KB -> two = 8 waves).
 # Builds tools/_variants/libdabgpu_{base,occ3,occ2}.so; time with
-#   DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/exp_r05.py cfg3power 32768
+#   DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/experiments/exp_r05.py cfg3power 32768
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 for v in "occ3 41984" "occ2 55296"; do
   set -- $v

@@ -5,7 +5,7 @@
 # per-lane dword load requested a symbol ahead -- the instruction stream such a kernel would have; the phases it reads are
 # garbage.  Builds tools/_variants/libdabgpu_{base,prek}.so; time with tools/time_cfg3_variants.py.
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 d="$ROOT/tools/_variants/src_prek"
 rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"

@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""Round-5 measurements on one MI355X (python tools/exp_r05.py <what> ...; results as JSON lines on stdout):
+"""Round-5 measurements on one MI355X (python tools/experiments/exp_r05.py <what> ...; results as JSON lines on stdout):
 
   lanes      cfg 3 at B = 1 ... 1024 frames per call on ONE context, 1 ... 4 lanes, HIP-event timed through the two fences
              (dabgpu_wait_for_stream / dabgpu_stream_wait_for) -- what dabgpu_set_lanes buys a ModPlugin-sized caller
@@ -21,7 +21,7 @@ import os
 import sys
 import time
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tools"))
 
@@ -331,7 +331,7 @@ def cfg4lanes(argv):
 
 def cfg3power(argv):
     """cfg 3 (or cfg3 + option) at B frames per launch with board power: one arm of an A/B over libraries
-    (DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/exp_r05.py cfg3power [B] [cfr|nofir|window] [tag])."""
+    (DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/experiments/exp_r05.py cfg3power [B] [cfr|nofir|window] [tag])."""
     B = int(argv[0]) if argv else 32768
     option = argv[1] if len(argv) > 1 and argv[1] != "-" else None
     tag = argv[2] if len(argv) > 2 else os.path.basename(os.environ.get("DABGPU_LIB", "product"))

@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Why is submit/collect bimodal from process to process (s16, 32 frames per batch: 0.46 or 0.86 ms per batch on one box,
 profiles/r06_hostpath_bisect.txt)?  Runs the loop in fresh processes, then under rocprofv3 --memory-copy-trace.
-usage (GPU box): python tools/exp_r06_async_modes.py [child FMT B]"""
+usage (GPU box): python tools/experiments/exp_r06_async_modes.py [child FMT B]"""
 import importlib, os, subprocess, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 
 

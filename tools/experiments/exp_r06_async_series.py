@@ -1,9 +1,9 @@
 #!/usr/bin/env python3
 """Time series of submit / collect (profiles/r06_async_modes.txt: the first repetition of a measurement is slow at 32 frames
 per batch, the SECOND one at 1 frame per batch): per-block means of the time spent inside submit and inside collect.
-usage (GPU box): python tools/exp_r06_async_series.py FMT B N BLOCK [idle_ms]"""
+usage (GPU box): python tools/experiments/exp_r06_async_series.py FMT B N BLOCK [idle_ms]"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 P = importlib.import_module("odr-dabmod_amd")

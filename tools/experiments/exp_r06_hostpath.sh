@@ -1,8 +1,8 @@
 #!/bin/bash
 # Bisect of the asynchronous host path: the SAME box runs tools/time_host_path.py of four source states
 # alternately (library + Python plumbing of each state, built in the build container under tools/_variants/hp_<sha>/).
-# usage (GPU box): bash tools/exp_r06_hostpath.sh > gpurun_out/r06_hostpath_bisect.txt
-cd "$(dirname "$0")/.."
+# usage (GPU box): bash tools/experiments/exp_r06_hostpath.sh > gpurun_out/r06_hostpath_bisect.txt
+cd "$(dirname "$0")/../.."
 export TMPDIR=/tmp
 python -c "import torch" 2>/dev/null
 for round in 1 2; do

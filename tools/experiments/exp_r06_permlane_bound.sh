@@ -17,10 +17,10 @@
 #           the instruction stream with one LDS exchange less and NOTHING in its place -- the absolute upper bound
 #   perm    twoex + the 144 instructions of the transposition levels executed on the transform's registers in its place
 #           (an upper bound still: no second radix-8 stage's twiddles by lane group, no extra registers for the selects)
-# usage: tools/exp_r06_permlane_bound.sh ; then on the GPU box
-#   for l in base twoex perm; do DABGPU_LIB=tools/_variants/libdabgpu_$l.so python tools/exp_r05.py cfg3power 32768; done
+# usage: tools/experiments/exp_r06_permlane_bound.sh ; then on the GPU box
+#   for l in base twoex perm; do DABGPU_LIB=tools/_variants/libdabgpu_$l.so python tools/experiments/exp_r05.py cfg3power 32768; done
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 for v in twoex perm; do
 d="$ROOT/tools/_variants/src_$v"

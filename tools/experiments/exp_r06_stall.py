@@ -2,9 +2,9 @@
 """Where does the ONE ~40 ms stall of a fresh process come from (profiles/r06_async_series_ab.txt: one collect() between
 the 512th and the 1024th one-frame batch, never again)?  Same loop on the synchronous entry point, with one lane, with the
 copy back on the lane's own stream removed (device-resident call + dabgpu_synchronize), and after an idle second.
-usage (GPU box): python tools/exp_r06_stall.py"""
+usage (GPU box): python tools/experiments/exp_r06_stall.py"""
 import importlib, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 import torch

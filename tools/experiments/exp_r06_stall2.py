@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """profiles/r06_stall.txt: plain torch (D2H copy + event record + event synchronize) shows the same one-off stall as
 submit/collect; hipStreamSynchronize loops do not.  Which half is it -- the record or the host-side wait?
-usage (GPU box): python tools/exp_r06_stall2.py"""
+usage (GPU box): python tools/experiments/exp_r06_stall2.py"""
 import time
 import numpy as np
 import torch

@@ -3,7 +3,7 @@
 # same phase of their symbol loops) lose throughput to lockstep -- their LDS and VALU phases colliding instead of interleaving?
 # Scratch builds with a start stagger of (blockIdx >> 8) & 3 quarters of a symbol period.  Time with tools/time_small.py.
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 for q in 20 40 80; do
   d="$ROOT/tools/_variants/src_stag$q"

@@ -3,7 +3,7 @@
 # consecutive samples, so that a symbol went out in 16-byte stores, 1 KB contiguous per wave (four for the body, one or two for the
 # cyclic prefix) instead of ten 512-byte ones?  The scratch build stores the registers it has as if they were such pairs.
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 d="$ROOT/tools/_variants/src_st16"
 rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"

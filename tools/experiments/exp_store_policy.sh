@@ -5,7 +5,7 @@
 # that the flag reached the kernel (a variant that is byte-identical to the product build would be a silent no-op).
 # Time with tools/time_cfg3_variants.py 32768 (cfg 3) or DABGPU_LIB=... python bench.py --no-cpu-baseline --counters off.
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 grep -q "DABGPU_STORE_AUX" "$ROOT/odr-dabmod_amd/csrc/tf_kernel.h" || { echo "tf_kernel.h no longer reads DABGPU_STORE_AUX" >&2; exit 1; }
 for aux in ${@:-0 2 1 16 17 3 18}; do
   name="aux$(printf %02d $aux)"

@@ -2,7 +2,7 @@
 # A/B over every bench workload: non-temporal output stores in the frame kernel (all variants) and in the x4 resampler.
 # Run on the GPU box:  for l in tools/_variants/*.so; do DABGPU_LIB=$l python bench.py --no-cpu-baseline --counters off; done
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 mkdir -p "$ROOT/tools/_variants"
 "$ROOT/tools/variants.sh" base ""
 d="$ROOT/tools/_variants/src_ntall"

@@ -6,9 +6,9 @@
 # single-symbol 2048-point inverse transform (scatter, barriers, gather): the instruction stream of the two-exchange kernel
 # without any of its costs (twice the state per lane at half the waves per CU, radix-16 butterflies, 28 resident twiddles).
 # Builds tools/_variants/libdabgpu_{base,twoex}.so; time with
-#   DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/exp_r05.py cfg3power 32768
+#   DABGPU_LIB=tools/_variants/libdabgpu_x.so python tools/experiments/exp_r05.py cfg3power 32768
 set -e
-ROOT="$(cd "$(dirname "$0")/.." && pwd)"
+ROOT="$(cd "$(dirname "$0")/../.." && pwd)"
 "$ROOT/tools/variants.sh" base ""
 d="$ROOT/tools/_variants/src_twoex"
 rm -rf "$d"; mkdir -p "$d/odr-dabmod_amd" "$d/include"
