@@ -89,6 +89,19 @@ DABGPU_API int dabgpu_get_geometry(const dabgpu_ctx *ctx, dabgpu_geometry *g);
  * constructor argument derived from the sink, src/DabMod.cpp:259-347 */
 DABGPU_API int dabgpu_set_gain(dabgpu_ctx *ctx, int gain_mode, float digital, float normalise,
                                float var_variance);
+/* How a CHAIN call forms the multiplier of gain mode var (computeGainVar, src/GainControl.cpp:251-340).  The reference walks a
+ * symbol with four fp32 running means and four running variances (mean += (x - mean) / count), 2 x N/2 dependent divisions
+ * whose rounding error (up to 5.8e-7 relative, tests/test_oracle_golden.py) is part of its output.
+ *   DABGPU_GAIN_ROUNDING_EXACT (default): the exact population variance inside the frame kernel -- closer to the arithmetic
+ *     the reference approximates, 5.8 ... 6.2e-7 from ITS scalar, one kernel per chain call.
+ *   DABGPU_GAIN_ROUNDING_REFERENCE: the reference's recurrence operation for operation, as the stand-alone stage
+ *     (dabgpu_gain_process) does: the frame kernel stops after OfdmGenerator, a kernel of four lanes per symbol replays the
+ *     recurrence, the symbols are scaled in place and the guard interval / FIRFilter run as kernels of their own.  The gain
+ *     scalars then equal the reference's bit for bit on the same symbols (along a chain: within 2.3e-7, the recurrence's own
+ *     sensitivity to the last bits of its input; chain total 2.5e-7 instead of 6.3e-7); cfg 3 runs at about a quarter of its rate.
+ * No effect on gain modes fix and max (their scalars are exact either way).  Takes effect at the next *_process call. */
+enum { DABGPU_GAIN_ROUNDING_EXACT = 0, DABGPU_GAIN_ROUNDING_REFERENCE = 1 };
+DABGPU_API int dabgpu_set_gain_rounding(dabgpu_ctx *ctx, int rounding);
 /* FIRFilter::load_filter_taps, src/FIRFilter.cpp:95-141 (n <= 512; up to 128 taps run fused) */
 DABGPU_API int dabgpu_set_fir_taps(dabgpu_ctx *ctx, const float *taps, size_t n);
 /* FIRFilter("default"): the built-in 45 taps, src/FIRFilter.cpp:59-71 */

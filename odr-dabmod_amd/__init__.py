@@ -35,7 +35,7 @@ EXPORTS = [
     "dabgpu_set_output_format", "dabgpu_get_num_clipped", "dabgpu_fir_inverse_design",
     "dabgpu_set_fir_boundary_mode", "dabgpu_debug_last_variant", "dabgpu_debug_trace",
     "dabgpu_set_lanes", "dabgpu_wait_for_stream", "dabgpu_stream_wait_for", "dabgpu_set_handover_frames",
-    "dabgpu_post_process_dev", "dabgpu_debug_lanes",
+    "dabgpu_post_process_dev", "dabgpu_debug_lanes", "dabgpu_set_gain_rounding",
 ]
 
 FORMATS = {"s16": (1, np.int16), "u8": (2, np.uint8), "s8": (3, np.int8)}
@@ -114,6 +114,7 @@ def load_library():
     lib.dabgpu_set_fir_default_taps.argtypes = [vp]
     lib.dabgpu_set_window_overlap.argtypes = [vp, sz]
     lib.dabgpu_set_fir_boundary_mode.argtypes = [vp, C.c_int]
+    lib.dabgpu_set_gain_rounding.argtypes = [vp, C.c_int]
     lib.dabgpu_debug_last_variant.argtypes = [vp, C.c_char_p, sz]
     lib.dabgpu_debug_trace.argtypes = [vp, C.c_int]
     lib.dabgpu_set_resampler.argtypes = [vp, sz, sz]
@@ -370,6 +371,11 @@ class Modulator:
         """False (default): boundary outputs of the fused FIRFilter through the taps' inverse where one exists;
         True: always the direct sum over the unfiltered samples (packed dual transform)."""
         self._chk(self._lib.dabgpu_set_fir_boundary_mode(self._h, 1 if direct else 0))
+
+    def set_gain_rounding(self, reference):
+        """False (default): gain mode var from the exact variance inside the frame kernel; True: chain calls replay the
+        reference's running fp32 recurrence (src/GainControl.cpp:251-340) -- its scalars bit for bit, separate kernels."""
+        self._chk(self._lib.dabgpu_set_gain_rounding(self._h, 1 if reference else 0))
 
     def trace(self, enable=True):
         """Turn the launch trace behind last_variant() on or off (off by default)."""

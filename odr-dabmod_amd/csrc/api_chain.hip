@@ -153,6 +153,12 @@ int fused_ntaps(const dabgpu_ctx *c)
     return (n >= 1 && n < 45) ? 45 : (int)n;
 }
 
+// gain mode var by the reference's recurrence (dabgpu_set_gain_rounding): the chain call is split at GainControl
+bool gain_replay(const dabgpu_ctx *c, unsigned mask)
+{
+    return c->cur.gain_reference_rounding && c->cur.gain_mode == DABGPU_GAIN_VAR && (mask & DABGPU_STAGE_GAIN);
+}
+
 int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, unsigned mask, bool windowed,
                float2 *native_out, size_t native, float *gain1, hipStream_t s, bool keep_stats,
                unsigned long long *s16_clipped, const float2 *tii_seg, bool *tii_done, int fused_fmt)
@@ -206,6 +212,38 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
     }
 
     a.overlap = (int)c->cur.overlap;
+    const bool replay = gain_replay(c, mask);
+    if (replay) {
+        // OfdmGenerator (+ CFR) alone, then the reference's recurrence on the unscaled symbols and the multipliers applied in
+        // place (src/GainControl.cpp:118-155), then guard interval / FIRFilter as kernels of their own
+        flags &= ~(unsigned)TF_GAIN;
+        a.gain1 = nullptr;
+        const int nsym = c->g.nb_symbols + 1;
+        const size_t nsymN = (size_t)nsym * (size_t)c->g.N;
+        const bool noguard = mask & DABGPU_STAGE_NOGUARD;
+        float2 *x0 = native_out;
+        if (!noguard) {
+            HIPCHK(c, c->d_b.reserve(n_frames * nsymN * sizeof(float2)));
+            x0 = (float2 *)c->d_b.p;
+        }
+        a.chunks_per_frame = auto_chunks(c, n_frames);
+        a.syms_per_chunk = run_symbols(nsym, a.chunks_per_frame, false);
+        a.out = x0;
+        a.out_stride = noguard ? native : nsymN;
+        if (noguard && native != nsymN) return fail(c, DABGPU_E_DEVICE, "gain rounding: unexpected frame stride");
+        HIPCHK(c, launch_tf(a, flags, s));
+        HIPCHK(c, c->d_gains.reserve(n_frames * (size_t)nsym * sizeof(float)));
+        HIPCHK(c, launch_gain_replay(x0, n_frames, nsym, c->g.N, a.gain, (float *)c->d_gains.p, from_bits ? gain1 : nullptr, s));
+        if (noguard) return DABGPU_OK;
+        if (mask & DABGPU_STAGE_FIR)
+            HIPCHK(c, launch_guard_fir(x0, n_frames, c->g, (int)c->cur.overlap, (const float *)c->d_window.p,
+                                       c->cur.taps.data(), (int)c->cur.taps.size(), native_out, s));
+        else if (c->cur.overlap > 0)
+            HIPCHK(c, launch_guard_window(x0, n_frames, c->g, (int)c->cur.overlap, (const float *)c->d_window.p, native_out, s));
+        else
+            HIPCHK(c, launch_guard_copy(x0, n_frames, c->g, native_out, s));
+        return DABGPU_OK;
+    }
     if (!windowed) {
         if (!(mask & DABGPU_STAGE_NOGUARD)) flags |= TF_GUARD;
         if (mask & DABGPU_STAGE_FIR) flags |= TF_FIR;
@@ -438,6 +476,7 @@ int run_chain(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames, 
                         resampler_has_s16(ra) && poly_ok;
         }
     }
+    if (gain_replay(c, mask)) fuse_native = false;     // (the frame kernel is not the chain's last kernel then)
     float2 *d_out = (float2 *)d_out_v;
     if (fmt && !fuse_native && !fuse_post) {
         HIPCHK(c, c->d_fmt.reserve(n_frames * per * sizeof(float2)));

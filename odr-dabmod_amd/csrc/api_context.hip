@@ -502,7 +502,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     for (DevBuf *b : {&c->d_twiddle, &c->d_src, &c->d_dst, &c->d_phq, &c->d_mag, &c->d_taps, &c->d_firh, &c->d_eqg,
                       &c->d_window, &c->d_coef, &c->d_rs_window, &c->d_rs_tw_in, &c->d_rs_tw_out,
                       &c->d_rs_halo, &c->d_rs_tw_s, &c->d_rs_tw_l, &c->d_a, &c->d_b, &c->d_c, &c->d_in, &c->d_out, &c->d_count, &c->d_fmt, &c->d_clip, &c->d_phase,
-                      &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1, &c->d_cic,
+                      &c->d_acp, &c->d_tii_car, &c->d_tii_frame, &c->d_gain1, &c->d_gains, &c->d_cic,
                       &c->d_cfr_counts, &c->d_cfr_mer, &c->d_cfr_papr, &c->d_cfr_tmp})
         b->release();
     for (auto &sl : c->slot) {
@@ -518,7 +518,7 @@ void dabgpu_destroy(dabgpu_ctx *c)
     for (auto &l : c->lane) {
         if (l.stream) { (void)hipStreamSynchronize(l.stream); (void)hipStreamDestroy(l.stream); }
         if (l.ev) (void)hipEventDestroy(l.ev);
-        for (DevBuf *b : {&l.d_a, &l.d_b, &l.d_fmt, &l.d_clip, &l.d_gain1, &l.d_cfr_counts, &l.d_cfr_mer, &l.d_cfr_papr, &l.d_cfr_tmp})
+        for (DevBuf *b : {&l.d_a, &l.d_b, &l.d_fmt, &l.d_clip, &l.d_gain1, &l.d_gains, &l.d_cfr_counts, &l.d_cfr_mer, &l.d_cfr_papr, &l.d_cfr_tmp})
             b->release();
     }
     for (hipEvent_t e : {c->ho_prod[0], c->ho_prod[1], c->ho_cons[0], c->ho_cons[1], c->ho_start, c->ho_join, c->own_ev})
@@ -551,6 +551,19 @@ int dabgpu_set_gain(dabgpu_ctx *c, int gain_mode, float digital, float normalise
         return DABGPU_OK;
     c->set.gain_mode = gain_mode; c->set.digital = digital; c->set.normalise = normalise;
     c->set.var_variance = var_variance;
+    ++c->set.epoch;
+    return DABGPU_OK;
+}
+
+int dabgpu_set_gain_rounding(dabgpu_ctx *c, int rounding)
+{
+    if (!c) return DABGPU_E_INVALID;
+    if (rounding != DABGPU_GAIN_ROUNDING_EXACT && rounding != DABGPU_GAIN_ROUNDING_REFERENCE)
+        return fail(c, DABGPU_E_INVALID, "invalid gain rounding");
+    std::lock_guard<std::mutex> lk(c->mu);
+    const bool ref = rounding == DABGPU_GAIN_ROUNDING_REFERENCE;
+    if (c->set.gain_reference_rounding == ref) return DABGPU_OK;
+    c->set.gain_reference_rounding = ref;
     ++c->set.epoch;
     return DABGPU_OK;
 }

@@ -44,6 +44,7 @@ struct DevBuf {
 struct Settings {
     int gain_mode = DABGPU_GAIN_VAR;      // src/ConfigParser.h:60-91 defaults
     float digital = 1.0f, normalise = 1.0f, var_variance = 4.0f;
+    bool gain_reference_rounding = false;  // dabgpu_set_gain_rounding: chain calls replay the reference's variance recurrence
     std::vector<float> taps;
     size_t overlap = 0;
     size_t rs_in = 2048000, rs_out = 2048000;
@@ -121,6 +122,7 @@ struct dabgpu_ctx {
     hipStream_t clip_stream = nullptr;     // stream of the most recent chain call that converted its output
     // TII (f-4): carrier set, the one-frame carrier image and its native-rate response, gain of symbol 1
     dabgpu_api::DevBuf d_acp, d_tii_car, d_tii_frame, d_gain1, d_cic;
+    dabgpu_api::DevBuf d_gains;           // gain rounding REFERENCE: the multipliers of a call's symbols
     size_t cic_spacing = 0;               // what d_cic was built for (CicEqualizer, a12)
     int cic_R = 0;
     // CFR statistics (f-3) of the most recent chain / OfdmGenerator call, and a scratch set for internal runs
@@ -144,7 +146,7 @@ struct dabgpu_ctx {
     struct Lane {
         hipStream_t stream = nullptr;
         hipEvent_t ev = nullptr;
-        dabgpu_api::DevBuf d_a, d_b, d_fmt, d_clip, d_gain1, d_cfr_counts, d_cfr_mer, d_cfr_papr, d_cfr_tmp;
+        dabgpu_api::DevBuf d_a, d_b, d_fmt, d_clip, d_gain1, d_gains, d_cfr_counts, d_cfr_mer, d_cfr_papr, d_cfr_tmp;
     };
     enum { kMaxLanes = 4, kLaneMaxFrames = 2048, kLaneScratchBytes = 256 << 20 };
     Lane lane[kMaxLanes];                 // (entry 0: only `ev` is used)
@@ -231,7 +233,7 @@ struct LaneScope {
         if (i == 0) return;
         dabgpu_ctx::Lane &l = c->lane[i];
         std::swap(c->d_a, l.d_a); std::swap(c->d_b, l.d_b); std::swap(c->d_fmt, l.d_fmt); std::swap(c->d_clip, l.d_clip);
-        std::swap(c->d_gain1, l.d_gain1); std::swap(c->d_cfr_counts, l.d_cfr_counts); std::swap(c->d_cfr_mer, l.d_cfr_mer);
+        std::swap(c->d_gain1, l.d_gain1); std::swap(c->d_gains, l.d_gains); std::swap(c->d_cfr_counts, l.d_cfr_counts); std::swap(c->d_cfr_mer, l.d_cfr_mer);
         std::swap(c->d_cfr_papr, l.d_cfr_papr); std::swap(c->d_cfr_tmp, l.d_cfr_tmp);
     }
 };

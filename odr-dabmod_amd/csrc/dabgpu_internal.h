@@ -119,6 +119,10 @@ hipError_t launch_diff_mod(const float2 *phase, const float2 *data, size_t nsym_
                            float2 *out, hipStream_t s);
 hipError_t launch_gain(const float2 *in, size_t nsym, int N, GainParams gp, float2 *out,
                        hipStream_t s);
+// gain mode var with the reference's running recurrence (chain calls under dabgpu_set_gain_rounding(ctx, 1)): x0 holds
+// n_frames x nsym unscaled symbols of N samples; scaled in place, the multipliers left in gains[n_frames * nsym]
+hipError_t launch_gain_replay(float2 *x0, size_t n_frames, int nsym, int N, GainParams gp, float *gains, float *gain1,
+                              hipStream_t s);
 hipError_t launch_guard_copy(const float2 *in, size_t n_frames, Geometry g, float2 *out,
                              hipStream_t s);
 hipError_t launch_guard_window(const float2 *in, size_t n_frames, Geometry g, int overlap,

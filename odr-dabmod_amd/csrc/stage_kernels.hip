@@ -82,27 +82,50 @@ __global__ void diff_mod_kernel(const cf *__restrict__ phase, const cf *__restri
 // while the rest of the workgroup waits: ~2 x N/2 dependent divisions per symbol, microseconds, and the drop-in
 // stage then returns the reference's gain BIT FOR BIT instead of the exact population variance the fused chain
 // uses (which differs from this recurrence by up to 5e-7 relative).  Products and sums are rounded separately.
+// (sym may be global memory: the samples of sixteen steps are requested together, a block ahead of the serial chain that
+// consumes them -- nvec is a multiple of 16 for every transmission mode, N / 2 >= 128)
 DEV float gain_var_replay(const float *sym, int nvec, float var_variance, int l)
 {
 #pragma clang fp contract(off)
+    constexpr int kAhead = 16;
     float mean = 0.f;
-    for (int v = 0; v < nvec; ++v) {
-        const float d = sym[4 * v + l] - mean;
-        mean = mean + d / (float)(v + 1);
+    float cur[kAhead], nxt[kAhead];
+#pragma unroll
+    for (int i = 0; i < kAhead; ++i) cur[i] = sym[4 * i + l];
+    for (int v0 = 0; v0 < nvec; v0 += kAhead) {
+        const int vn = v0 + kAhead < nvec ? v0 + kAhead : 0;             // (the last block requests the first again: pass 2 starts there)
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) nxt[i] = sym[4 * (vn + i) + l];
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const float d = cur[i] - mean;
+            mean = mean + d / (float)(v0 + i + 1);
+        }
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) cur[i] = nxt[i];
     }
     // lanes {0,2} hold re, {1,3} hold im
     const float other = __shfl_xor(mean, 2, 64);
     const float m2 = (mean + other) * 0.5f;
     float var = 0.f;
-    for (int v = 0; v < nvec; ++v) {
-        const float diff = sym[4 * v + l] - m2;
-        const float sq = diff * diff;
-        const float d = sq - var;
-        var = var + d / (float)(v + 1);
+    for (int v0 = 0; v0 < nvec; v0 += kAhead) {
+        const int vn = v0 + kAhead < nvec ? v0 + kAhead : v0;
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) nxt[i] = sym[4 * (vn + i) + l];
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) {
+            const float diff = cur[i] - m2;
+            const float sq = diff * diff;
+            const float d = sq - var;
+            var = var + d / (float)(v0 + i + 1);
+        }
+#pragma unroll
+        for (int i = 0; i < kAhead; ++i) cur[i] = nxt[i];
     }
     const float merged = (var + __shfl_xor(var, 2, 64)) * 0.5f;       // lanes 0 and 1: re and im
     const float sd = sqrtf(merged) * var_variance;
-    const float sd_re = __shfl(sd, 0, 64), sd_im = __shfl(sd, 1, 64);
+    const int quad = (int)(threadIdx.x & 63u) & ~3;                       // (every group of four lanes walks a symbol of its own)
+    const float sd_re = __shfl(sd, quad, 64), sd_im = __shfl(sd, quad + 1, 64);
     if ((int)sd_re == 0) return 1.0f;
     return 32767.0f / (sd_re > sd_im ? sd_re : sd_im);
 }
@@ -147,6 +170,48 @@ template <int LOGN> __global__ void gain_kernel(const cf *__restrict__ in, size_
         const cf x = in[s * N + t + T * m];
         out[s * N + t + T * m] = cscale(x, g);
     }
+}
+
+// The reference's gain scalars inside a CHAIN call (dabgpu_set_gain_rounding(ctx, 1); src/GainControl.cpp:251-340): the
+// recurrence is serial in the sample index, so a chain that wants it bit for bit cannot form it inside the frame kernel
+// (2 x N/2 dependent divisions per symbol against a few microseconds per symbol there).  Instead the frame kernel stops
+// after the IFFT, this kernel walks SIXTEEN symbols per wave -- four lanes each, one per SSE lane, straight from the
+// unscaled symbols in memory (sixteen 16-byte segments per load, every line read twice and served by the cache the
+// second time) -- and gain_apply_kernel scales the symbols in place before the guard interval / FIRFilter kernels.
+// gains[frame * nsym + s] = scalar(symbol s) * constant, the two roundings of src/GainControl.cpp:146-155.
+__global__ void gain_replay_kernel(const cf *__restrict__ x0, size_t total_syms, int N, GainParams gp,
+                                   float *__restrict__ gains)
+{
+    const size_t sym = (size_t)blockIdx.x * 16 + (threadIdx.x >> 2);
+    const bool on = sym < total_syms;
+    const float *p = reinterpret_cast<const float *>(x0 + (on ? sym : 0) * (size_t)N);
+    const float gv = gain_var_replay(p, N / 2, gp.var_variance, threadIdx.x & 3);
+    float g;
+    {
+#pragma clang fp contract(off)
+        g = gv * gp.constant;
+    }
+    if (on && (threadIdx.x & 3) == 0) gains[sym] = g;
+}
+
+// x[frame][s][n] *= gains[frame][s], symbol 0 with symbol 1's (src/GainControl.cpp:139-144); gain1[frame] = the multiplier
+// of symbol 1 (what the TII null symbol is scaled by).  Four samples per lane.
+__global__ void gain_apply_kernel(cf *__restrict__ x0, size_t n_frames, int nsym, int N, const float *__restrict__ gains,
+                                  float *__restrict__ gain1)
+{
+    const size_t per_sym = (size_t)N / 4;                 // lanes per symbol
+    const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_frames * (size_t)nsym * per_sym) return;
+    const size_t symi = i / per_sym, f = symi / (size_t)nsym;
+    const int s = (int)(symi % (size_t)nsym);
+    const int src = (s == 0 && nsym > 1) ? 1 : s;
+    const float g = gains[f * (size_t)nsym + (size_t)src];
+    if (gain1 && s == (nsym > 1 ? 1 : 0) && i % per_sym == 0) gain1[f] = g;
+    float4 *q = reinterpret_cast<float4 *>(x0 + symi * (size_t)N) + 2 * (i % per_sym);
+    float4 a = q[0], b = q[1];
+    a.x *= g; a.y *= g; a.z *= g; a.w *= g;
+    b.x *= g; b.y *= g; b.z *= g; b.w *= g;
+    q[0] = a; q[1] = b;
 }
 
 // a8 GuardIntervalInserter as a gather: sample p of a frame's output stream from the frame's
@@ -406,6 +471,17 @@ hipError_t launch_gain(const float2 *in, size_t nsym, int N, GainParams gp, floa
         case 2048: DABGPU_LAUNCH(gain_kernel<11>, grid, dim3(256), 0, s, in, nsym, gp, out); break;
         default: return hipErrorInvalidValue;
     }
+    return hipGetLastError();
+}
+
+hipError_t launch_gain_replay(float2 *x0, size_t n_frames, int nsym, int N, GainParams gp, float *gains, float *gain1,
+                              hipStream_t s)
+{
+    const size_t total = n_frames * (size_t)nsym;
+    if (total == 0) return hipSuccess;
+    DABGPU_LAUNCH(gain_replay_kernel, dim3(blocks_for(total, 16)), dim3(64), 0, s, x0, total, N, gp, gains);
+    DABGPU_LAUNCH(gain_apply_kernel, dim3(blocks_for(total * (size_t)(N / 4), 256)), dim3(256), 0, s, x0, n_frames, nsym, N,
+                  gains, gain1);
     return hipGetLastError();
 }
 

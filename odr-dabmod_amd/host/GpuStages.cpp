@@ -900,6 +900,7 @@ DabGpuChain::DabGpuChain(const Settings &s, const LiveSettings &live)
         m_rc_gain.reset(new GainParameters(dev, gainMode, digitalGain, s.normalise, variance));
         m_rc_gain->push_settings();
     }
+    if (s.referenceGainRounding) m_ctx.check(dabgpu_set_gain_rounding(dev, DABGPU_GAIN_ROUNDING_REFERENCE));
     m_rc_guard.reset(new GuardParameters(dev, overlap));
     if (!tapsFile.empty()) {
         m_mask |= DABGPU_STAGE_FIR;

@@ -19,6 +19,8 @@
 //   --bits-only          stop after the front-end: write the hot path's input blocks (no GPU needed)
 //   --reference-latency  emit exactly the frames the reference emits: one transmission frame fewer per pipelined stage
 //                        of the equivalent reference graph (GainControl, FIRFilter, MemlessPoly: src/ModPlugin.cpp:90-115)
+//   --reference-gain     gain mode var: the reference's running fp32 recurrence (src/GainControl.cpp:251-340) instead of the
+//                        exact variance (DabGpuChain::Settings::referenceGainRounding)
 #include "Frontend.h"
 #include "GpuStages.h"
 
@@ -38,7 +40,8 @@ namespace {
                          "       [--digital G] [--normalise X] [--var V] [--fir none|default|file] [--rate R] [--poly file]\n"
                          "       [--ofdmwindowing W] [--tii comb,pattern] [--cfr clip,errorclip] [--loop N] [--bits-only]\n"
                          "       [--batch N]   N transmission frames per GPU call, two calls in flight (default 1: frame by frame)\n"
-                         "       [--reference-latency]   drop the frames the reference's pipelined stages never emit\n");
+                         "       [--reference-latency]   drop the frames the reference's pipelined stages never emit\n"
+                         "       [--reference-gain]      gain mode var by the reference's running recurrence (bit-equal scalars, slower)\n");
     std::exit(2);
 }
 }  // namespace
@@ -88,6 +91,7 @@ int main(int argc, char **argv)
             else if (a == "--bits-only") bits_only = true;
             else if (a == "--batch") batch = std::max<size_t>(1, std::stoul(val()));
             else if (a == "--reference-latency") reference_latency = true;
+            else if (a == "--reference-gain") gs.referenceGainRounding = true;
             else usage();
         }
 

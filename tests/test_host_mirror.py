@@ -279,6 +279,34 @@ def test_config1_eti_file_to_iq_file(tmp_path, fmt):
         assert got.size == want.size and d.max() <= 1 and (d != 0).mean() < int_off_by_one_limit(want)
 
 
+@pytest.mark.gpu
+def test_config1_with_the_reference_gain_rounding(tmp_path):
+    """dabmod_file --reference-gain (DabGpuChain::Settings::referenceGainRounding -> dabgpu_set_gain_rounding): config 1 with
+    the reference's var-gain recurrence replayed; the file is closer to the oracle's than the default's (whose exact
+    variance is up to 6e-7 from the reference's scalar) -- max-abs of the largest sample 4e-7 against 7e-7."""
+    import importlib
+    import oracle as O
+    from tests.conftest import record_bound
+    from tests.golden.synth import synth_eti
+    build_host()
+    fe_mod = importlib.import_module("odr-dabmod_amd.frontend")
+    eti = synth_eti(24)
+    fin, fa, fb = str(tmp_path / "in.eti"), str(tmp_path / "a.iq"), str(tmp_path / "b.iq")
+    eti.tofile(fin)
+    tool = os.path.join(HOST, "dabmod_file")
+    for out, extra in ((fa, []), (fb, ["--reference-gain"])):
+        r = subprocess.run([tool, fin, out] + extra, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+    bits = fe_mod.Frontend().eti_to_bits(eti, 1)
+    ref = O.Chain(mode=1, stages=O.STAGE_GAIN, gain_mode=2, normalise=1.0).process(bits)
+    a = np.fromfile(fa, dtype=np.complex64).reshape(6, -1)
+    b = np.fromfile(fb, dtype=np.complex64).reshape(6, -1)
+    ea, eb = (np.abs(y - ref).max() / np.abs(ref).max() for y in (a, b))
+    assert record_bound("cfg 1 file, gain rounding REFERENCE, max-abs / |out|_inf against the reference", eb, 4e-7)
+    assert record_bound("cfg 1 file, exact variance, max-abs / |out|_inf against the reference", ea, 8e-7)
+    assert eb < ea and not np.array_equal(a, b)
+
+
 POLY_AM = (1.0, 0.05, -0.01, 0.002, 0.0)       # the non-identity set of SURVEY 8 a13 / cfg 4
 POLY_PM = (0.0, 0.02, 0.003, 0.0, 0.0)
 
