@@ -12,8 +12,9 @@
 #                     -- and the enrolment of its remote-controllables; the wiring from "connect(cifPart, cifMap)" to the
 #                     end of the plugin loop becomes two connects; "num_clipped_samples" reads the chain.
 #   DabModulator.h    one member more: std::shared_ptr<DabGpuChain> m_gpuChain.
-#   ConfigParser.h    one setting more in mod_settings_t: gpuReferenceLatency (the reference's start-up frame count,
-#                     DabGpuChain::Settings::emulatePipelineDrops; default off).
+#   ConfigParser.h    two settings more in mod_settings_t: gpuReferenceLatency (the reference's start-up frame count,
+#                     DabGpuChain::Settings::emulatePipelineDrops) and gpuReferenceGain (gain mode var by the reference's
+#                     running recurrence, DabGpuChain::Settings::referenceGainRounding); both default off.
 set -e
 dst=${1:?usage: install_fused.sh <copy of the reference src/ with the drop-in headers installed>}
 [ -f "$dst/GpuStages.h" ] || { echo "run install_dropins.sh on $dst first" >&2; exit 1; }
@@ -65,6 +66,7 @@ function construct() {
     print "        gs.cfrErrorClip = m_settings.cfrErrorClip;"
     print "        gs.outputFormat = m_format.empty() ? \"complexf\" : m_format;"
     print "        if (m_settings.gpuReferenceLatency) gs.emulatePipelineDrops = gs.referencePipelineDepth();"
+    print "        gs.referenceGainRounding = m_settings.gpuReferenceGain;"
     print "        DabGpuChain::LiveSettings live;     // the remote control writes where the reference keeps these values"
     print "        live.gainMode = &m_settings.gainMode;"
     print "        live.digitalGain = &m_settings.digitalgain;"
@@ -98,6 +100,6 @@ function construct() {
 
 awk '{ print } index($0, "std::shared_ptr<FormatConverter> m_formatConverter;") { print "    std::shared_ptr<DabGpuChain> m_gpuChain;   // install_fused.sh" }' \
     "$hdr" > "$dst/DabModulator.h"
-awk '{ print } index($0, "bool showProcessTime = true;") { print "    bool gpuReferenceLatency = false;   // install_fused.sh: DabGpuChain::Settings::emulatePipelineDrops" }' \
+awk '{ print } index($0, "bool showProcessTime = true;") { print "    bool gpuReferenceLatency = false;   // install_fused.sh: DabGpuChain::Settings::emulatePipelineDrops"; print "    bool gpuReferenceGain = false;      // install_fused.sh: DabGpuChain::Settings::referenceGainRounding" }' \
     "$cfg" > "$dst/ConfigParser.h"
 rm -f "$cpp" "$hdr" "$cfg"

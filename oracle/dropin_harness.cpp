@@ -29,6 +29,7 @@
  *   --show-metadata 1         one line "meta K: FCT FCT FCT FCT" on stdout per frame the sink writes: the frame counts of the
  *                             metadata that ARRIVED WITH output frame K (src/Flowgraph.cpp:146-175 moves it along the edges)
  *   --reference-latency 1     (fused build) mod_settings_t::gpuReferenceLatency: the reference's start-up frame count
+ *   --reference-gain 1        (fused build) mod_settings_t::gpuReferenceGain: gain mode var by the reference's recurrence
  */
 #include "DabModulator.h"
 #include "EtiReader.h"
@@ -107,6 +108,7 @@ int main(int argc, char **argv)
         else if (k == "--cfr") { s.enableCfr = true; sscanf(v.c_str(), "%f,%f", &s.cfrClip, &s.cfrErrorClip); }
 #ifdef DABGPU_FUSED_BUILD
         else if (k == "--reference-latency") s.gpuReferenceLatency = v != "0";
+        else if (k == "--reference-gain") s.gpuReferenceGain = v != "0";
 #endif
         else if (k == "--rc") {
             RcAction a;

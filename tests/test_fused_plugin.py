@@ -234,6 +234,34 @@ def test_fused_plugin_inside_the_reference_graph_builder(tmp_path, cfg):
 
 @pytest.mark.gpu
 @have_fused
+@pytest.mark.parametrize("cfg", ["cfg1", "cfg3"])
+def test_fused_plugin_with_the_reference_gain_rounding(tmp_path, cfg):
+    """mod_settings_t::gpuReferenceGain -> DabGpuChain::Settings::referenceGainRounding -> dabgpu_set_gain_rounding: the one
+    fused node then forms the var-gain multipliers by the reference's recurrence (src/GainControl.cpp:251-340), as the
+    per-stage GainControl drop-in inside dabmod_dropin does -- same transform, same recurrence, same filter arithmetic: the
+    two graphs write the same bytes, and both are closer to the oracle than the fused default (exact variance)."""
+    from tests.conftest import record_bound
+    fin, bits = _eti(tmp_path)
+    n = bits.shape[0]
+    args, drops, _, chain = _cfg(tmp_path, cfg)
+    f_ref, f_def, f_drop = (str(tmp_path / x) for x in ("refgain.iq", "default.iq", "dropin.iq"))
+    _run(FUSED, fin, f_ref, args + ["--reference-gain", "1"])
+    _run(FUSED, fin, f_def, args)
+    _run(DROPIN, fin, f_drop, args)
+    ref = chain.process(bits)
+    a = np.fromfile(f_ref, dtype=np.complex64).reshape(-1, ref.shape[1])
+    b = np.fromfile(f_def, dtype=np.complex64).reshape(-1, ref.shape[1])
+    per_stage = np.fromfile(f_drop, dtype=np.complex64).reshape(-1, ref.shape[1])
+    assert a.shape[0] == n == b.shape[0] and per_stage.shape[0] == n - drops
+    assert np.array_equal(a[:n - drops].view(np.uint32), per_stage.view(np.uint32))
+    ea, eb = (np.abs(y - ref).max() / np.abs(ref).max() for y in (a, b))
+    assert record_bound("dabmod_fused %s, gain rounding REFERENCE, max-abs / |out|_inf against the oracle" % cfg, ea, 4e-7)
+    assert record_bound("dabmod_fused %s, exact variance, max-abs / |out|_inf against the oracle" % cfg, eb, 8e-7)
+    assert ea < eb
+
+
+@pytest.mark.gpu
+@have_fused
 def test_fused_plugin_remote_control_through_the_reference_registry(tmp_path):
     """rcs.set_param("gain", "digital", ...) etc. -- the reference's own RemoteControllers (lib/RemoteControl.cpp) on
     the controllables DabGpuChain enrolled -- between two transmission frames: the frames before the change are byte
