@@ -77,6 +77,7 @@ int pick_lane(dabgpu_ctx *c, size_t n_frames, unsigned mask, bool *rotating)
     {
         std::lock_guard<std::mutex> lk(c->mu);
         scratch = c->set.overlap > 0 || c->set.out_format != 0 || c->set.cfr_enable || c->set.tii_enable ||
+                  (c->set.gain_reference_rounding && c->set.gain_mode == DABGPU_GAIN_VAR && (mask & DABGPU_STAGE_GAIN)) ||
                   (mask & DABGPU_STAGE_POLY) || (int)c->set.taps.size() > tf_max_fused_taps();
     }
     if (scratch && n_frames * 2 * tf_samples(c->g) * sizeof(float2) > (size_t)dabgpu_ctx::kLaneScratchBytes) return 0;
