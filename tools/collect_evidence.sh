@@ -17,6 +17,12 @@ done
 [ -f $G/measured_bounds.jsonl ] && cp $G/measured_bounds.jsonl $P/${tag}_measured_bounds.jsonl
 [ -f $G/dispatch_matrix.txt ] && cp $G/dispatch_matrix.txt $P/${tag}_dispatch_matrix.txt
 [ -f $G/d2h.txt ] && cp $G/d2h.txt $P/${tag}_d2h_pageable.txt
+# (tools/evidence_run.sh: the bench line, the modes' rates and counters, the gain roundings' rates, the -m gpu suite's log)
+[ -s $G/${tag}_bench_line.json ] && cp $G/${tag}_bench_line.json $P/${tag}_bench_line.json
+[ -s $G/${tag}_small_modes_final.txt ] && cp $G/${tag}_small_modes_final.txt $P/${tag}_small_modes_final.txt
+[ -s $G/${tag}_modes_counters.txt ] && cp $G/${tag}_modes_counters.txt $P/${tag}_modes_counters.txt
+[ -s $G/${tag}_gain_rounding_rates.txt ] && cp $G/${tag}_gain_rounding_rates.txt $P/${tag}_gain_rounding_rates.txt
+[ -s $G/final_tests.log ] && tail -40 $G/final_tests.log > $P/${tag}_gpu_tests.txt
 python3 $R/tools/isa_mix.py --json $P/isa_mix.json > /dev/null
 python3 $R/tools/make_traffic.py $G/prof_$tag cfg3=$B3 cfg2=$BO ifft_fir_stage=$BO cfg4=$B4 > /dev/null
 python3 $R/tools/readme_dispatch.py > /dev/null
