@@ -180,3 +180,35 @@ def test_other_gain_modes_are_untouched_and_bad_values_refused(pkg):
             md._chk(md._lib.dabgpu_set_gain_rounding(md._h, 7))
     finally:
         md.close()
+
+
+def test_symbols_entry_point_empty_batch_and_zero_variance(pkg):
+    """dabgpu_symbols_process_dev (carriers in) takes the same split path -- the same bytes as the coded-bits entry, whose carriers
+    the oracle's front stages reproduce bit for bit; an empty batch is an empty batch; var_variance = 0 is the reference's
+    "(int)(var_variance sigma) == 0 -> gain 1" (src/GainControl.cpp:324-331)."""
+    import torch
+    md = pkg.Modulator(mode=1, max_frames=2)
+    try:
+        _var(md)
+        per, K, N = md.geometry["tf_input_bytes"], md.geometry["carriers"], md.geometry["spacing"]
+        bits = np.stack([synth_bits(per, seed=5300 + i) for i in range(2)])
+        pr, _ = O.phase_reference(1)
+        car = np.stack([O.signal_mux(np.zeros(K, np.complex64), O.diff_mod(pr, O.freq_interleave(O.qpsk_map(b, K), 1), K))
+                        for b in bits])
+        stages = pkg.STAGE_GAIN | pkg.STAGE_FIR
+        ns = md.out_samples_per_frame(stages)
+        a = torch.empty((2, ns), dtype=torch.complex64, device="cuda")
+        b = torch.empty((2, ns), dtype=torch.complex64, device="cuda")
+        md.chain_dev(torch.from_numpy(bits).cuda(), 2, stages, a)
+        md.symbols_dev(torch.from_numpy(car).cuda(), 2, stages, b)
+        assert torch.equal(a, b)
+        assert md.chain_dev(torch.from_numpy(bits).cuda(), 0, stages, a) == 0
+        # var_variance 0: every symbol at gain 1 x constant
+        md.set_gain(2, 0.5, 1.0 / 50000.0, 0.0)
+        x = md.chain(bits, pkg.STAGE_NOGUARD)
+        y = md.chain(bits, pkg.STAGE_NOGUARD | pkg.STAGE_GAIN)
+        want = O.gain_control(x.reshape(-1), N, 2, 0.5, 1.0 / 50000.0, 0.0).reshape(x.shape)
+        assert np.array_equal(y.view(np.uint32), want.view(np.uint32))
+        assert np.array_equal(y, x * np.float32(np.float32(1.0 / 50000.0) * np.float32(0.5)))
+    finally:
+        md.close()
