@@ -96,9 +96,9 @@ DABGPU_API int dabgpu_set_gain(dabgpu_ctx *ctx, int gain_mode, float digital, fl
  *     the reference approximates, 5.8 ... 6.2e-7 from ITS scalar, one kernel per chain call.
  *   DABGPU_GAIN_ROUNDING_REFERENCE: the reference's recurrence operation for operation, as the stand-alone stage
  *     (dabgpu_gain_process) does: the frame kernel stops after OfdmGenerator, a kernel of four lanes per symbol replays the
- *     recurrence, the symbols are scaled in place and the guard interval / FIRFilter run as kernels of their own.  The gain
+ *     recurrence, and the guard interval / FIRFilter run as kernels of their own that scale the symbols as they read them.  The gain
  *     scalars then equal the reference's bit for bit on the same symbols (along a chain: within 2.3e-7, the recurrence's own
- *     sensitivity to the last bits of its input; chain total 2.5e-7 instead of 6.3e-7); cfg 3 runs at about a quarter of its rate.
+ *     sensitivity to the last bits of its input; chain total 2.5e-7 instead of 6.3e-7); cfg 3 runs at about 30 % of its rate.
  * No effect on gain modes fix and max (their scalars are exact either way).  Takes effect at the next *_process call. */
 enum { DABGPU_GAIN_ROUNDING_EXACT = 0, DABGPU_GAIN_ROUNDING_REFERENCE = 1 };
 DABGPU_API int dabgpu_set_gain_rounding(dabgpu_ctx *ctx, int rounding);

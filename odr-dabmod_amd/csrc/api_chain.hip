@@ -214,8 +214,8 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
     a.overlap = (int)c->cur.overlap;
     const bool replay = gain_replay(c, mask);
     if (replay) {
-        // OfdmGenerator (+ CFR) alone, then the reference's recurrence on the unscaled symbols and the multipliers applied in
-        // place (src/GainControl.cpp:118-155), then guard interval / FIRFilter as kernels of their own
+        // OfdmGenerator (+ CFR) alone, then the reference's recurrence on the unscaled symbols (src/GainControl.cpp:118-155), then
+        // guard interval / FIRFilter as kernels of their own, which scale the symbols as they read them
         flags &= ~(unsigned)TF_GAIN;
         a.gain1 = nullptr;
         const int nsym = c->g.nb_symbols + 1;
@@ -233,15 +233,19 @@ int run_native(dabgpu_ctx *c, const void *d_in, bool from_bits, size_t n_frames,
         if (noguard && native != nsymN) return fail(c, DABGPU_E_DEVICE, "gain rounding: unexpected frame stride");
         HIPCHK(c, launch_tf(a, flags, s));
         HIPCHK(c, c->d_gains.reserve(n_frames * (size_t)nsym * sizeof(float)));
-        HIPCHK(c, launch_gain_replay(x0, n_frames, nsym, c->g.N, a.gain, (float *)c->d_gains.p, from_bits ? gain1 : nullptr, s));
+        // (the multipliers are applied by the guard kernel as it gathers the symbols; a chain that stops here scales in place)
+        const float *gains = (const float *)c->d_gains.p;
+        HIPCHK(c, launch_gain_replay(x0, n_frames, nsym, c->g.N, a.gain, (float *)c->d_gains.p, from_bits ? gain1 : nullptr,
+                                     noguard, s));
         if (noguard) return DABGPU_OK;
         if (mask & DABGPU_STAGE_FIR)
             HIPCHK(c, launch_guard_fir(x0, n_frames, c->g, (int)c->cur.overlap, (const float *)c->d_window.p,
-                                       c->cur.taps.data(), (int)c->cur.taps.size(), native_out, s));
+                                       c->cur.taps.data(), (int)c->cur.taps.size(), native_out, s, gains));
         else if (c->cur.overlap > 0)
-            HIPCHK(c, launch_guard_window(x0, n_frames, c->g, (int)c->cur.overlap, (const float *)c->d_window.p, native_out, s));
+            HIPCHK(c, launch_guard_window(x0, n_frames, c->g, (int)c->cur.overlap, (const float *)c->d_window.p, native_out, s,
+                                          gains));
         else
-            HIPCHK(c, launch_guard_copy(x0, n_frames, c->g, native_out, s));
+            HIPCHK(c, launch_guard_copy(x0, n_frames, c->g, native_out, s, gains));
         return DABGPU_OK;
     }
     if (!windowed) {

@@ -120,17 +120,19 @@ hipError_t launch_diff_mod(const float2 *phase, const float2 *data, size_t nsym_
 hipError_t launch_gain(const float2 *in, size_t nsym, int N, GainParams gp, float2 *out,
                        hipStream_t s);
 // gain mode var with the reference's running recurrence (chain calls under dabgpu_set_gain_rounding(ctx, 1)): x0 holds
-// n_frames x nsym unscaled symbols of N samples; scaled in place, the multipliers left in gains[n_frames * nsym]
+// n_frames x nsym unscaled symbols of N samples; the multipliers are left in gains[n_frames * nsym] (symbol 1's also in gain1[frame]
+// when given); apply: scale the symbols in place -- or leave that to the guard kernels below (their `gains` argument)
 hipError_t launch_gain_replay(float2 *x0, size_t n_frames, int nsym, int N, GainParams gp, float *gains, float *gain1,
-                              hipStream_t s);
+                              bool apply, hipStream_t s);
+// (gains: optional, n_frames x (nb_symbols + 1) multipliers applied to the symbols as they are gathered -- symbol 0 with symbol 1's)
 hipError_t launch_guard_copy(const float2 *in, size_t n_frames, Geometry g, float2 *out,
-                             hipStream_t s);
+                             hipStream_t s, const float *gains = nullptr);
 hipError_t launch_guard_window(const float2 *in, size_t n_frames, Geometry g, int overlap,
-                               const float *window, float2 *out, hipStream_t s);
+                               const float *window, float2 *out, hipStream_t s, const float *gains = nullptr);
 // guard interval (copy or windowed) + FIR in one pass over the IFFT output ((nb_symbols+1) x N per frame).
 // For this and launch_fir, `taps` is a HOST pointer to ntaps floats: they travel as a kernel argument.
 hipError_t launch_guard_fir(const float2 *in, size_t n_frames, Geometry g, int overlap, const float *window,
-                            const float *taps, int ntaps, float2 *out, hipStream_t s);
+                            const float *taps, int ntaps, float2 *out, hipStream_t s, const float *gains = nullptr);
 hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, const float *taps,
                       int ntaps, float2 *out, hipStream_t s);
 hipError_t launch_poly(const float2 *in, size_t nsamples, const float *am, const float *pm,

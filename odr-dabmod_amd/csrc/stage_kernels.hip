@@ -179,8 +179,8 @@ template <int LOGN> __global__ void gain_kernel(const cf *__restrict__ in, size_
 // unscaled symbols in memory (sixteen 16-byte segments per load, every line read twice and served by the cache the
 // second time) -- and gain_apply_kernel scales the symbols in place before the guard interval / FIRFilter kernels.
 // gains[frame * nsym + s] = scalar(symbol s) * constant, the two roundings of src/GainControl.cpp:146-155.
-__global__ void gain_replay_kernel(const cf *__restrict__ x0, size_t total_syms, int N, GainParams gp,
-                                   float *__restrict__ gains)
+__global__ void gain_replay_kernel(const cf *__restrict__ x0, size_t total_syms, int nsym, int N, GainParams gp,
+                                   float *__restrict__ gains, float *__restrict__ gain1)
 {
     const size_t sym = (size_t)blockIdx.x * 16 + (threadIdx.x >> 2);
     const bool on = sym < total_syms;
@@ -191,13 +191,16 @@ __global__ void gain_replay_kernel(const cf *__restrict__ x0, size_t total_syms,
 #pragma clang fp contract(off)
         g = gv * gp.constant;
     }
-    if (on && (threadIdx.x & 3) == 0) gains[sym] = g;
+    if (on && (threadIdx.x & 3) == 0) {
+        gains[sym] = g;
+        // the multiplier of symbol 1 (what the null symbol -- TII -- is scaled by, src/GainControl.cpp:139-144)
+        if (gain1 && (int)(sym % (size_t)nsym) == (nsym > 1 ? 1 : 0)) gain1[sym / (size_t)nsym] = g;
+    }
 }
 
-// x[frame][s][n] *= gains[frame][s], symbol 0 with symbol 1's (src/GainControl.cpp:139-144); gain1[frame] = the multiplier
-// of symbol 1 (what the TII null symbol is scaled by).  Four samples per lane.
-__global__ void gain_apply_kernel(cf *__restrict__ x0, size_t n_frames, int nsym, int N, const float *__restrict__ gains,
-                                  float *__restrict__ gain1)
+// x[frame][s][n] *= gains[frame][s], symbol 0 with symbol 1's (src/GainControl.cpp:139-144).  Four samples per lane.  (Chains that
+// stop at GainControl; with a guard interval behind it the guard kernels below take the multipliers as they gather.)
+__global__ void gain_apply_kernel(cf *__restrict__ x0, size_t n_frames, int nsym, int N, const float *__restrict__ gains)
 {
     const size_t per_sym = (size_t)N / 4;                 // lanes per symbol
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,7 +209,6 @@ __global__ void gain_apply_kernel(cf *__restrict__ x0, size_t n_frames, int nsym
     const int s = (int)(symi % (size_t)nsym);
     const int src = (s == 0 && nsym > 1) ? 1 : s;
     const float g = gains[f * (size_t)nsym + (size_t)src];
-    if (gain1 && s == (nsym > 1 ? 1 : 0) && i % per_sym == 0) gain1[f] = g;
     float4 *q = reinterpret_cast<float4 *>(x0 + symi * (size_t)N) + 2 * (i % per_sym);
     float4 a = q[0], b = q[1];
     a.x *= g; a.y *= g; a.z *= g; a.w *= g;
@@ -224,32 +226,43 @@ DEV void guard_locate(const Geometry &g, int p, int &s, int &o)
     else { s = 1 + (p - g.null_size) / g.sym_size; o = (p - g.null_size) % g.sym_size; }
 }
 
-DEV cf guard_copy_at(const cf *__restrict__ x0, const Geometry &g, int s, int o)
+// Sample n of symbol s, times the symbol's multiplier where the caller has a table of them (gs: one frame's nsym multipliers
+// from gain_replay_kernel; symbol 0 takes symbol 1's) -- the product rounded by itself, as GainControl's output is before the
+// guard interval sees it.
+DEV cf guard_sample(const cf *__restrict__ x0, const Geometry &g, const float *__restrict__ gs, int s, int n)
+{
+#pragma clang fp contract(off)
+    const cf x = x0[(size_t)s * (size_t)g.N + (size_t)n];
+    if (!gs) return x;
+    const float m = gs[(s == 0 && g.nb_symbols > 0) ? 1 : s];
+    return mk(x.x * m, x.y * m);
+}
+
+DEV cf guard_copy_at(const cf *__restrict__ x0, const Geometry &g, int s, int o, const float *__restrict__ gs = nullptr)
 {
     const int cpl = (s == 0 ? g.null_size : g.sym_size) - g.N;
     const int n = o < cpl ? g.N - cpl + o : o - cpl;
-    return x0[(size_t)s * (size_t)g.N + (size_t)n];
+    return guard_sample(x0, g, gs, s, n);
 }
 
 // Raised-cosine overlap W > 0 (src/GuardIntervalInserter.cpp:149-300): every output sample is its
 // own symbol's sample times a window factor, plus (inside 2W-wide seams) one neighbour term.
 // Products and the sum are rounded separately, as in the reference.
 DEV cf guard_window_at(const cf *__restrict__ x0, const Geometry &g, int W, const float *__restrict__ win, int s,
-                       int o)
+                       int o, const float *__restrict__ gs = nullptr)
 {
 #pragma clang fp contract(off)  // products and sums rounded separately, like the reference
     const int N = g.N, nsym = g.nb_symbols + 1;
     const int seg = s == 0 ? g.null_size : g.sym_size;
     const int cpl = seg - N;
-    const cf *x = x0 + (size_t)s * (size_t)N;
     const bool last = (s == nsym - 1);
     if (s >= 1 && o < W) {
         // overwritten first by the previous symbol's suffix (1/2 -> 0), then += own rising edge
-        const cf *xp = x - N;
         const float fs = win[W - 1 - o];
-        cf r = mk(xp[o].x * fs, xp[o].y * fs);
+        const cf xq = guard_sample(x0, g, gs, s - 1, o);
+        cf r = mk(xq.x * fs, xq.y * fs);
         const float fr = win[W + o];
-        const cf xr = x[N - cpl + o];
+        const cf xr = guard_sample(x0, g, gs, s, N - cpl + o);
         const float pr_ = xr.x * fr, pi_ = xr.y * fr;
         return mk(r.x + pr_, r.y + pi_);
     }
@@ -258,19 +271,19 @@ DEV cf guard_window_at(const cf *__restrict__ x0, const Geometry &g, int W, cons
         // falling half window 1 -> 1/2, then the next symbol's rising edge is added
         const int i2 = o - (seg - W);
         const float ff = win[2 * W - 1 - i2];
-        const cf r = mk(x[n].x * ff, x[n].y * ff);
-        const cf *xn = x + N;
+        const cf xc = guard_sample(x0, g, gs, s, n);
+        const cf r = mk(xc.x * ff, xc.y * ff);
         const int cpn = g.sym_size - N;
-        const cf xr = xn[N - cpn - W + i2];
+        const cf xr = guard_sample(x0, g, gs, s + 1, N - cpn - W + i2);
         const float fr = win[i2];
         const float pr_ = xr.x * fr, pi_ = xr.y * fr;
         return mk(r.x + pr_, r.y + pi_);
     }
-    return x[n];
+    return guard_sample(x0, g, gs, s, n);
 }
 
 __global__ void guard_copy_kernel(const cf *__restrict__ in, size_t n_frames, Geometry g,
-                                  cf *__restrict__ out)
+                                  cf *__restrict__ out, const float *__restrict__ gains)
 {
     const size_t tf = (size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -278,11 +291,12 @@ __global__ void guard_copy_kernel(const cf *__restrict__ in, size_t n_frames, Ge
     const size_t f = i / tf;
     int s, o;
     guard_locate(g, (int)(i - f * tf), s, o);
-    out[i] = guard_copy_at(in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N, g, s, o);
+    out[i] = guard_copy_at(in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N, g, s, o,
+                           gains ? gains + f * (size_t)(g.nb_symbols + 1) : nullptr);
 }
 
 __global__ void guard_window_kernel(const cf *__restrict__ in, size_t n_frames, Geometry g, int W,
-                                    const float *__restrict__ win, cf *__restrict__ out)
+                                    const float *__restrict__ win, cf *__restrict__ out, const float *__restrict__ gains)
 {
     const size_t tf = (size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size;
     const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -290,7 +304,8 @@ __global__ void guard_window_kernel(const cf *__restrict__ in, size_t n_frames, 
     const size_t f = i / tf;
     int s, o;
     guard_locate(g, (int)(i - f * tf), s, o);
-    out[i] = guard_window_at(in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N, g, W, win, s, o);
+    out[i] = guard_window_at(in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N, g, W, win, s, o,
+                             gains ? gains + f * (size_t)(g.nb_symbols + 1) : nullptr);
 }
 
 // a9 FIRFilter stand-alone (src/FIRFilter.cpp:162-192): LDS-tiled look-ahead FIR,
@@ -337,7 +352,7 @@ void fir_kernel(const cf *__restrict__ in, size_t frame_samples, const FirTaps<N
 // goes to HBM (1.57 MB written + 1.57 MB read per Mode-I frame less).
 template <int NTP> __global__ __launch_bounds__(256)
 void guard_fir_kernel(const cf *__restrict__ in, Geometry g, int W, const float *__restrict__ win,
-                      const FirTaps<NTP> taps, cf *__restrict__ out)
+                      const FirTaps<NTP> taps, cf *__restrict__ out, const float *__restrict__ gains)
 {
     constexpr int R = 8, TILE = 256 * R;
     __shared__ cf sb[fir_pad(TILE + NTP + R + 8) + 1];
@@ -345,6 +360,7 @@ void guard_fir_kernel(const cf *__restrict__ in, Geometry g, int W, const float 
     const int tf = g.null_size + g.nb_symbols * g.sym_size;
     const int base = (int)blockIdx.x * TILE;
     const cf *x0 = in + f * (size_t)(g.nb_symbols + 1) * (size_t)g.N;
+    const float *gs = gains ? gains + f * (size_t)(g.nb_symbols + 1) : nullptr;
     // The lane's samples are 256 apart: locate the first one, then step (no division per sample).
     // All gathers are issued before the first LDS store, so the lane waits for memory once, not per sample.
     constexpr int LIMIT = TILE + NTP + R + 8, KMAX = (LIMIT + 255) / 256;
@@ -356,7 +372,7 @@ void guard_fir_kernel(const cf *__restrict__ in, Geometry g, int W, const float 
         const int p = base + (int)threadIdx.x + 256 * k;
         fetched[k] = mk(0.f, 0.f);
         if (p < tf && (int)threadIdx.x + 256 * k < LIMIT)
-            fetched[k] = W > 0 ? guard_window_at(x0, g, W, win, sg, og) : guard_copy_at(x0, g, sg, og);
+            fetched[k] = W > 0 ? guard_window_at(x0, g, W, win, sg, og, gs) : guard_copy_at(x0, g, sg, og, gs);
         og += 256;
         for (int len = sg == 0 ? g.null_size : g.sym_size; og >= len; len = g.sym_size) { og -= len; ++sg; }
     }
@@ -475,33 +491,34 @@ hipError_t launch_gain(const float2 *in, size_t nsym, int N, GainParams gp, floa
 }
 
 hipError_t launch_gain_replay(float2 *x0, size_t n_frames, int nsym, int N, GainParams gp, float *gains, float *gain1,
-                              hipStream_t s)
+                              bool apply, hipStream_t s)
 {
     const size_t total = n_frames * (size_t)nsym;
     if (total == 0) return hipSuccess;
-    DABGPU_LAUNCH(gain_replay_kernel, dim3(blocks_for(total, 16)), dim3(64), 0, s, x0, total, N, gp, gains);
-    DABGPU_LAUNCH(gain_apply_kernel, dim3(blocks_for(total * (size_t)(N / 4), 256)), dim3(256), 0, s, x0, n_frames, nsym, N,
-                  gains, gain1);
+    DABGPU_LAUNCH(gain_replay_kernel, dim3(blocks_for(total, 16)), dim3(64), 0, s, x0, total, nsym, N, gp, gains, gain1);
+    if (apply)
+        DABGPU_LAUNCH(gain_apply_kernel, dim3(blocks_for(total * (size_t)(N / 4), 256)), dim3(256), 0, s, x0, n_frames, nsym,
+                      N, gains);
     return hipGetLastError();
 }
 
 hipError_t launch_guard_copy(const float2 *in, size_t n_frames, Geometry g, float2 *out,
-                             hipStream_t s)
+                             hipStream_t s, const float *gains)
 {
     const size_t n = n_frames * ((size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size);
     if (n == 0) return hipSuccess;
     DABGPU_LAUNCH(guard_copy_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, n_frames, g,
-                       out);
+                       out, gains);
     return hipGetLastError();
 }
 
 hipError_t launch_guard_window(const float2 *in, size_t n_frames, Geometry g, int overlap,
-                               const float *window, float2 *out, hipStream_t s)
+                               const float *window, float2 *out, hipStream_t s, const float *gains)
 {
     const size_t n = n_frames * ((size_t)g.null_size + (size_t)g.nb_symbols * (size_t)g.sym_size);
     if (n == 0) return hipSuccess;
     DABGPU_LAUNCH(guard_window_kernel, dim3(blocks_for(n, 256)), dim3(256), 0, s, in, n_frames,
-                       g, overlap, window, out);
+                       g, overlap, window, out, gains);
     return hipGetLastError();
 }
 
@@ -528,7 +545,7 @@ hipError_t launch_fir(const float2 *in, size_t frame_samples, size_t n_frames, c
 }
 
 hipError_t launch_guard_fir(const float2 *in, size_t n_frames, Geometry g, int overlap, const float *window,
-                            const float *taps, int ntaps, float2 *out, hipStream_t s)
+                            const float *taps, int ntaps, float2 *out, hipStream_t s, const float *gains)
 {
     if (n_frames == 0) return hipSuccess;
     if (ntaps < 1 || ntaps > kMaxTapsUnfused) return hipErrorInvalidValue;
@@ -537,15 +554,15 @@ hipError_t launch_guard_fir(const float2 *in, size_t n_frames, Geometry g, int o
     if (ntaps <= 48) {
         FirTaps<48> t{};
         std::copy(taps, taps + ntaps, t.t);
-        DABGPU_LAUNCH(guard_fir_kernel<48>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+        DABGPU_LAUNCH(guard_fir_kernel<48>, grid, dim3(256), 0, s, in, g, overlap, window, t, out, gains);
     } else if (ntaps <= 128) {
         FirTaps<128> t{};
         std::copy(taps, taps + ntaps, t.t);
-        DABGPU_LAUNCH(guard_fir_kernel<128>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+        DABGPU_LAUNCH(guard_fir_kernel<128>, grid, dim3(256), 0, s, in, g, overlap, window, t, out, gains);
     } else {
         FirTaps<512> t{};
         std::copy(taps, taps + ntaps, t.t);
-        DABGPU_LAUNCH(guard_fir_kernel<512>, grid, dim3(256), 0, s, in, g, overlap, window, t, out);
+        DABGPU_LAUNCH(guard_fir_kernel<512>, grid, dim3(256), 0, s, in, g, overlap, window, t, out, gains);
     }
     return hipGetLastError();
 }

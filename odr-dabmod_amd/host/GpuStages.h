@@ -411,7 +411,7 @@ public:
         // back itself, see dabmod_file --batch --reference-latency).
         unsigned emulatePipelineDrops = 0;
         // Gain mode var: form the multiplier by the reference's running fp32 recurrence (src/GainControl.cpp:251-340)
-        // instead of the exact variance -- the reference's scalars bit for bit on the same symbols, at about a quarter of
+        // instead of the exact variance -- the reference's scalars bit for bit on the same symbols, at about 30 % of
         // the chain's rate (dabgpu_set_gain_rounding).  Off by default.
         bool referenceGainRounding = false;
         unsigned referencePipelineDepth() const
