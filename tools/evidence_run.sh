@@ -13,7 +13,9 @@ bash tools/profile_all.sh $tag > $G/profile_all_$tag.log 2>&1
 bash tools/profile_variants.sh ${tag}v > $G/profile_variants_$tag.log 2>&1
 bash tools/prof_modes.sh 2>&1 | noids > $G/${tag}_modes_counters.txt
 cd $R
+t0=$SECONDS
 python bench.py > $G/${tag}_bench_line.json 2> $G/${tag}_bench_line.err
+echo "python bench.py (default flags): $((SECONDS - t0)) s wall" > $G/${tag}_bench_wall.txt
 python tools/time_host_path.py 2>&1 | noids > $G/host_path.txt
 python tools/time_host_path.py s16 2>&1 | noids > $G/host_path_s16.txt
 python tools/time_small.py 2>&1 | noids > $G/time_small.txt
@@ -22,3 +24,4 @@ python tools/time_gain_rounding.py 4096 2>&1 | noids > $G/${tag}_gain_rounding_r
 python -m pytest tests -m gpu -q > $G/final_tests.log 2>&1
 tail -3 $G/final_tests.log
 tail -c 600 $G/${tag}_bench_line.json
+cat $G/${tag}_bench_wall.txt
