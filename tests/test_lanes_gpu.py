@@ -643,3 +643,103 @@ def test_cfr_statistics_are_those_of_the_most_recent_call_whichever_lane(pkg):
     # (the MER symbol rotates with the frames a context has seen, src/OfdmGenerator.cpp:198,250: another symbol of the same
     # frame after four chain frames -- the same power to a few ulps, not the same sum)
     assert abs(a["mer_sum_iq"] - b["mer_sum_iq"]) < 1e-5 * a["mer_sum_iq"]
+
+
+_STRESS_OPS = int(__import__("os").environ.get("DABGPU_STRESS_OPS", "160"))     # (a one-off hunt: DABGPU_STRESS_OPS=3000)
+
+
+def _stress_settings(rs):
+    """One remote-control action of the kind that rewrites device tables or changes which kernels run."""
+    k = rs.randint(8)
+    if k == 0:
+        gm, dg = int(rs.choice([0, 1, 2])), float(rs.choice([1.0, 0.8]))
+        return "gain %d %.1f" % (gm, dg), lambda md: md.set_gain(gm, dg, 0.5, 4.0)
+    if k == 1:
+        on, comb, pat = bool(rs.randint(2)), int(rs.randint(1, 24)), int(rs.randint(0, 70))
+        return "tii %d %d %d" % (on, comb, pat), lambda md: md.set_tii(on, comb, pat, False)
+    if k == 2:
+        on, clip = bool(rs.randint(2)), float(rs.choice([45.0, 60.0]))
+        return "cfr %d %.0f" % (on, clip), lambda md: md.set_cfr(on, clip, 0.2)
+    if k == 3:
+        w = int(rs.choice([0, 0, 10, 24]))
+        return "window %d" % w, lambda md: md.set_window_overlap(w)
+    if k == 4:
+        fmt = rs.choice([None, "s16", "u8"])
+        fmt = None if fmt is None else str(fmt)
+        return "format %s" % fmt, lambda md: md.set_output_format(fmt)
+    if k == 5:
+        n = int(rs.choice([45, 13, 101]))
+        taps = None if n == 45 else (np.hanning(n) / np.hanning(n).sum()).astype(np.float32)
+        return "taps %d" % n, lambda md: md.set_fir_taps(taps)
+    if k == 6:
+        ref = bool(rs.randint(2))
+        return "gain rounding %d" % ref, lambda md: md.set_gain_rounding(ref)
+    direct = bool(rs.randint(2))
+    return "boundary mode %d" % direct, lambda md: md.set_fir_boundary_mode(direct)
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_operation_sequences_on_three_lanes_equal_the_serial_context(pkg, seed):
+    """A differential stress of the ordering rules of section 4.5: ONE random sequence of chain calls (1 ... 16 frames, with and
+    without FIRFilter) and remote-control actions (gain, TII, CFR, window, output format, taps, gain rounding, boundary mode)
+    runs twice -- on a context with three lanes, every call queued on the context's own stream and nothing waited for until
+    the end; and on a one-lane context that is synchronised after every call.  Every call must leave the same BYTES: a
+    setting changed while batches are in flight on other lanes (tables rewritten, the TII segment rebuilt, scratch reused)
+    may neither tear an earlier batch nor miss a later one, and the stream state (TII frame parity, the CFR statistics'
+    rotating symbol) must advance call by call."""
+    import torch
+    rs = np.random.RandomState(9000 + seed)
+    per = O.tf_input_bytes(1)
+    pool = torch.from_numpy(np.frombuffer(rs.bytes(16 * per), np.uint8).reshape(16, per).copy()).cuda()
+    ops = []
+    for _ in range(_STRESS_OPS):
+        if rs.rand() < 0.3:
+            ops.append(("set",) + _stress_settings(rs))
+        else:
+            B = int(rs.choice([1, 1, 2, 3, 5, 16]))
+            ops.append(("call", B, int(rs.randint(0, 16 - B + 1)), int(rs.choice([1, 3, 3]))))
+    results = {}
+    for lanes in (3, 1):
+        md = pkg.Modulator(mode=1, max_frames=16)
+        try:
+            md.set_lanes(lanes)
+            md.set_gain(2, 1.0, 0.5, 4.0)
+            # every output buffer first, and torch's zero fills DONE before the first call: the library's lanes are streams of
+            # their own, which torch's stream is not ordered against (dabgpu_wait_for_stream exists for callers that need it)
+            outs, fmt = [], None
+            for op in ops:
+                if op[0] == "set":
+                    if op[1].startswith("format"):
+                        fmt = None if op[1].endswith("None") else op[1].split()[1]
+                    continue
+                n = op[1] * 196608
+                outs.append(torch.zeros(n, dtype=torch.complex64, device="cuda") if fmt is None else
+                            torch.zeros(2 * n, dtype=torch.int16 if fmt == "s16" else torch.uint8, device="cuda"))
+            torch.cuda.synchronize()
+            j = 0
+            for op in ops:
+                if op[0] == "set":
+                    op[2](md)
+                    continue
+                _, B, at, stages = op
+                md.chain_dev_queued(pool[at:at + B], B, stages, outs[j])
+                j += 1
+                if lanes == 1:
+                    md.synchronize()
+            md.synchronize()
+            results[lanes] = outs
+        finally:
+            md.close()
+    assert len(results[1]) == len(results[3]) > 0
+    calls = [op for op in ops if op[0] == "call"]
+    trail = []
+    j = 0
+    for op in ops:
+        if op[0] == "set":
+            trail.append(op[1])
+            continue
+        a, b = results[3][j], results[1][j]
+        assert a.dtype == b.dtype and a.numel() == b.numel()
+        assert bool((_u32(a) == _u32(b)).all()) if a.dtype == torch.complex64 else bool((a == b).all()), \
+            (j, calls[j][1:], trail[-6:])
+        j += 1
