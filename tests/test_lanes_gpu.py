@@ -645,7 +645,7 @@ def test_cfr_statistics_are_those_of_the_most_recent_call_whichever_lane(pkg):
     assert abs(a["mer_sum_iq"] - b["mer_sum_iq"]) < 1e-5 * a["mer_sum_iq"]
 
 
-_STRESS_OPS = int(__import__("os").environ.get("DABGPU_STRESS_OPS", "160"))     # (a one-off hunt: DABGPU_STRESS_OPS=3000)
+_STRESS_OPS = int(__import__("os").environ.get("DABGPU_STRESS_OPS", "600"))     # (a one-off hunt: DABGPU_STRESS_OPS=3000)
 
 
 def _stress_settings(rs):
