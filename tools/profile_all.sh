@@ -9,7 +9,7 @@ R=$GRAFT_REPO_ROOT
 cd /tmp && export TMPDIR=/tmp
 top=$R/gpurun_out/prof_$tag
 mkdir -p $top
-rocprofv3 --kernel-trace --stats -d $top/bench_stats -o stats -- python $R/bench.py --frames $B3 --steps 5 --warmup 1 --no-extra --no-cpu-baseline > $top/bench_under_rocprof.json 2> $top/bench_stats.log
+rocprofv3 --kernel-trace --stats -d $top/bench_stats -o stats -- python $R/bench.py --frames $B3 --steps 20 --warmup 5 --no-extra --no-cpu-baseline > $top/bench_under_rocprof.json 2> $top/bench_stats.log
 python3 - <<PYEOF > $top/bench_stats_summary.txt 2>&1
 import glob, sqlite3
 for f in glob.glob("$top/bench_stats/**/*.db", recursive=True):
