@@ -292,6 +292,11 @@ def test_fused_plugin_remote_control_through_the_reference_registry(tmp_path):
          ["--normalise", repr(NORM), "--cfr", "40,0.2"]),
         ("tii", ["--fir", "default", "--normalise", repr(NORM)], [("tii", "comb", "5"), ("tii", "pattern", "11"), ("tii", "enable", "1")],
          ["--fir", "default", "--normalise", repr(NORM), "--tii", "5,11"]),
+        # with the reference's gain recurrence inside the chain (gpuReferenceGain): the split path follows the remote control as well
+        ("refgain_var", ["--fir", "default", "--normalise", repr(NORM), "--reference-gain", "1"], [("gain", "var", "3.0"), ("gain", "digital", "0.7")],
+         ["--fir", "default", "--normalise", repr(NORM), "--reference-gain", "1", "--var", "3.0", "--digital", "0.7"]),
+        ("refgain_mode", ["--fir", "default", "--normalise", repr(NORM), "--reference-gain", "1", "--gainmode", "fix"], [("gain", "mode", "var")],
+         ["--fir", "default", "--normalise", repr(NORM), "--reference-gain", "1"]),
     ]
     at = 16
     for name, opts0, actions, opts1 in cases:
