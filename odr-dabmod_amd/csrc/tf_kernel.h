@@ -350,7 +350,11 @@ void tf_kernel(const TfArgs a)
 #ifdef DABGPU_STORE_AUX
     constexpr int kStoreAux = DABGPU_STORE_AUX;
 #else
-    constexpr int kStoreAux = FROM_BITS ? 2 : 0;
+    // (Mode III, round 6: its symbols are 319 samples and a store instruction covers 256 bytes per frame -- one whole line and two
+    // halves; streamed out non-temporally the halves reach memory unmerged.  Plain stores: 0.370 -> 0.404 of the roofline, same box;
+    // Mode II, 512 bytes per store, is indifferent, Mode IV keeps nt: profiles/r06_store_policy_modes.txt.  Regrouping the two
+    // frames' slots by v_permlane32_swap so that a store instruction writes 512 contiguous bytes of ONE frame: -1.5 %, not kept.)
+    constexpr int kStoreAux = (FROM_BITS && LOGN != 8) ? 2 : 0;
 #endif
     auto put = [&](int soff, int voff, cf y) __attribute__((always_inline)) {
         if constexpr (OFMT == 1) {
