@@ -30,6 +30,13 @@ int Node::process()
 Flowgraph::~Flowgraph()
 {
     if (m_show_time) std::fputs(processTimeReport().c_str(), stderr);
+    // Node -> Edge -> Node is a cycle of shared_ptr (the reference's Node keeps the edges' BUFFERS, src/Flowgraph.h:43-75, and has
+    // none): without this the nodes -- and the plugins they hold -- outlived the graph, a pipelined plugin's worker thread was never
+    // joined, and the last frames were still being worked on while main() returned and the HIP runtime shut down (round 6: 5 of
+    // 500 runs of `host_selftest cfg4` ended in SIGSEGV or an exception from a worker thread).
+    for (auto &n : m_nodes) n->dropEdges();
+    m_edges.clear();
+    m_nodes.clear();
 }
 
 std::shared_ptr<Node> Flowgraph::nodeFor(const std::shared_ptr<ModPlugin> &p)

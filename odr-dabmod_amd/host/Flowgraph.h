@@ -22,6 +22,8 @@ public:
     void addOutputEdge(std::shared_ptr<Edge> e) { m_out.push_back(std::move(e)); }
     int process();
     double processTimeUs() const { return m_time_us; }
+    // (a node's edges point back at it: the graph lets go of them when it is destroyed, Flowgraph::~Flowgraph)
+    void dropEdges() { m_in.clear(); m_out.clear(); }
 
 private:
     std::shared_ptr<ModPlugin> m_plugin;
