@@ -195,8 +195,11 @@ void tf_kernel(const TfArgs a)
     // small read-only tables copied to LDS once: read through global memory they compile to
     // vector loads (the output stores may alias them), and every such load drags an
     // s_waitcnt vmcnt(0) -- i.e. a wait for the previous symbol's stores -- into the loop
-    float *taps_l = reinterpret_cast<float *>(bitbuf + NH * (FROM_BITS ? 2 * kBitStride : 0));
-    bitbuf += hoff(2 * kBitStride);
+    // PAIR (Mode I equalised kernels, round 6): four block slots, block d in slot d & 3, fetched two blocks at a time (below)
+    constexpr bool PAIR = VAR.pair;
+    constexpr int kBitBlocks = PAIR ? 4 : 2;
+    float *taps_l = reinterpret_cast<float *>(bitbuf + NH * (FROM_BITS ? kBitBlocks * kBitStride : 0));
+    bitbuf += hoff(kBitBlocks * kBitStride);
     // (BWIN, HALVES: the boundary filter holds its taps in registers -- no tap table; the 512 bytes are what lets an eleventh
     // Mode III workgroup onto a CU)
     constexpr int kTapsL = VAR.bwin ? 0 : kMaxTaps, kMagL = 160;
@@ -420,6 +423,40 @@ void tf_kernel(const TfArgs a)
     // (I dword j -> slot 2 j, Q dword j -> slot 2 j + 1; kBitWords = dummy slot)
     const int bit_slot = t < kBitWords / 2 ? 2 * t : (t < kBitWords ? 2 * (t - kBitWords / 2) + 1 : kBitWords);
 
+    // PAIR: the vector load of the prefetch shares its in-order counter (vmcnt) with the stores, so waiting for it is waiting for every
+    // store of the previous iteration (profiles/r06_prefetch_wait_bound.txt: +4.7 % with the wait out of the loop).  Two consecutive
+    // blocks -- 192 contiguous dwords, one per lane of the first three waves -- are fetched on every EVEN symbol and parked behind its
+    // transform; the odd symbol in between neither loads nor waits.  Block d lives in slot d & 3: pair p = blocks 2p, 2p + 1.
+    static_assert(!PAIR || (T >= 2 * kBitWords && FROM_BITS), "PAIR: a lane per dword of two blocks");
+    // (the lane's block, dword and LDS slot inside a pair are re-derived from its index where they are used -- a handful of integer
+    // instructions every other symbol -- instead of living in three lane registers across the loop: the kernel sits at 128)
+    auto pair_lane = [&](int &b, int &j, int &slot) __attribute__((always_inline)) {
+        int tl = t;
+        asm volatile("" : "+v"(tl));
+        b = (tl >= kBitWords && tl < 2 * kBitWords) ? 1 : 0;
+        j = tl - b * kBitWords;
+        slot = tl < 2 * kBitWords ? b * kBitStride + (j < kBitWords / 2 ? 2 * j : 2 * (j - kBitWords / 2) + 1) : kBitWords;
+        if (tl >= 2 * kBitWords) j = 0;
+    };
+    // The load and its wait are written out (inline assembly, tied through the loaded register): left to the compiler, the symbol
+    // that does NOT fetch inherits "this register may have a load in flight" where the two paths meet and waits there all the same
+    // -- for nothing of its own, i.e. for the previous iteration's stores, which is the wait this exists to halve.
+    auto fetch_pair = [&](int pr) __attribute__((always_inline)) -> uint32_t {
+        int b, j, slot;
+        pair_lane(b, j, slot);
+        const int blk = min(max(2 * pr + b, 0), G::nb_symbols - 2);
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(fbits + (size_t)blk * (size_t)(K / 4)) + j;
+        uint32_t w;
+        asm volatile("global_load_dword %0, %1, off" : "=v"(w) : "v"(src));
+        return w;
+    };
+    auto park_pair = [&](int pr, uint32_t w) __attribute__((always_inline)) {
+        int b, j, slot;
+        pair_lane(b, j, slot);
+        asm volatile("s_waitcnt vmcnt(0)" : "+v"(w));
+        bitbuf[2 * (pr & 1) * kBitStride + slot] = w;
+    };
+
     // the lane's 6 active carriers of symbol s
     // MAG_IN_GAIN (the equalised-boundary variant with GainControl: every sample of the symbol is scaled by g after the
     // transform anyway): the symbol's common carrier magnitude |y_s| is not applied to the twelve carrier components here but
@@ -516,7 +553,15 @@ void tf_kernel(const TfArgs a)
             }
         }
         // stage the block of the first symbol (block s_begin-2) into bitbuf[0]
-        bitbuf[bit_slot] = fetch_block(s_begin - 2);   // (clamped; unused when the loop starts at s <= 1)
+        if constexpr (PAIR) {
+            // the pair that holds the first symbol's block -- and the next pair as well when that block is the pair's second one
+            // (the even symbol that would have fetched it is not part of this run)
+            const int d_first = max(max(s_begin, 1) - 2, 0), p0 = d_first >> 1;
+            park_pair(p0, fetch_pair(p0));
+            if (d_first & 1) park_pair(p0 + 1, fetch_pair(p0 + 1));
+        } else {
+            bitbuf[bit_slot] = fetch_block(s_begin - 2);   // (clamped; unused when the loop starts at s <= 1)
+        }
     }
 
     // f-3 crest-factor reduction of one symbol held 8 samples per lane (reference
@@ -1070,8 +1115,13 @@ void tf_kernel(const TfArgs a)
         uint32_t pf = 0u;
         if (FROM_BITS) {
             lds_barrier();                    // bitbuf[bb] written (prologue / previous iteration)
-            if (s >= 2) advance(bitbuf + bb * kBitStride);
-            pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
+            if constexpr (PAIR) {
+                if (s >= 2) advance(bitbuf + ((s - 2) & 3) * kBitStride);
+                if ((s & 1) == 0) pf = fetch_pair(s >> 1);     // blocks s, s + 1: of symbols s + 2, s + 3 (clamped past the end)
+            } else {
+                if (s >= 2) advance(bitbuf + bb * kBitStride);
+                pf = fetch_block(s - 1);            // block of symbol s+1 (clamped; unused past the end)
+            }
             load_active(s, val);
             if (GAIN && !CFR && a.gain.mode == 2) {
                 // Gain statistics without touching the time domain.  With every carrier on the
@@ -1173,7 +1223,12 @@ void tf_kernel(const TfArgs a)
             // stored: vmcnt retires in order and also counts stores, so a wait for this load placed after
             // the boundary outputs' (conditional) store has to be vmcnt(0) -- every wave would sit out the
             // full HBM write latency of that store once per symbol.  (Half bb^1 was last read an iteration ago.)
-            bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;
+            if constexpr (PAIR) {
+                // (the slots of pair (s >> 1) - 2, last read an iteration ago)
+                if ((s & 1) == 0) park_pair(s >> 1, pf);
+            } else {
+                bitbuf[(bb ^ 1) * kBitStride + bit_slot] = pf;
+            }
         }
 
         float g = 1.0f;

@@ -32,7 +32,7 @@ size_t tf_lds_bytes(int logN, unsigned flags, int nt, int overlap, int ntaps)
     const bool wf = (flags & TF_WINDOW) && (flags & TF_FIR) && !eq;
     if (eq) b += kEqElems * sizeof(float2);                                       // windows, w, d, inverse filter, window factors
     else if ((flags & TF_FIR) && !wf) b += (4 * (nt ? nt - 1 : kBnd) + (v.bwin ? 4 : 0)) * sizeof(float2);  // 2 x [tail | next head] (+ padding)
-    if (flags & TF_FROM_BITS) b += 2 * ((3 * N / 4) / 16 + 2) * sizeof(uint32_t);  // staged coded bits (kBitStride)
+    if (flags & TF_FROM_BITS) b += (v.pair ? 4 : 2) * ((3 * N / 4) / 16 + 2) * sizeof(uint32_t);  // staged coded bits (kBitStride)
     b *= nh;                                                                      // (everything so far belongs to a frame)
     b += ((v.bwin ? 0 : kMaxTaps) + 160) * sizeof(float) + 64 * sizeof(float2);  // taps (not where they live in registers), |y_s| table, unit vectors (8 rotations)
     b += 56 * sizeof(float2);                                      // twiddles of the stride-8 stage

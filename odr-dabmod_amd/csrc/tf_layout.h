@@ -28,6 +28,8 @@ struct TfVariant {
                         // work on two frames -- every per-frame LDS buffer twice, blockIdx counts pairs of frames
     bool bwin;          // modes II - IV, the packed dual transform with the default-length filter (round 6): the boundary filter works
                         // from a register window (four outputs x twelve taps per lane); its sample buffers carry four slots of padding
+    bool pair;          // Mode I equalised-boundary kernels (round 6): the coded bits are prefetched two symbols' blocks at a time -- four
+                        // block slots in LDS instead of two -- so that the wait behind the previous iteration's stores comes every other symbol
     int waves_per_simd; // asked of the register allocator (HIP: the second __launch_bounds__ argument)
 };
 constexpr TfVariant tf_variant(int logn, bool from_bits, bool gain, bool guard, bool fir, int nt, bool cfr, bool gvar,
@@ -41,6 +43,7 @@ constexpr TfVariant tf_variant(int logn, bool from_bits, bool gain, bool guard, 
     v.dual = fir && !eq && !v.cfr_seq;
     v.bwin = logn != 11 && fir && nt == 45 && !cfr && !win && !eq;
     v.halves = logn == 8 && from_bits && guard && fir && nt == 45 && !cfr && !gvar && ofmt == 0 && !win && !eq;
+    v.pair = eq && logn == 11;
     // EQ: 4 (128 VGPRs, 29 KB of LDS: four workgroups per CU); modes II - IV: 3 (their one- and two-wave workgroups are limited by
     //   the windows' LDS before that, and at 128 registers they spill)
     // CFR: 4 where it is built lean, 3 on the other coded-bits chains with the guard interval that keep one transform live, else 2
