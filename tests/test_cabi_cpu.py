@@ -166,3 +166,16 @@ def test_power_probe_picks_the_devices_own_card_or_refuses(tmp_path, monkeypatch
     assert probe.cards == [cards[1]] and probe.by == "pci"
     r = probe.measure(busy((1350, 900, 255)), interval=0.0)
     assert r["watts_avg"] == 900.0
+
+
+def test_hand_written_prefetch_of_the_pair_kernels_is_not_touched_before_its_wait():
+    """The Mode I equalised kernels fetch the coded bits of two symbols with an inline `global_load_dword` and wait for it with an
+    inline `s_waitcnt vmcnt(0)` tied to the loaded register (tf_kernel.h: fetch_pair / park_pair) -- the compiler's own wait-count
+    bookkeeping does not see that load, so nothing it emits may read or move the register in between.  Checked on the device
+    assembly of every instantiation (tools/check_pair_prefetch_asm.py; hipcc cross-compiles here)."""
+    import subprocess
+    import sys
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "check_pair_prefetch_asm.py")], capture_output=True, text=True,
+                       timeout=900)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "prefetch loads checked" in r.stdout and " ok" in r.stdout
