@@ -1018,6 +1018,91 @@ void tf_kernel(const TfArgs a)
         }
     };
 
+    // PIPELINED boundary (round 6; Mode I, no windowing): the two steps of a boundary -- d = g (*) w, then y = z_prev + taps (*) d --
+    // were two dependent LDS round trips with a barrier between them, on three of the four waves, per symbol (a quarter of a wave's
+    // iteration by the phase stamps).  Step 2 of boundary b needs nothing of symbol b + 1, but it can WAIT for it: iteration s now
+    // runs step 1 of its own boundary and step 2 of the PREVIOUS one side by side -- independent, their LDS reads in flight together,
+    // no barrier between them (d of the previous boundary was written an iteration ago).  d and the 44 tail samples of z_prev
+    // that step 2 adds are double-buffered (eq_d: [d0 | d1 | tails0 | tails1], 44 each); the last boundary of a run is finished
+    // behind the loop (eq_boundary_flush).  Same arithmetic, same order: the samples do not change.
+    constexpr bool kPipeB = EQ && !WIN && LOGN == 11 && OFMT == 0;     // (the integer-store forms spill with it)
+    [[maybe_unused]] int pb_pos = -1;         // stream position of the pending boundary's outputs (none: -1); its buffers: eq_d half cur ^ 1
+    auto eq_step2_pending = [&](int par) __attribute__((always_inline)) -> cf {
+        const int i = min(t >> 2, C - 1), q = t & 3;
+        const float *tq = taps_l + (C - i) + q;
+        const cf *dq = eq_d + 44 * par + q;
+        cf y = mk(0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 11; ++k) y = axpy(y, tq[4 * k], dq[4 * k]);
+        quad_sum2_dpp(y.x, y.y);
+        return cadd(y, eq_d[88 + 44 * par + i]);
+    };
+    auto eq_store_pending = [&](cf y) __attribute__((always_inline)) {
+        const int i = min(t >> 2, C - 1);
+        if (TII_IN && tii_on && pb_pos == len0 - C) {         // (the null symbol's boundary outputs: plus the TII segment's)
+            const cf ts = a.tii_seg[len0 - C + i];
+            y = mk(fmaf(g1s, ts.x, y.x), fmaf(g1s, ts.y, y.y));
+        }
+        if (t < 4 * C && (t & 3) == 0) put(pb_pos, t >> 2, y);
+    };
+    auto eq_boundary_pipelined = [&](const cf *zp) __attribute__((always_inline)) {
+        constexpr int kEqR = 4, kEqLanes = 16 * (44 / kEqR);                   // 176
+        cf acc[4] = {mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f), mk(0.f, 0.f)};
+        // (the pending boundary's step 2 first -- two registers to carry -- then this boundary's step 1: no barrier, and the reads of
+        // the one behind the arithmetic of the other)
+        cf ypend = mk(0.f, 0.f);
+        if (t < kEqLanes) {
+            ypend = eq_step2_pending(cur ^ 1);
+            const int m0 = kEqR * (t >> 4), j0 = 10 * (t & 15);
+            const cf *wp = eq_w + (m0 + (kEqTaps - 1 - 9) - j0);
+            const float2 *g2 = reinterpret_cast<const float2 *>(g_l + j0);
+            cf wv[kEqR + 9];
+            float gg[10];
+#pragma unroll
+            for (int i = 0; i < kEqR + 9; ++i) wv[i] = wp[i];
+#pragma unroll
+            for (int u = 0; u < 5; ++u) { const float2 g = g2[u]; gg[2 * u] = g.x; gg[2 * u + 1] = g.y; }
+#pragma unroll
+            for (int u = 0; u < 10; ++u)
+#pragma unroll
+                for (int r = 0; r < kEqR; ++r) acc[r] = axpy(acc[r], gg[u], wv[r + 9 - u]);
+        }
+#define DABGPU_DPP6(CTRL)                                                                       \
+        "v_add_f32_dpp %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %4, %4, %4 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %5, %5, %5 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define DABGPU_DPP2(CTRL)                                                                       \
+        "v_add_f32_dpp %6, %6, %6 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                      \
+        "v_add_f32_dpp %7, %7, %7 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+        asm volatile("s_nop 1\n\t"
+                     DABGPU_DPP6("quad_perm:[1,0,3,2]") DABGPU_DPP2("quad_perm:[1,0,3,2]")
+                     DABGPU_DPP6("quad_perm:[2,3,0,1]") DABGPU_DPP2("quad_perm:[2,3,0,1]")
+                     DABGPU_DPP6("row_ror:4") DABGPU_DPP2("row_ror:4") DABGPU_DPP6("row_ror:8") DABGPU_DPP2("row_ror:8")
+                     : "+v"(acc[0].x), "+v"(acc[0].y), "+v"(acc[1].x), "+v"(acc[1].y), "+v"(acc[2].x), "+v"(acc[2].y),
+                       "+v"(acc[3].x), "+v"(acc[3].y));
+#undef DABGPU_DPP6
+#undef DABGPU_DPP2
+        if (t < kEqLanes && (t & 15) == 0) {
+#pragma unroll
+            for (int r = 0; r < kEqR; ++r) eq_d[44 * cur + kEqR * (t >> 4) + r] = acc[r];
+        }
+        // the 44 samples of z_prev this boundary's step 2 will add -- kept, the window they come from is rewritten by then
+        // (the lanes behind the 176: otherwise idle here)
+        if (t >= kEqLanes && t < kEqLanes + 44) eq_d[88 + 44 * cur + (t - kEqLanes)] = zp[kEqQL - C + (t - kEqLanes)];
+        if (pb_pos >= 0 && t < kEqLanes) eq_store_pending(ypend);
+        pb_pos = prev_pos + prev_seg - C;                      // this boundary becomes the pending one (the caller flips `cur`)
+    };
+    // the pending boundary's step 2 behind the loop (a barrier first: its d was written in the last iteration)
+    auto eq_boundary_flush = [&]() __attribute__((always_inline)) {
+        if (pb_pos < 0) return;
+        lds_barrier();
+        eq_store_pending(eq_step2_pending(cur ^ 1));
+        pb_pos = -1;
+    };
+
     // The same for transmission mode IV (round 6; no windowing, no TII -- modes III and IV have none --, complexf output): the
     // workgroup has 128 lanes, the 176 lane-jobs of either step are done in two passes.  (Kept apart from the Mode I form above so
     // that the headline kernel's instruction stream is exactly what it was.)
@@ -1465,7 +1550,11 @@ void tf_kernel(const TfArgs a)
         }
         pt.stamp(PH_STORES);
         if constexpr (EQ) {
-            if (have_prev) { if constexpr (LOGN == 11) eq_boundary(eq_zp + cur * kEqW, false); else eq_boundary_small(eq_zp + cur * kEqW); }
+            if (have_prev) {
+                if constexpr (kPipeB) eq_boundary_pipelined(eq_zp + cur * kEqW);
+                else if constexpr (LOGN == 11) eq_boundary(eq_zp + cur * kEqW, false);
+                else eq_boundary_small(eq_zp + cur * kEqW);
+            }
             cur ^= 1;
             pt.stamp(PH_BOUNDARY);
             if (lookahead) break;
@@ -1484,6 +1573,7 @@ void tf_kernel(const TfArgs a)
             }
         }
     }
+    if constexpr (kPipeB) eq_boundary_flush();
     if (EQ && s_end == nsym && have_prev) {
         // end of the frame: nothing follows (a zero symbol: w = -z_prev), missing terms are dropped
         const cf *zp = eq_zp + cur * kEqW;

@@ -8,7 +8,7 @@ namespace dabgpu {
 // their difference against the current one (kEqWLen each), the unfiltered differences d (kEqDLen), the inverse filter
 // (kEqTaps + 8 floats), the raised-cosine factors of the windowed form (2 kEqWinMax floats)
 constexpr int kEqWinMax = 10;      // widest overlap the equalised-boundary variant windows itself: 2 x 10 + 44 = 64 boundary outputs
-constexpr int kEqWLen = 240, kEqDLen = 80;
+constexpr int kEqWLen = 240, kEqDLen = 176;    // (d: 80 used by the windowed form; 2 x 44 differences + 2 x 44 tails by the pipelined boundary)
 constexpr int kEqElems = 3 * kEqWLen + kEqDLen + (kEqTaps + 8) / 2 + 16;
 constexpr int kWinMax = 128;       // widest raised-cosine overlap the frame kernel applies itself (TF_WINDOW)
 constexpr int kBnd = 128;          // LDS slots per boundary buffer; the fused FIR handles ntaps <= kBnd
